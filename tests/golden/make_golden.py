@@ -1,0 +1,307 @@
+"""Generate golden fixtures by importing the reference IN THE BUILD CONTAINER.
+
+Run (CPU only, a few minutes):   python tests/golden/make_golden.py [case ...]
+
+Writes ``tests/golden/*.npz`` -- arrays only (inputs, weights, expected outputs / grads).
+No reference source, bytecode or pickled reference object is stored.  ``/root/reference``
+does not exist on the GPU box, so nothing outside this script reads it.
+
+Shims: the reference tree imports ``models.*`` although its
+directory is ``model/`` (D1), and imports packages that are absent here (``seaborn``,
+``reformer_pytorch``; D13).  They are satisfied with in-memory stub modules; nothing is
+written into the read-only reference tree (``sys.dont_write_bytecode``).
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+from argparse import Namespace
+
+sys.dont_write_bytecode = True
+REF = "/root/reference/InterpretGatedNetwork"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+import numpy as np
+import torch
+
+
+def import_reference():
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for name, attrs in (("seaborn", {}), ("reformer_pytorch", {"LSHSelfAttention": object})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for k, v in attrs.items():
+                setattr(m, k, v)
+            sys.modules[name] = m
+    import model  # noqa: the reference's directory name
+    sys.modules["models"] = model
+    import importlib
+    for sub in ("Shapelet", "FullyConvNet", "Transformer", "InterpGN", "eegcnn"):
+        sys.modules[f"models.{sub}"] = importlib.import_module(f"model.{sub}")
+    return {s: sys.modules[f"models.{s}"] for s in ("Shapelet", "FullyConvNet", "Transformer", "InterpGN", "eegcnn")}
+
+
+def cfg(**kw):
+    base = dict(enc_in=6, seq_len=100, num_class=4, epsilon=1.0, distance_func='euclidean',
+                memory_efficient=False, sbm_cls='linear', dropout=0.0, lambda_reg=0.1, lambda_div=0.1,
+                dnn_type='FCN', task_name='classification', pred_len=0, label_len=0, output_attention=False,
+                d_model=64, embed='timeF', freq='h', factor=1, n_heads=4, d_ff=128, activation='gelu',
+                e_layers=2, c_out=4, dec_in=6, d_layers=1,
+                eegcnn_layers=2, eegcnn_pooling='mean', eegcnn_dropout1=0.0, eegcnn_dropout2=0.0,
+                eegcnn_n_heads=8, eegcnn_d_ff=256)
+    base.update(kw)
+    return Namespace(**base)
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def sd_np(model, prefix="sd."):
+    return {prefix + k: npy(v) for k, v in model.state_dict().items()}
+
+
+def grads_np(model, prefix="grad."):
+    return {prefix + k: npy(p.grad) for k, p in model.named_parameters() if p.grad is not None}
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (np.asarray(v)) for k, v in arrs.items()})
+    print(f"wrote {path}  ({os.path.getsize(path)/1e6:.2f} MB)")
+
+
+# ------------------------------------------------------------------------------------
+def case_shapelet_modes(R):
+    """Shapelet.forward for every distance branch + LTS, tiny shape, with grad of sum(p*r)."""
+    S = R["Shapelet"]
+    B, C, T, K, L = 3, 4, 60, 3, 9
+    g = torch.Generator().manual_seed(11)
+    xn = torch.randn(B, C, T, generator=g)
+    r = torch.randn(B, K * C, generator=g)
+    for name, dfunc, lts in (("l1", "euclidean", False), ("cos", "cosine", False),
+                             ("pearson", "pearson", False), ("lts", "euclidean", True)):
+        torch.manual_seed(5)
+        cls = S.DistThresholdShapelet if lts else S.Shapelet
+        m = cls(dim_data=C, shapelet_len=L, num_shapelet=K, stride=1, eps=0.7, distance_func=dfunc)
+        p, dmin = m(xn)
+        (p * r).sum().backward()
+        out = dict(xn=npy(xn), r=npy(r), w=npy(m.weights), eps=np.float32(0.7), p=npy(p), dmin=npy(dmin),
+                   grad_w=npy(m.weights.grad))
+        if lts:
+            out.update(thr=npy(m.threshold), grad_thr=npy(m.threshold.grad))
+        save(f"shapelet_{name}", **out)
+    # MSE (ShapeletDistanceFunc called on raw (B,C,T): the only way it is correct)
+    torch.manual_seed(5)
+    w = torch.normal(0, 1, (K, C, L)).requires_grad_(True)
+    d = S.ShapeletDistance(xn, w)                      # (B,Tw,K,C)
+    eps = 0.7
+    p = torch.exp(-torch.pow(eps * d, 2))
+    hard = torch.zeros_like(p).scatter_(1, p.argmax(dim=1, keepdim=True), 1.)
+    soft = torch.softmax(p, dim=1)
+    maxp = torch.sum((hard + soft - soft.detach()) * p, dim=1).flatten(1)
+    (maxp * r).sum().backward()
+    save("shapelet_mse", xn=npy(xn), r=npy(r), w=npy(w), eps=np.float32(eps), p=npy(maxp),
+         dmin=npy(d.min(dim=1).values.flatten(1)), grad_w=npy(w.grad), d_full=npy(d))
+
+
+def case_shapelet_bm(R):
+    """Driver-default IGN groups at the BasicMotions shape (C=6,T=100): K=5, L={10,20,30,50}."""
+    S = R["Shapelet"]
+    B, C, T = 8, 6, 100
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, T, C, generator=g) * 2.0 + 0.5
+    xn = x.permute(0, 2, 1)
+    xn = (xn - xn.mean(dim=-1, keepdims=True)) / (xn.std(dim=-1, keepdims=True) + 1e-8)
+    out = dict(x=npy(x), xn=npy(xn))
+    for gi, L in enumerate((10, 20, 30, 50)):
+        torch.manual_seed(100 + gi)
+        m = S.Shapelet(dim_data=C, shapelet_len=L, num_shapelet=5, stride=1, eps=1.0)
+        r = torch.randn(B, 5 * C, generator=g)
+        p, dmin = m(xn)
+        (p * r).sum().backward()
+        out.update({f"w{gi}": npy(m.weights), f"r{gi}": npy(r), f"p{gi}": npy(p), f"dmin{gi}": npy(dmin),
+                    f"grad_w{gi}": npy(m.weights.grad)})
+    save("shapelet_bm", **out)
+
+
+def _run_model(model, x, y, model_name, gating_value=None, train=True):
+    model.train(train)
+    res = model(x, torch.ones(x.shape[0], x.shape[1]), None, None) if gating_value is None else \
+        model(x, torch.ones(x.shape[0], x.shape[1]), None, None, gating_value=gating_value)
+    return res
+
+
+def case_sbm(R):
+    """SBM heads (linear / bilinear / attention) and LTS at BM shape with the 6x10 groups."""
+    S = R["Shapelet"]
+    B = 8
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, 100, 6, generator=g)
+    y = torch.arange(B) % 4
+    lens = [0.05, 0.1, 0.2, 0.3, 0.5, 0.8]
+    for name, cls_name, sbm_cls in (("sbm_linear", "ShapeBottleneckModel", "linear"),
+                                    ("sbm_bilinear", "ShapeBottleneckModel", "bilinear"),
+                                    ("sbm_attention", "ShapeBottleneckModel", "attention"),
+                                    ("lts", "DistThresholdSBM", "linear")):
+        c = cfg(sbm_cls=sbm_cls)
+        torch.manual_seed(0)
+        nshp = 10 if sbm_cls != "bilinear" else 2       # bilinear weight is (N, F, F): keep F small
+        m = getattr(S, cls_name)(configs=c, num_shapelet=[nshp] * 6, shapelet_len=lens)
+        m.train()
+        out, info = m(x)
+        loss = torch.nn.functional.cross_entropy(out, y) + info.loss.mean()
+        loss.backward()
+        save(name, x=npy(x), y=npy(y), num_shapelet=np.int64(nshp), out=npy(out), p=npy(info.p), d=npy(info.d),
+             model_loss=npy(info.loss), train_loss=npy(loss), **sd_np(m), **grads_np(m))
+
+
+def case_ign(R):
+    """InterpGN(FCN) at BM shape: outputs, ModelInfo, training loss, all grads, gating_value test path."""
+    I = R["InterpGN"]
+    B = 8
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, 100, 6, generator=g)
+    y = torch.arange(B) % 4
+    c = cfg()
+    torch.manual_seed(0)
+    m = I.InterpGN(c)
+    m.train()
+    out, info = m(x, torch.ones(B, 100), None, None)
+    ce = torch.nn.functional.cross_entropy
+    loss = ce(out, y) + info.loss.mean() + 1.0 * ce(info.shapelet_preds, y)
+    loss.backward()
+    arrs = dict(x=npy(x), y=npy(y), out=npy(out), eta=npy(info.eta), shapelet_preds=npy(info.shapelet_preds),
+                dnn_preds=npy(info.dnn_preds), p=npy(info.p), d=npy(info.d), model_loss=npy(info.loss),
+                train_loss=npy(loss), **grads_np(m))
+    sd_after = sd_np(m, "sd_after.")                 # BN running stats after one train-mode forward
+    m.eval()
+    with torch.no_grad():
+        out_e, info_e = m(x, torch.ones(B, 100), None, None)
+        out_g, info_g = m(x, torch.ones(B, 100), None, None, gating_value=0.05)
+    arrs.update(eval_out=npy(out_e), eval_eta=npy(info_e.eta), gated_out=npy(out_g), gated_eta=npy(info_g.eta))
+    torch.manual_seed(0)
+    m0 = I.InterpGN(c)
+    save("ign_fcn_bm", **arrs, **sd_np(m0), **sd_after)
+
+
+def case_ign_ch(R):
+    """InterpGN(FCN) at the full CHISCO shape (C=122,T=1000,N=3), B=2 (~7.5 GB peak)."""
+    I = R["InterpGN"]
+    B = 2
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(B, 1000, 122, generator=g)
+    y = torch.tensor([2, 0])
+    c = cfg(enc_in=122, seq_len=1000, num_class=3, c_out=3)
+    torch.manual_seed(0)
+    m = I.InterpGN(c)
+    sd0 = sd_np(m)
+    m.train()
+    out, info = m(x, torch.ones(B, 1000), None, None)
+    ce = torch.nn.functional.cross_entropy
+    loss = ce(out, y) + info.loss.mean() + ce(info.shapelet_preds, y)
+    loss.backward()
+    gr = grads_np(m)
+    # keep the fixture small: shapelet / head grads in full, FCN grads as float32 too (1.5 MB)
+    save("ign_fcn_ch", x=npy(x), y=npy(y), out=npy(out), eta=npy(info.eta), shapelet_preds=npy(info.shapelet_preds),
+         dnn_preds=npy(info.dnn_preds), p=npy(info.p), d=npy(info.d), model_loss=npy(info.loss),
+         train_loss=npy(loss), **sd0, **gr)
+
+
+def case_train_steps(R):
+    """3 Adam steps (lr 5e-3) of the reference's training step for InterpGN(FCN) at BM shape (+ pos_weight clamp)."""
+    I = R["InterpGN"]
+    ce = torch.nn.functional.cross_entropy
+    for tag, pos_weight in (("", False), ("_posw", True)):
+        c = cfg()
+        torch.manual_seed(0)
+        m = I.InterpGN(c)
+        sd0 = sd_np(m, "sd0.")
+        opt = torch.optim.Adam(m.parameters(), lr=5e-3)
+        g = torch.Generator().manual_seed(61)
+        xs = torch.randn(3, 8, 100, 6, generator=g)
+        ys = torch.randint(0, 4, (3, 8), generator=g)
+        losses = []
+        m.train()
+        for i in range(3):
+            out, info = m(xs[i], torch.ones(8, 100), None, None)
+            loss = ce(out, ys[i]) + info.loss.mean() + 1.0 * ce(info.shapelet_preds, ys[i])
+            loss.backward()
+            opt.step()
+            if pos_weight:
+                m.step()
+            opt.zero_grad()
+            losses.append(loss.item())
+        save("train_step_ign" + tag, xs=npy(xs), ys=npy(ys), losses=np.array(losses, dtype=np.float64),
+             **sd0, **sd_np(m, "sd3."))
+
+
+def case_transformer(R):
+    """Transformer-encoder baseline (d_model 64, 4 heads, d_ff 128, 2 layers) + the attention core alone."""
+    T = R["Transformer"]
+    from layers.SelfAttention_Family import FullAttention
+    B = 4
+    c = cfg()
+    torch.manual_seed(0)
+    m = T.Model(c)
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(B, 100, 6, generator=g)
+    mask = torch.ones(B, 100)
+    mask[1, 80:] = 0.
+    y = torch.arange(B) % 4
+    m.train()
+    out = m(x, mask, None, None)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    save("transformer_bm", x=npy(x), mask=npy(mask), y=npy(y), out=npy(out), loss=npy(loss), **sd_np(m), **grads_np(m))
+    # attention core
+    q = torch.randn(2, 37, 3, 16, generator=g, requires_grad=True)
+    k = torch.randn(2, 53, 3, 16, generator=g, requires_grad=True)
+    v = torch.randn(2, 53, 3, 16, generator=g, requires_grad=True)
+    go = torch.randn(2, 37, 3, 16, generator=g)
+    o, _ = FullAttention(False, 1, attention_dropout=0.0)(q, k, v, None)
+    (o * go).sum().backward()
+    save("attention_core", q=npy(q), k=npy(k), v=npy(v), go=npy(go), o=npy(o), gq=npy(q.grad), gk=npy(k.grad), gv=npy(v.grad))
+
+
+def case_eegcnn(R):
+    """EEG-CNN baseline: working semantics are (B,C,T) input and NO mask; dropouts 0."""
+    E = R["eegcnn"]
+    B, C, T = 4, 122, 1000
+    c = cfg(enc_in=C, seq_len=T, num_class=3, c_out=3, d_model=128)   # d_model 128 keeps the fixture ~3 MB
+    g = torch.Generator().manual_seed(81)
+    x = torch.randn(B, C, T, generator=g)
+    y = torch.tensor([0, 1, 2, 1])
+    sink = io.StringIO()
+    with contextlib.redirect_stdout(sink):
+        torch.manual_seed(0)
+        m = E.EEGCNNTransformer(c)
+        sd0 = sd_np(m)
+        m.train()
+        out, _ = m(x)
+        feat = m.eegcnn(x)
+        loss = torch.nn.functional.cross_entropy(out, y)
+        loss.backward()
+        gr = grads_np(m)
+        sd_after = {k: v for k, v in sd_np(m, "sd_after.").items() if "running" in k}
+        m.eval()
+        with torch.no_grad():
+            out_e, _ = m(x)
+    # drop the 2x (5000,512) positional buffers from the fixture: they are deterministic sin/cos tables
+    sd0 = {k: v for k, v in sd0.items() if not k.endswith("pos_encoder.pe")}
+    save("eegcnn_ch", x=npy(x), y=npy(y), out=npy(out), feat=npy(feat), loss=npy(loss), eval_out=npy(out_e),
+         **sd0, **gr, **sd_after)
+
+
+CASES = dict(shapelet_modes=case_shapelet_modes, shapelet_bm=case_shapelet_bm, sbm=case_sbm, ign=case_ign,
+             ign_ch=case_ign_ch, train_steps=case_train_steps, transformer=case_transformer, eegcnn=case_eegcnn)
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    R = import_reference()
+    names = sys.argv[1:] or list(CASES)
+    for n in names:
+        print(f"== {n}")
+        CASES[n](R)
