@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: epochs/sec of IGN 3-class training on synthetic CHISCO-shaped EEG
+(B=256 per GPU, C=122, T=1000; N_train=8192 samples per epoch) -- BASELINE.json's metric.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one optimizer step of the training hot path (IGN/exp/experiment_classification.py:313-343) on one
+batch per rank: instance norm -> shapelet bank (HIP) -> SBM head + FCN expert -> gini gate -> 3-term loss ->
+backward (HIP shapelet backward) -> gradient all-reduce over RCCL (N>1) -> Adam.  Inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.nn.functional as F
+
+N_TRAIN = 8192          # samples per epoch
+PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md, "Peak FP32 (vector)"
+
+
+def ch_config(model='InterpGN', dnn_type='FCN'):
+    return Namespace(enc_in=122, seq_len=1000, num_class=3, c_out=3, epsilon=1.0, distance_func='euclidean',
+                     memory_efficient=False, sbm_cls='linear', dropout=0.0, lambda_reg=0.1, lambda_div=0.1,
+                     dnn_type=dnn_type, model=model, task_name='classification', pred_len=0, label_len=0,
+                     output_attention=False, d_model=512, embed='timeF', freq='h', factor=1, n_heads=8, d_ff=2048,
+                     activation='gelu', e_layers=2)
+
+
+def synth_batches(n_batches, B, T, C, n_class, rank, world, device):
+    """Deterministic synthetic EEG, X ~ N(0,1): batch `i` of rank `r` is seeded by its GLOBAL batch index, so the
+    global data set is the same for every world size (CPU generator)."""
+    xs, ys = [], []
+    for i in range(n_batches):
+        g = torch.Generator().manual_seed(1234 + (i * world + rank))
+        xs.append(torch.randn(B, T, C, generator=g).to(device))
+        ys.append(torch.randint(0, n_class, (B,), generator=g).to(device))
+    return xs, ys
+
+
+def shapelet_algorithmic_flops(B, C, T, groups):
+    """E = B * sum_g K*C*Tw*L element-ops; forward 2E, backward 3E flops."""
+    E = B * sum(K * C * (T - L + 1) * L for (K, L) in groups)
+    return 2 * E, 3 * E
+
+
+def cpu_baseline(cfg, sample_b, threads):
+    """The CPU oracle (a restatement of the reference path, kind="port") timed on the host: one full training step
+    (fwd + bwd + Adam) on `sample_b` samples of the same synthetic distribution."""
+    from oracle import ign_oracle as O
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    m = O.OracleIGN(cfg, chunk=8)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=5e-3)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(sample_b, cfg.seq_len, cfg.enc_in, generator=g)
+    y = torch.randint(0, cfg.num_class, (sample_b,), generator=g)
+    t0 = time.perf_counter()
+    out, info = m(x)
+    loss = O.train_loss('InterpGN', out, info, y)
+    loss.backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    return dict(value=(sample_b / dt) / N_TRAIN, unit="epochs/s", cores=threads, kind="port",
+                sample=f"1 train step (fwd+bwd+Adam) of the CPU oracle on {sample_b} samples of shape (1000,122): "
+                       f"{dt:.1f} s = {dt / sample_b:.2f} s/sample")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="samples for the CPU baseline step (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import speech_imagery_eeg_amd  # noqa: F401
+    from ign_hip import _lib
+    from ign_hip.ddp import FlatParamBucket
+    from models.InterpGN import InterpGN
+
+    cfg = ch_config()
+    B, T, C = args.batch, cfg.seq_len, cfg.enc_in
+    torch.manual_seed(0)                       # same initial replica on every rank
+    model = InterpGN(cfg).to(dev).train()
+    bucket = FlatParamBucket(model, world)     # flat fp32 grad bucket: one RCCL all-reduce per step
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3, fused=True)
+
+    n_batches = min(args.steps + args.warmup, max(1, N_TRAIN // (B * world)))
+    xs, ys = synth_batches(n_batches, B, T, C, cfg.num_class, rank, world, dev)
+    mask = torch.ones(B, T, device=dev)
+
+    def step(i):
+        x, y = xs[i % n_batches], ys[i % n_batches]
+        out, info = model(x, mask, None, None)
+        loss = F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y)
+        loss.backward()
+        bucket.allreduce()
+        opt.step()
+        bucket.zero_grad()
+        return loss.detach()
+
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    _lib.timing_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    fwd_ms, fwd_n = _lib.timing_read("shp_fwd")
+    bwd_ms, bwd_n = _lib.timing_read("shp_bwd")
+    _lib.timing_enable(False)
+
+    if rank == 0:
+        groups = [(s.n, s.length) for s in model.sbm.shapelets]
+        f_fwd, f_bwd = shapelet_algorithmic_flops(B, C, T, groups)
+        # dominant kernel: the shapelet backward (3E of the 5E shapelet flops).  One step issues one launch per
+        # length group; `achieved` aggregates the G launches of a step (algorithmic flops / measured device time).
+        bwd_tflops = (f_bwd * args.steps) / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
+        fwd_tflops = (f_fwd * args.steps) / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
+        res = {
+            "metric": "epochs/sec (B=256, C=122, T=1000) IGN 3-class",
+            "value": (args.steps * B * world / N_TRAIN) / dt,
+            "unit": "epochs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Synthetic CHISCO-shape EEG (122ch x 1000, 3-class) IGN(FCN expert), "
+                                   "driver-default groups K=5 x L{100,200,300,500}, Adam lr 5e-3, fp32",
+                       "per_gpu_batch": B, "global_batch": B * world, "samples_per_epoch": N_TRAIN,
+                       "parallelism": f"dp{world}", "final_loss": float(last)},
+            "roofline": {"bound": "valu", "kernel": "shp_bwd_kernel", "achieved": bwd_tflops,
+                         "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": bwd_tflops / PEAK_FP32_VALU_TFLOPS,
+                         "traffic": None,
+                         "ms_per_step": bwd_ms / max(1, args.steps), "launches": bwd_n,
+                         "fwd_kernel": {"kernel": "shp_fwd_kernel", "achieved": fwd_tflops,
+                                        "frac": fwd_tflops / PEAK_FP32_VALU_TFLOPS,
+                                        "ms_per_step": fwd_ms / max(1, args.steps), "launches": fwd_n}},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, os.cpu_count() or 1)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

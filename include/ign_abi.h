@@ -1,0 +1,88 @@
+/* ign_abi.h -- C ABI of libign_hip.so: the MI355X (gfx950) hot path of the Interpretability-Gated-Network.
+ *
+ * The reference (001camellia/Speech-Imagery-EEG, IGN/ = InterpretGatedNetwork/) has no FFI: its hot path is a
+ * chain of PyTorch eager ops inside Python modules.  Each entry point below replaces one such chain; the
+ * reference lines it stands in for are cited per function.  Binding side: INTEGRATION.md (ctypes).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (contiguous fp32 unless noted); the library never
+ *    allocates or frees device memory and keeps no mutable global state;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are enqueued and the call
+ *    returns immediately;
+ *  - return 0 on success; IGN_E_* (<0) on argument errors (nothing was launched); -(hipError_t) on a launch error;
+ *    ign_last_error() gives a human-readable reason for the calling thread;
+ *  - `workspace` buffers are caller-provided, sized by the matching *_workspace_bytes().
+ */
+#ifndef IGN_ABI_H
+#define IGN_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IGN_ABI_VERSION 1
+
+#define IGN_E_ARG      (-1001)  /* bad pointer / dimension                                */
+#define IGN_E_UNSUP    (-1002)  /* combination not implemented (see message)              */
+#define IGN_E_TOOBIG   (-1003)  /* a row does not fit the LDS staging budget              */
+
+/* distance / gate selectors: `mode` = IGN_DIST_* | IGN_GATE_*                                           */
+#define IGN_DIST_L1    0   /* mean |x-w|      IGN/model/Shapelet.py:74 ("euclidean", the default)        */
+#define IGN_DIST_MSE   1   /* mean (x-w)^2    IGN/model/Shapelet.py:24-40 (memory_efficient branch)      */
+#define IGN_DIST_COS   2   /* 1 - cos         IGN/model/Shapelet.py:64-66                                */
+#define IGN_DIST_PEARS 3   /* 1 - pearson     IGN/model/Shapelet.py:67-69,11-19                          */
+#define IGN_GATE_RBF   0x00 /* exp(-(eps d)^2) + straight-through max   IGN/model/Shapelet.py:77-84      */
+#define IGN_GATE_LTS   0x10 /* straight-through soft-min + sigmoid(thr - min_d)  Shapelet.py:105-111     */
+
+int         ign_abi_version(void);
+const char* ign_last_error(void);
+
+/* Instance normalisation fused with the (B,T,C) -> (B,C,T) transpose.
+ * Replaces IGN/model/Shapelet.py:186-187  (rearrange 'b t c -> b c t'; (x-mean_T)/(std_T(unbiased)+eps)).
+ * xt_bct (nullable) additionally receives the un-normalised transpose (input of the FCN expert,
+ * IGN/model/FullyConvNet.py:53).                                                                        */
+int ign_instnorm_fwd(const float* x_btc, float* xn_bct, float* xt_bct, int B, int T, int C, float eps,
+                     void* stream);
+
+/* Shapelet transform of ONE length group: sliding-window distance + gate, never materialising (B,Tw,K,C,L).
+ * Replaces IGN/model/Shapelet.py:60-84 (GATE_RBF) / :96-111 (GATE_LTS).   Tw = (T-L)/stride + 1.
+ *   xn_bct   (B,C,T)    normalised input
+ *   w_kcl    (K,C,L)    shapelets            thr_kc (K,C) LTS thresholds (NULL for RBF)
+ *   p_out    row-major (B, ld) ; this group writes columns [col0 + k*C + c]     (max_p / sigmoid gate)
+ *   dmin_out same indexing                                                       (min_t d)
+ *   tstar    (B,K,C) int32  arg-max_t p  (RBF) / arg-min_t d (LTS); first index on ties (torch.argmax)
+ *   zmu      (B,K,C,2)      {Z, mu}: RBF Z=sum_t exp(p_t), mu=sum_t softmax_t(p) p_t ;
+ *                           LTS Z=sum_t exp(-(d_t-dmin)), mu=sum_t softmin_t(d) d_t      (for backward)
+ *   d_save   (B,C,K,Tw)     every window distance, kept for the backward (NULL: not saved)              */
+int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const float* thr_kc,
+                     float* p_out, float* dmin_out, int ld, int col0,
+                     int32_t* tstar, float* zmu, float* d_save,
+                     int B, int C, int T, int K, int L, int stride, float eps, int mode, void* stream);
+
+/* Backward of the above w.r.t. the shapelets (autograd of Shapelet.py:60-84 / :96-111; closed form in
+ * SURVEY.md App. A).  g_out is dloss/dp_out with the same (ld, col0) indexing as p_out.
+ *   gw_kcl (K,C,L) receives dloss/dw (overwritten, deterministic: fixed-order two-stage reduction over B)
+ *   workspace: ign_shapelet_bwd_workspace_bytes() bytes.
+ * Gradients w.r.t. the input are not produced (inputs are data: IGN/exp/experiment_classification.py:315).
+ * LTS: dloss/dthr is a (B,KC) elementwise reduction the caller forms from g_out and p_out.             */
+size_t ign_shapelet_bwd_workspace_bytes(int B, int C, int T, int K, int L, int stride, int mode);
+int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const float* g_out, const float* p_out,
+                     const float* dmin_out, int ld, int col0,
+                     const int32_t* tstar, const float* zmu, const float* d_save,
+                     float* gw_kcl, void* workspace,
+                     int B, int C, int T, int K, int L, int stride, float eps, int mode, void* stream);
+
+/* Per-kernel HIP-event timing (measurement only; off by default).  When enabled every kernel launch made by
+ * this library is bracketed by hipEventRecord on the caller's stream.  ign_timing_read() waits for the recorded
+ * events of `label` ("shp_fwd", "shp_bwd", "reduce_parts", "instnorm"), and returns the accumulated
+ * device milliseconds and launch count since the last enable.  Not for use under graph capture.             */
+int ign_timing_enable(int on);
+int ign_timing_read(const char* label, double* total_ms, long long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IGN_ABI_H */

@@ -1,0 +1,279 @@
+// C-ABI entry points of libign_hip.so: argument validation and launch planning for the shapelet kernels.
+#include "ign_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <algorithm>
+
+static thread_local char g_err[512] = "";
+
+void ign_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ign_check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ign_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return -(int)e;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ timing
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+namespace {
+struct TimingSlot {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0.0;
+    long long launches = 0;
+};
+bool g_timing = false;
+std::mutex g_tm;
+std::map<std::string, TimingSlot> g_slots;
+void drain(TimingSlot& sl) {
+    for (auto& pr : sl.pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            sl.total_ms += ms;
+            sl.launches += 1;
+        }
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    sl.pending.clear();
+}
+}  // namespace
+
+IgnScopedTimer::IgnScopedTimer(const char* l, hipStream_t s) : label(l), stream(s), e0(nullptr), e1(nullptr), on(g_timing) {
+    if (!on) return;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(e0, stream);
+}
+IgnScopedTimer::~IgnScopedTimer() {
+    if (!on) return;
+    (void)hipEventRecord(e1, stream);
+    std::lock_guard<std::mutex> lk(g_tm);
+    g_slots[label].pending.emplace_back(e0, e1);
+}
+
+extern "C" int ign_timing_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_tm);
+    for (auto& kv : g_slots) drain(kv.second);
+    g_slots.clear();
+    g_timing = on != 0;
+    return 0;
+}
+
+extern "C" int ign_timing_read(const char* label, double* total_ms, long long* launches) {
+    if (!label || !total_ms || !launches) { ign_set_error("ign_timing_read: null argument"); return IGN_E_ARG; }
+    std::lock_guard<std::mutex> lk(g_tm);
+    auto it = g_slots.find(label);
+    if (it == g_slots.end()) { *total_ms = 0.0; *launches = 0; return 0; }
+    drain(it->second);
+    *total_ms = it->second.total_ms;
+    *launches = it->second.launches;
+    return 0;
+}
+
+extern "C" int ign_abi_version(void) { return IGN_ABI_VERSION; }
+extern "C" const char* ign_last_error(void) { return g_err; }
+
+extern shp_fwd_launch_t ign_fwd_table_p0[4][2][3];
+extern shp_fwd_launch_t ign_fwd_table_p1[4][2][3];
+extern shp_fwd_launch_t ign_fwd_table_p2[4][2][3];
+extern shp_fwd_launch_t ign_fwd_table_p3[4][2][3];
+
+shp_fwd_launch_t ign_get_fwd_launcher(int dist, int TT, int KT) {
+    if (dist < 0 || dist > 1 || TT < 1 || TT > 16) return nullptr;
+    const int ki = KT == 1 ? 0 : KT == 2 ? 1 : KT == 5 ? 2 : -1;
+    if (ki < 0) return nullptr;
+    shp_fwd_launch_t (*tabs[4])[2][3] = {ign_fwd_table_p0, ign_fwd_table_p1, ign_fwd_table_p2, ign_fwd_table_p3};
+    return tabs[(TT - 1) / 4][(TT - 1) % 4][dist][ki];
+}
+
+static int split_mode(int mode, int* dist, int* gate, const char* who) {
+    *dist = mode & 0xf;
+    *gate = (mode & IGN_GATE_LTS) ? GATE_LTS : GATE_RBF;
+    if ((mode & ~0x1f) != 0 || *dist > IGN_DIST_PEARS) {
+        ign_set_error("%s: unknown mode 0x%x", who, mode);
+        return IGN_E_ARG;
+    }
+    if (*dist != IGN_DIST_L1 && *dist != IGN_DIST_MSE) {
+        ign_set_error("%s: distance %d (cosine/pearson) is not implemented in this library version", who, *dist);
+        return IGN_E_UNSUP;
+    }
+    return 0;
+}
+
+static int check_dims(const char* who, int B, int C, int T, int K, int L, int stride) {
+    if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || L <= 0 || stride <= 0 || L > T) {
+        ign_set_error("%s: bad dimensions B=%d C=%d T=%d K=%d L=%d stride=%d", who, B, C, T, K, L, stride);
+        return IGN_E_ARG;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+extern "C" int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const float* thr_kc, float* p_out,
+                                float* dmin_out, int ld, int col0, int32_t* tstar, float* zmu, float* d_save, int B,
+                                int C, int T, int K, int L, int stride, float eps, int mode, void* stream) {
+    static const char* who = "ign_shapelet_fwd";
+    int dist, gate, rc;
+    if ((rc = split_mode(mode, &dist, &gate, who))) return rc;
+    if ((rc = check_dims(who, B, C, T, K, L, stride))) return rc;
+    if (!xn_bct || !w_kcl || !p_out || !dmin_out || !tstar || !zmu || (gate == GATE_LTS && !thr_kc)) {
+        ign_set_error("%s: null pointer argument", who);
+        return IGN_E_ARG;
+    }
+    if (ld < col0 + K * C || col0 < 0) {
+        ign_set_error("%s: output row pitch ld=%d too small for col0=%d + K*C=%d", who, ld, col0, K * C);
+        return IGN_E_ARG;
+    }
+    const int Tw = (T - L) / stride + 1;
+    // TT windows per lane: one wave pass covers the row when Tw <= 1024; strided windows use TT = 1.
+    int TT = (stride == 1) ? std::min(16, (Tw + 63) / 64) : 1;
+    const int npass = (Tw + 64 * TT - 1) / (64 * TT);
+    int xs_len = (npass * 64 * TT - 1) * stride + (TT - 1) + L;
+    xs_len = (xs_len + 3) & ~3;
+    int wpb = 4;
+    const size_t park = (npass > 1) ? (size_t)5 * 5 * 64 * 4 : 0;     // per wave: 5 stats x KT<=5 x 64 lanes
+    while (wpb > 1 && (size_t)wpb * (xs_len * 4 + park) > 64 * 1024) wpb >>= 1;
+    const size_t lds = (size_t)wpb * (xs_len * 4 + park);
+    if (lds > 64 * 1024) {
+        ign_set_error("%s: a row needs %zu bytes of LDS staging (T=%d L=%d stride=%d)", who, lds, T, L, stride);
+        return IGN_E_TOOBIG;
+    }
+    ShpFwdArgs a;
+    a.xn = xn_bct; a.w = w_kcl; a.thr = thr_kc; a.p_out = p_out; a.dmin_out = dmin_out; a.tstar = tstar; a.zmu = zmu;
+    a.d = d_save;
+    a.B = B; a.C = C; a.T = T; a.K = K; a.L = L; a.Tw = Tw; a.stride = stride; a.ld = ld; a.col0 = col0;
+    a.npass = npass; a.xs_len = xs_len; a.gate = gate; a.eps = eps; a.invL = 1.0f / (float)L;
+    const int nbg = (B + wpb - 1) / wpb;
+    // shapelets in tiles of 5, then 2, then 1 (each tile shares the x registers across its shapelets)
+    int k0 = 0;
+    static const int tiles[3] = {5, 2, 1};
+    for (int ti = 0; ti < 3; ++ti) {
+        const int KT = tiles[ti];
+        const int n = (K - k0) / KT;
+        if (n <= 0) continue;
+        shp_fwd_launch_t fn = ign_get_fwd_launcher(dist, TT, KT);
+        if (!fn) {
+            ign_set_error("%s: no kernel for TT=%d KT=%d", who, TT, KT);
+            return IGN_E_UNSUP;
+        }
+        a.k0 = k0;
+        {
+            IgnScopedTimer tm("shp_fwd", (hipStream_t)stream);
+            fn(a, dim3((unsigned)C * nbg, (unsigned)n), dim3(wpb * 64), lds, (hipStream_t)stream);
+        }
+        if ((rc = ign_check_launch("shp_fwd_kernel"))) return rc;
+        k0 += n * KT;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ backward
+struct BwdPlan {
+    int JJ, cpk, kb, nkt, threads, twpad, xs_len, nbs;
+    size_t lds;
+};
+
+static int plan_bwd(int B, int C, int T, int K, int L, int Tw, BwdPlan* p) {
+    // JJ: j's per lane.  Prefer 8 (A operand amortised over more work) unless 4 fills the waves better.
+    int best = 0;
+    double best_eff = -1.0;
+    const int cand[2] = {8, 4};
+    for (int i = 0; i < 2; ++i) {
+        const int JJ = cand[i];
+        const int cpk = (L + JJ - 1) / JJ;
+        if (cpk > 512) continue;
+        const int kb = std::max(1, std::min(K, 512 / cpk));
+        const int threads = ((kb * cpk + 63) / 64) * 64;
+        double eff = (double)kb * L / ((double)threads * JJ);
+        if (JJ == 8) eff *= 1.10;            // (3*JJ+overhead)/3*JJ: per-t overhead is amortised over JJ
+        if (eff > best_eff) { best_eff = eff; best = JJ; }
+    }
+    if (!best) return IGN_E_TOOBIG;
+    p->JJ = best;
+    p->cpk = (L + best - 1) / best;
+    p->kb = std::max(1, std::min(K, 512 / p->cpk));
+    p->nkt = (K + p->kb - 1) / p->kb;
+    p->threads = ((p->kb * p->cpk + 63) / 64) * 64;
+    p->twpad = ((Tw + IGN_BWD_TT - 1) / IGN_BWD_TT) * IGN_BWD_TT;
+    p->xs_len = (p->cpk * best + p->twpad + 3) & ~3;
+    p->lds = ((size_t)p->xs_len + (size_t)p->kb * p->twpad) * 4;
+    while (p->lds > 64 * 1024 && p->kb > 1) {       // shrink the shapelet tile until LDS fits
+        p->kb = (p->kb + 1) / 2;
+        p->nkt = (K + p->kb - 1) / p->kb;
+        p->threads = ((p->kb * p->cpk + 63) / 64) * 64;
+        p->lds = ((size_t)p->xs_len + (size_t)p->kb * p->twpad) * 4;
+    }
+    if (p->lds > 64 * 1024) return IGN_E_TOOBIG;
+    // batch slices: enough blocks to fill 256 CUs a few times over, >= 2 rows per slice when possible
+    int nbs = (2048 + C * p->nkt - 1) / (C * p->nkt);
+    nbs = std::max(1, std::min(nbs, std::max(1, B / 2)));
+    p->nbs = std::min(nbs, B);
+    return 0;
+}
+
+extern "C" size_t ign_shapelet_bwd_workspace_bytes(int B, int C, int T, int K, int L, int stride, int mode) {
+    (void)mode;
+    if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || L <= 0 || stride != 1 || L > T) return 0;
+    BwdPlan p;
+    if (plan_bwd(B, C, T, K, L, T - L + 1, &p)) return 0;
+    return (size_t)p.nbs * K * C * L * sizeof(float);
+}
+
+extern "C" int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const float* g_out, const float* p_out,
+                                const float* dmin_out, int ld, int col0, const int32_t* tstar, const float* zmu,
+                                const float* d_save, float* gw_kcl, void* workspace, int B, int C, int T, int K,
+                                int L, int stride, float eps, int mode, void* stream) {
+    static const char* who = "ign_shapelet_bwd";
+    int dist, gate, rc;
+    if ((rc = split_mode(mode, &dist, &gate, who))) return rc;
+    if ((rc = check_dims(who, B, C, T, K, L, stride))) return rc;
+    if (stride != 1) {
+        ign_set_error("%s: stride %d not implemented (the reference uses stride 1 below seq_len 3000)", who, stride);
+        return IGN_E_UNSUP;
+    }
+    if (!xn_bct || !w_kcl || !g_out || !tstar || !zmu || !d_save || !gw_kcl || !workspace ||
+        (gate == GATE_LTS && (!p_out || !dmin_out))) {
+        ign_set_error("%s: null pointer argument (d_save is required: run the forward with d_save)", who);
+        return IGN_E_ARG;
+    }
+    if (ld < col0 + K * C || col0 < 0) {
+        ign_set_error("%s: row pitch ld=%d too small for col0=%d + K*C=%d", who, ld, col0, K * C);
+        return IGN_E_ARG;
+    }
+    const int Tw = T - L + 1;
+    BwdPlan p;
+    if ((rc = plan_bwd(B, C, T, K, L, Tw, &p))) {
+        ign_set_error("%s: no launch plan for K=%d L=%d Tw=%d", who, K, L, Tw);
+        return rc;
+    }
+    shp_bwd_launch_t fn = ign_get_bwd_launcher(dist, p.JJ);
+    if (!fn) {
+        ign_set_error("%s: no kernel for JJ=%d dist=%d", who, p.JJ, dist);
+        return IGN_E_UNSUP;
+    }
+    ShpBwdArgs a;
+    a.xn = xn_bct; a.w = w_kcl; a.g = g_out; a.p = p_out; a.dmin = dmin_out; a.tstar = tstar; a.zmu = zmu; a.d = d_save;
+    a.part = (float*)workspace;
+    a.B = B; a.C = C; a.T = T; a.K = K; a.L = L; a.Tw = Tw; a.ld = ld; a.col0 = col0;
+    a.nbs = p.nbs; a.kb = p.kb; a.cpk = p.cpk; a.twpad = p.twpad; a.xs_len = p.xs_len; a.gate = gate;
+    a.eps = eps; a.invL = 1.0f / (float)L;
+    {
+        IgnScopedTimer tm("shp_bwd", (hipStream_t)stream);
+        fn(a, dim3((unsigned)C, (unsigned)p.nbs, (unsigned)p.nkt), dim3(p.threads), p.lds, (hipStream_t)stream);
+    }
+    if ((rc = ign_check_launch("shp_bwd_kernel"))) return rc;
+    IgnScopedTimer tm2("reduce_parts", (hipStream_t)stream);
+    ign_launch_reduce_parts(a.part, gw_kcl, p.nbs, (size_t)K * C * L, (hipStream_t)stream);
+    return ign_check_launch("reduce_parts_kernel");
+}

@@ -1,0 +1,70 @@
+// Shared declarations of libign_hip.so (gfx950 only; no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/ign_abi.h"
+
+#define IGN_WAVE 64
+
+// thread-local error message (ign_abi.cpp owns the storage)
+void ign_set_error(const char* fmt, ...);
+int  ign_check_launch(const char* what);
+
+// RAII bracket used around kernel launches when ign_timing_enable(1) is active (ign_abi.hip)
+struct IgnScopedTimer {
+    IgnScopedTimer(const char* label, hipStream_t s);
+    ~IgnScopedTimer();
+    const char* label; hipStream_t stream; hipEvent_t e0, e1; bool on;
+};
+
+enum { DIST_L1 = 0, DIST_MSE = 1 };
+enum { GATE_RBF = 0, GATE_LTS = 1 };
+
+// ---------------------------------------------------------------- forward
+struct ShpFwdArgs {
+    const float* xn;      // (B,C,T)
+    const float* w;       // (K,C,L)
+    const float* thr;     // (K,C) or null
+    float* p_out;         // (B,ld) + col0
+    float* dmin_out;      // (B,ld) + col0
+    int32_t* tstar;       // (B,K,C)
+    float* zmu;           // (B,K,C,2)
+    float* d;             // (B,C,K,Tw) or null
+    int B, C, T, K, L, Tw, stride, ld, col0;
+    int k0;               // first shapelet of this launch (blockIdx.y adds KT each)
+    int npass;            // passes of 64*TT windows per row
+    int xs_len;           // floats of LDS per wave (multiple of 4)
+    int gate;             // GATE_RBF / GATE_LTS
+    float eps, invL;
+};
+
+// launchers generated per (DIST, TT, KT); defined in ign_shapelet_fwd_*.hip
+typedef void (*shp_fwd_launch_t)(const ShpFwdArgs&, dim3 grid, dim3 block, size_t lds, hipStream_t);
+shp_fwd_launch_t ign_get_fwd_launcher(int dist, int TT, int KT);   // null if not instantiated
+
+// ---------------------------------------------------------------- backward
+struct ShpBwdArgs {
+    const float* xn;      // (B,C,T)
+    const float* w;       // (K,C,L)
+    const float* g;       // (B,ld)+col0 upstream grad of p_out
+    const float* p;       // (B,ld)+col0 forward gate output (LTS)
+    const float* dmin;    // (B,ld)+col0 (LTS)
+    const int32_t* tstar; // (B,K,C)
+    const float* zmu;     // (B,K,C,2)
+    const float* d;       // (B,C,K,Tw)
+    float* part;          // (nbs,K,C,L) partial sums over batch slices
+    int B, C, T, K, L, Tw, ld, col0;
+    int nbs;              // batch slices (gridDim.y)
+    int kb;               // shapelets per block (gridDim.z tiles)
+    int cpk;              // j-chunks per shapelet = ceil(L/JJ)
+    int twpad;            // Tw rounded up to TT
+    int xs_len;           // floats of x staging (multiple of 4)
+    int gate;
+    float eps, invL;
+};
+typedef void (*shp_bwd_launch_t)(const ShpBwdArgs&, dim3 grid, dim3 block, size_t lds, hipStream_t);
+shp_bwd_launch_t ign_get_bwd_launcher(int dist, int JJ);            // JJ in {4,8}
+constexpr int IGN_BWD_TT = 16;
+
+void ign_launch_reduce_parts(const float* part, float* out, int nparts, size_t n, hipStream_t s);

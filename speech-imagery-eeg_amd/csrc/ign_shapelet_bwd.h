@@ -1,0 +1,138 @@
+// Shapelet backward (dloss/dw): second sliding pass with the roles of t and j swapped.
+//
+// Autograd of IGN/model/Shapelet.py:60-84 / :96-111, closed form in SURVEY.md App. A:
+//   dl/dw[k,c,j] = sum_b sum_t  A[b,k,c,t] * sign(x[b,c,t+j] - w[k,c,j])           (L1)
+//   dl/dw[k,c,j] = sum_b sum_t A2[b,k,c,t] * (x[b,c,t+j] - w[k,c,j])                (MSE)
+// where A = -(dl/dd_t)/L and dl/dd_t follows from the saved distances d_t, the row statistics
+// {t*, Z, mu} and the upstream gradient of the gate output.
+//
+// Mapping (fp32 VALU bound, 3 ops per (b,c,k,t,j) element for L1: v_cmp, v_cndmask, v_add):
+//   * a block owns one channel c (and a tile of `kb` shapelets) and walks a slice of the batch;
+//   * lane <-> (k, chunk of JJ consecutive j): its JJ accumulators and JJ weights stay in registers for
+//     the whole batch slice, so there is NO cross-lane reduction -- only a fixed-order reduction over
+//     batch slices afterwards (deterministic, no float atomics);
+//   * per batch row the block stages x[b,c,:] and A[k,:] (computed cooperatively from d, once per
+//     (b,k,c,t)) in LDS; each lane then slides over t in steps of TT with a register window of
+//     x[jbase+t .. jbase+t+TT+JJ), reading A[k][t..t+TT) as an LDS broadcast.
+#pragma once
+#include "ign_common.h"
+
+template <int JJ, int DIST>
+__global__ void __launch_bounds__(512) shp_bwd_kernel(const ShpBwdArgs a) {
+    constexpr int TT = IGN_BWD_TT;
+    static_assert(JJ % 4 == 0 && TT % 4 == 0, "float4 LDS reads need 4-float alignment");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                       // [xs_len]
+    float* As = smem + a.xs_len;            // [kb][twpad]
+
+    const int c = blockIdx.x, bs = blockIdx.y;
+    const int kbase = blockIdx.z * a.kb;
+    const int kcount = min(a.kb, a.K - kbase);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int kl = tid / a.cpk;
+    const int jc = tid - kl * a.cpk;
+    const bool active = kl < kcount;
+    const int jbase = jc * JJ;
+
+    float wreg[JJ], acc[JJ];
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj) {
+        const int j = jbase + jj;
+        wreg[jj] = (active && j < a.L) ? a.w[((size_t)(kbase + kl) * a.C + c) * a.L + j] : INFINITY;
+        acc[jj] = 0.f;
+    }
+
+    const int b_begin = (int)(((long long)a.B * bs) / a.nbs);
+    const int b_end = (int)(((long long)a.B * (bs + 1)) / a.nbs);
+    const float two_eps2 = 2.f * a.eps * a.eps;
+
+    for (int b = b_begin; b < b_end; ++b) {
+        __syncthreads();                    // previous row fully consumed
+        {
+            const float* row = a.xn + ((size_t)b * a.C + c) * a.T;
+            for (int i = tid; i < a.xs_len; i += nthr) xs[i] = (i < a.T) ? row[i] : 0.f;
+        }
+        for (int k2 = 0; k2 < kcount; ++k2) {
+            const int k = kbase + k2;
+            const size_t sidx = ((size_t)b * a.K + k) * a.C + c;
+            const size_t col = (size_t)b * a.ld + a.col0 + (size_t)k * a.C + c;
+            const float gv = a.g[col];
+            const int ts = a.tstar[sidx];
+            const float invZ = 1.f / a.zmu[2 * sidx];
+            const float mu = a.zmu[2 * sidx + 1];
+            float gm = 0.f, dmin = 0.f;
+            if (a.gate == GATE_LTS) {
+                const float P = a.p[col];
+                gm = -gv * P * (1.f - P);       // dP/dm = -sigma'(thr - m)
+                dmin = a.dmin[col];
+            }
+            const float* drow = a.d + (((size_t)b * a.C + c) * a.K + k) * a.Tw;
+            float* Ak = As + k2 * a.twpad;
+            for (int t = tid; t < a.twpad; t += nthr) {
+                float A = 0.f;
+                if (t < a.Tw) {
+                    const float dv = drow[t];
+                    float dldd;
+                    if (a.gate == GATE_RBF) {
+                        const float u = a.eps * dv;
+                        const float p = expf(-(u * u));
+                        const float e = expf(p);
+                        const float coef = gv * ((t == ts ? 1.f : 0.f) + e * invZ * (p - mu));
+                        dldd = coef * (-two_eps2 * dv * p);
+                    } else {
+                        const float s = expf(dmin - dv) * invZ;
+                        dldd = gm * ((t == ts ? 1.f : 0.f) + s * (mu - dv));
+                    }
+                    A = (DIST == DIST_L1) ? -dldd * a.invL : -2.f * dldd * a.invL;
+                }
+                Ak[t] = A;
+            }
+        }
+        __syncthreads();
+
+        if (active) {
+            const float* Ak = As + kl * a.twpad;
+            const float* xl = xs + jbase;
+            float W[JJ + TT];
+#pragma unroll
+            for (int i = 0; i < JJ; i += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(xl + i);
+                W[i] = v.x; W[i + 1] = v.y; W[i + 2] = v.z; W[i + 3] = v.w;
+            }
+            for (int t0 = 0; t0 < a.twpad; t0 += TT) {
+                float A[TT];
+#pragma unroll
+                for (int i = 0; i < TT; i += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(xl + t0 + JJ + i);
+                    W[JJ + i] = v.x; W[JJ + i + 1] = v.y; W[JJ + i + 2] = v.z; W[JJ + i + 3] = v.w;
+                    const float4 q = *reinterpret_cast<const float4*>(Ak + t0 + i);
+                    A[i] = q.x; A[i + 1] = q.y; A[i + 2] = q.z; A[i + 3] = q.w;
+                }
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    const float av = A[t];
+                    const float nav = -av;
+#pragma unroll
+                    for (int jj = 0; jj < JJ; ++jj) {
+                        if (DIST == DIST_L1) acc[jj] += (W[t + jj] > wreg[jj]) ? av : nav;
+                        else                 acc[jj] = fmaf(av, W[t + jj] - wreg[jj], acc[jj]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < JJ; ++i) W[i] = W[i + TT];
+            }
+        }
+    }
+
+    if (active) {
+        float* out = a.part + (((size_t)bs * a.K + (kbase + kl)) * a.C + c) * a.L;
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj)
+            if (jbase + jj < a.L) out[jbase + jj] = acc[jj];
+    }
+}
+
+template <int JJ, int DIST>
+static void shp_bwd_launch(const ShpBwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((shp_bwd_kernel<JJ, DIST>), grid, block, lds, s, a);
+}

@@ -1,0 +1,225 @@
+// Shapelet forward: sliding-window distance + gate, one wavefront per (batch row, channel).
+//
+// Replaces IGN/model/Shapelet.py:60-84 (and :96-111 for the LTS gate) without materialising the
+// (B,Tw,K,C,L) broadcast.  Bound: fp32 VALU (|x-w| accumulate is not a contraction) -- 2 VALU ops per
+// (b,c,k,t,j) element; memory traffic is ~1e3x below the HBM roofline, so the design goal is an inner
+// loop that is nothing but `v_sub_f32 ; v_add_f32 |.|`:
+//   * lane l of the wave owns TT consecutive windows t = l*TT .. l*TT+TT-1 (TT = ceil(Tw/64): the whole
+//     row fits one wave pass, so the row reductions (arg-max, soft-max sums, min) are wave shuffles);
+//   * the x row is staged once in LDS (4 KB); each lane keeps a sliding register window of TT+J-1
+//     samples, so every LDS word read feeds TT*KT subtract/accumulate pairs;
+//   * all lanes share the channel, so w[k,c,j] is wave-uniform: it arrives through scalar loads and
+//     is consumed as the SGPR operand of v_sub -- no VGPR, no LDS traffic;
+//   * KT shapelets share each x register (KT*TT accumulators per lane).
+#pragma once
+#include "ign_common.h"
+
+template <int TT> struct FwdJ { static constexpr int J = (TT <= 8) ? 8 : 4; };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <int TT, int KT, int DIST>
+__global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
+    constexpr int J = FwdJ<TT>::J;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wpb = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nbg = (a.B + wpb - 1) / wpb;
+    const int c = blockIdx.x / nbg;                 // block-uniform: every wave of the block shares w[:,c,:]
+    const int bg = blockIdx.x - c * nbg;
+    int b = bg * wpb + wave;
+    const bool row_ok = b < a.B;
+    if (!row_ok) b = a.B - 1;
+    const int k0 = a.k0 + blockIdx.y * KT;
+
+    float* xs = smem + wave * a.xs_len;
+    {
+        const float* row = a.xn + ((size_t)b * a.C + c) * a.T;
+        for (int i = lane; i < a.xs_len; i += 64) xs[i] = (i < a.T) ? row[i] : 0.f;
+    }
+    __syncthreads();
+
+    const size_t wks = (size_t)a.C * a.L;
+    // w is read-only for the whole launch and its address is wave-uniform: read it through the constant
+    // address space so the loads are s_load_dword* (scalar cache) and each value is an SGPR operand.
+    typedef const __attribute__((address_space(4))) float* cfloat_p;
+    const cfloat_p wk = (cfloat_p)(uintptr_t)(a.w + ((size_t)k0 * a.C + c) * a.L);
+    const int L = a.L;
+
+    // Row statistics of this lane (merged across lanes at the end).  They are NOT kept in registers across
+    // the distance loop: rows longer than 64*TT windows (npass > 1, not the case for any T <= 1024+L)
+    // park them in LDS between passes, so the hot loop's register budget is acc + window only.
+    float r_best[KT], r_dmin[KT], r_Z[KT], r_M[KT];
+    int r_idx[KT];
+    float* park = smem + (blockDim.x >> 6) * a.xs_len + threadIdx.x;    // [5*KT][blockDim.x], npass > 1 only
+
+    for (int pass = 0; pass < a.npass; ++pass) {
+        const int tl = (pass * 64 + lane) * TT;     // first window owned by this lane
+        const float* xl = xs + tl * a.stride;       // stride != 1 only with TT == 1
+        float acc[KT][TT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc[k][t] = 0.f;
+        float xw[TT + J - 1];
+#pragma unroll
+        for (int i = 0; i < TT - 1; ++i) xw[i] = xl[i];
+
+        int j0 = 0;
+        for (; j0 + J <= L; j0 += J) {
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) xw[TT - 1 + jj] = xl[j0 + TT - 1 + jj];
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    const float wv = wk[k * wks + j0 + jj];          // wave-uniform -> s_load / SGPR operand
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) {
+                        const float df = xw[t + jj] - wv;
+                        if (DIST == DIST_L1) acc[k][t] += fabsf(df);
+                        else                 acc[k][t] = fmaf(df, df, acc[k][t]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TT - 1; ++i) xw[i] = xw[i + J];
+        }
+        for (; j0 < L; ++j0) {                      // L % J tail, one sample at a time
+            xw[TT - 1] = xl[j0 + TT - 1];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const float wv = wk[k * wks + j0];
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    const float df = xw[t] - wv;
+                    if (DIST == DIST_L1) acc[k][t] += fabsf(df);
+                    else                 acc[k][t] = fmaf(df, df, acc[k][t]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TT - 1; ++i) xw[i] = xw[i + 1];
+        }
+
+        // ---- per-pass epilogue: d = mean, gate statistics
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            if (pass == 0) {
+                r_best[k] = -INFINITY; r_dmin[k] = INFINITY; r_Z[k] = 0.f; r_M[k] = 0.f; r_idx[k] = 0x7fffffff;
+            } else {
+                r_best[k] = park[(5 * k + 0) * blockDim.x]; r_dmin[k] = park[(5 * k + 1) * blockDim.x];
+                r_Z[k] = park[(5 * k + 2) * blockDim.x];    r_M[k] = park[(5 * k + 3) * blockDim.x];
+                r_idx[k] = __float_as_int(park[(5 * k + 4) * blockDim.x]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            float* drow = a.d ? a.d + (((size_t)b * a.C + c) * a.K + (k0 + k)) * a.Tw : nullptr;
+            if (a.gate == GATE_RBF) {
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    const int tg = tl + t;
+                    if (tg < a.Tw) {
+                        const float dv = acc[k][t] * a.invL;
+                        if (drow && row_ok) drow[tg] = dv;
+                        const float u = a.eps * dv;
+                        const float p = expf(-(u * u));
+                        const float e = expf(p);
+                        r_Z[k] += e;
+                        r_M[k] = fmaf(e, p, r_M[k]);
+                        if (p > r_best[k]) { r_best[k] = p; r_idx[k] = tg; }
+                        r_dmin[k] = fminf(r_dmin[k], dv);
+                    }
+                    // keep the 2*KT*TT inlined expf bodies from being interleaved (register pressure, spills)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {                                  // LTS: soft-min over d, stabilised by the running min
+                float pmin = INFINITY;
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+                    if (tl + t < a.Tw) pmin = fminf(pmin, acc[k][t] * a.invL);
+                if (pmin < INFINITY) {
+                    // r_best holds -(running min) so the arg-min tie rule is "first index"
+                    const float mold = r_dmin[k];
+                    const float mnew = fminf(mold, pmin);
+                    const float sc = (mold < INFINITY) ? expf(mnew - mold) : 0.f;
+                    r_Z[k] *= sc; r_M[k] *= sc;
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) {
+                        const int tg = tl + t;
+                        if (tg < a.Tw) {
+                            const float dv = acc[k][t] * a.invL;
+                            if (drow && row_ok) drow[tg] = dv;
+                            const float e = expf(mnew - dv);
+                            r_Z[k] += e;
+                            r_M[k] = fmaf(e, dv, r_M[k]);
+                            if (-dv > r_best[k]) { r_best[k] = -dv; r_idx[k] = tg; }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    r_dmin[k] = mnew;
+                }
+            }
+        }
+        if (pass + 1 < a.npass) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                park[(5 * k + 0) * blockDim.x] = r_best[k]; park[(5 * k + 1) * blockDim.x] = r_dmin[k];
+                park[(5 * k + 2) * blockDim.x] = r_Z[k];    park[(5 * k + 3) * blockDim.x] = r_M[k];
+                park[(5 * k + 4) * blockDim.x] = __int_as_float(r_idx[k]);
+            }
+        }
+    }
+
+    // ---- merge the 64 lanes of the row
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        float best = r_best[k];
+        int idx = r_idx[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(idx, o, 64);
+            if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+        }
+        const float dmin = wave_min(r_dmin[k]);
+        float Z = r_Z[k], M = r_M[k];
+        if (a.gate == GATE_LTS) {
+            const float sc = (r_dmin[k] < INFINITY) ? expf(dmin - r_dmin[k]) : 0.f;
+            Z *= sc; M *= sc;
+        }
+        Z = wave_sum(Z);
+        M = wave_sum(M);
+        if (lane == 0 && row_ok) {
+            const int kk = k0 + k;
+            const size_t col = (size_t)b * a.ld + a.col0 + (size_t)kk * a.C + c;
+            const size_t sidx = ((size_t)b * a.K + kk) * a.C + c;
+            float pout;
+            if (a.gate == GATE_RBF) {
+                pout = best;                       // = p[t*] * (1 + s - s): Shapelet.py:81-82
+            } else {
+                const float th = a.thr[(size_t)kk * a.C + c];
+                pout = 1.f / (1.f + expf(-(th - dmin)));
+            }
+            a.p_out[col] = pout;
+            a.dmin_out[col] = dmin;
+            a.tstar[sidx] = idx;
+            a.zmu[2 * sidx] = Z;
+            a.zmu[2 * sidx + 1] = M / Z;
+        }
+    }
+}
+
+template <int TT, int KT, int DIST>
+static void shp_fwd_launch(const ShpFwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((shp_fwd_kernel<TT, KT, DIST>), grid, block, lds, s, a);
+}

@@ -1,0 +1,78 @@
+"""ctypes loader for libign_hip.so -- the only door between the Python host side and the HIP kernels.
+
+There is no CPU fallback: if the shared library is missing or a tensor is not on the GPU the call raises.
+Build with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C speech-imagery-eeg_amd/csrc``.
+"""
+import ctypes
+import os
+import threading
+
+_CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+_LOCK = threading.Lock()
+_LIB = None
+
+c_f = ctypes.POINTER(ctypes.c_float)
+c_i32 = ctypes.POINTER(ctypes.c_int32)
+vp, ci, cf, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/ign_abi.h declares (tests/test_abi_symbols.py)
+SIGNATURES = {
+    "ign_abi_version": (ci, []),
+    "ign_last_error": (ctypes.c_char_p, []),
+    "ign_instnorm_fwd": (ci, [vp, vp, vp, ci, ci, ci, cf, vp]),
+    "ign_shapelet_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),
+    "ign_shapelet_bwd_workspace_bytes": (sz, [ci, ci, ci, ci, ci, ci, ci]),
+    "ign_timing_enable": (ci, [ci]),
+    "ign_timing_read": (ci, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
+    "ign_shapelet_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),
+}
+
+
+class IgnError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_CSRC, "libign_hip.so")
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises IgnError if the library was not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    with _LOCK:
+        if _LIB is None:
+            path = lib_path()
+            if not os.path.exists(path):
+                raise IgnError(f"{path} not found: the HIP extension is not built "
+                               f"(run `make -C {_CSRC} -j8` or __graft_entry__.build()); there is no CPU fallback")
+            h = ctypes.CDLL(path)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(h, name)
+                fn.restype, fn.argtypes = res, args
+            if h.ign_abi_version() != 1:
+                raise IgnError(f"{path}: ABI version {h.ign_abi_version()} != 1")
+            _LIB = h
+    return _LIB
+
+
+def require():
+    return lib()
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().ign_last_error().decode("utf-8", "replace")
+        raise IgnError(f"{what} failed (rc={rc}): {msg}")
+
+
+def timing_enable(on=True):
+    lib().ign_timing_enable(1 if on else 0)
+
+
+def timing_read(label):
+    """-> (total device ms, launches) of the kernels recorded under `label` since timing_enable(True)."""
+    ms, n = ctypes.c_double(0.0), ctypes.c_longlong(0)
+    check(lib().ign_timing_read(label.encode(), ctypes.byref(ms), ctypes.byref(n)), "ign_timing_read")
+    return ms.value, n.value

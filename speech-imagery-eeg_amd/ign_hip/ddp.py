@@ -1,0 +1,65 @@
+"""Batch-sharded data parallelism for the IGN training step: one process per GPU, one flat fp32 gradient bucket,
+one RCCL all-reduce per optimizer step.
+
+The reference has only ``nn.DataParallel`` (IGN/exp/experiment_classification.py:279-281).  Here every rank owns
+a full replica and a disjoint slice of each global batch; after backward the gradients -- laid out contiguously
+in ONE buffer whose slices are the parameters' ``.grad`` views, so no flatten/unflatten copies exist -- are summed
+over ranks with a single ``all_reduce`` (4.27 MB for IGN-default: a latency-bound message on xGMI, one launch
+instead of one per tensor) and divided by the world size.  BatchNorm statistics stay per-rank, like DataParallel.
+Device-agnostic on purpose: the gloo/CPU tests in tests/test_ddp_cpu.py run the same code.
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatParamBucket:
+    def __init__(self, module, world_size=None, process_group=None):
+        self.group = process_group
+        self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("module has no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        n = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(n, device=dev, dtype=dt)
+        off = 0
+        for p in self.params:
+            if p.device != dev or p.dtype != dt:
+                raise ValueError("all parameters must share one device and dtype")
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.module = module
+
+    @property
+    def nbytes(self):
+        return self.flat_grad.numel() * self.flat_grad.element_size()
+
+    def broadcast_state(self, src=0):
+        """Make every replica identical to rank `src` (parameters and buffers) before the first step."""
+        if self.world == 1:
+            return
+        for t in list(self.module.parameters()) + list(self.module.buffers()):
+            dist.broadcast(t.data, src=src, group=self.group)
+
+    def allreduce(self):
+        """Average the gradients over ranks: one collective on the flat bucket."""
+        if self.world == 1:
+            return
+        dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat_grad.div_(self.world)
+
+    def zero_grad(self):
+        """Zero in place (``optimizer.zero_grad(set_to_none=True)`` would detach the views)."""
+        self.flat_grad.zero_()
+
+
+def shard_indices(n, rank, world, epoch=0, seed=0, shuffle=True):
+    """Global permutation from a shared seed; rank r takes the r-th contiguous slice of every global batch's worth.
+    Trailing samples that do not fill all ranks evenly are dropped (equal shard sizes keep the CE means exact)."""
+    if shuffle:
+        g = torch.Generator().manual_seed(seed + epoch)
+        perm = torch.randperm(n, generator=g)
+    else:
+        perm = torch.arange(n)
+    per = n // world
+    return perm[rank * per:(rank + 1) * per]

@@ -1,0 +1,119 @@
+"""Autograd ops over the C ABI (include/ign_abi.h).  torch supplies device memory, streams and autograd
+plumbing; the arithmetic is in libign_hip.so.  Every op raises on CPU tensors: there is no fallback path."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+DIST_L1, DIST_MSE, DIST_COS, DIST_PEARSON = 0, 1, 2, 3
+GATE_RBF, GATE_LTS = 0x00, 0x10
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(name, *ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.IgnError(f"{name}: tensor on {t.device}; the IGN hot path runs on the MI355X only "
+                                f"(no CPU fallback -- the CPU restatement lives in oracle/ for tests)")
+        if t.dtype != torch.float32:
+            raise _lib.IgnError(f"{name}: expected float32, got {t.dtype}")
+
+
+def instance_norm(x_btc, want_raw=False, eps=1e-8):
+    """(B,T,C) -> normalised (B,C,T) [+ raw transpose].  Replaces IGN/model/Shapelet.py:186-187."""
+    _need_gpu("instance_norm", x_btc)
+    x = x_btc.contiguous()
+    B, T, C = x.shape
+    xn = torch.empty(B, C, T, device=x.device, dtype=torch.float32)
+    xt = torch.empty_like(xn) if want_raw else None
+    L = _lib.lib()
+    _lib.check(L.ign_instnorm_fwd(_ptr(x), _ptr(xn), _ptr(xt), B, T, C, eps, _stream()), "ign_instnorm_fwd")
+    return xn, xt
+
+
+class ShapeletBankFn(torch.autograd.Function):
+    """All length groups of a shapelet bank in one autograd node.
+
+    forward(xn, eps, mode, stride_list, n_groups, w_0..w_{G-1}[, thr_0..thr_{G-1}]) -> (P, Dmin), both (B, sum_g K_g*C)
+    with the reference's feature order g*K*C + k*C + c (IGN/model/Shapelet.py:84,195-196).
+    Dmin is non-differentiable (the training loss never reads it: IGN/exp/experiment_classification.py:325-329).
+    """
+
+    @staticmethod
+    def forward(ctx, xn, eps, mode, strides, n_groups, *params):
+        ws = [w.contiguous() for w in params[:n_groups]]
+        thrs = [t.contiguous() for t in params[n_groups:]] if (mode & GATE_LTS) else [None] * n_groups
+        _need_gpu("shapelet_fwd", xn, *ws, *[t for t in thrs if t is not None])
+        xn = xn.contiguous()
+        B, C, T = xn.shape
+        ld = sum(w.shape[0] * C for w in ws)
+        P = torch.empty(B, ld, device=xn.device, dtype=torch.float32)
+        D = torch.empty_like(P)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        L = _lib.lib()
+        saved, col0 = [], 0
+        for g, w in enumerate(ws):
+            K, Cw, Lg = w.shape
+            if Cw != C:
+                raise _lib.IgnError(f"shapelet group {g}: weights have {Cw} channels, input has {C}")
+            stride = int(strides[g])
+            Tw = (T - Lg) // stride + 1
+            tstar = torch.empty(B, K, C, device=xn.device, dtype=torch.int32)
+            zmu = torch.empty(B, K, C, 2, device=xn.device, dtype=torch.float32)
+            dsave = torch.empty(B, C, K, Tw, device=xn.device, dtype=torch.float32) if need_grad else None
+            _lib.check(L.ign_shapelet_fwd(_ptr(xn), _ptr(w), _ptr(thrs[g]), _ptr(P), _ptr(D), ld, col0,
+                                          _ptr(tstar), _ptr(zmu), _ptr(dsave), B, C, T, K, Lg, stride,
+                                          float(eps), int(mode), _stream()), "ign_shapelet_fwd")
+            saved.append((tstar, zmu, dsave, col0, stride))
+            col0 += K * C
+        ctx.mark_non_differentiable(D)
+        ctx.meta = (float(eps), int(mode), n_groups, saved, need_grad)
+        ctx.save_for_backward(xn, P, D, *ws, *[t for t in thrs if t is not None])
+        return P, D
+
+    @staticmethod
+    def backward(ctx, gP, gD):
+        eps, mode, G, saved, had_grad = ctx.meta
+        if not had_grad:
+            raise _lib.IgnError("shapelet backward called but the forward ran without saving distances")
+        xn, P, D = ctx.saved_tensors[:3]
+        ws = ctx.saved_tensors[3:3 + G]
+        thrs = ctx.saved_tensors[3 + G:]
+        gP = gP.contiguous()
+        B, C, T = xn.shape
+        ld = P.shape[1]
+        L = _lib.lib()
+        grads_w, grads_t = [], []
+        for g, w in enumerate(ws):
+            K, _, Lg = w.shape
+            tstar, zmu, dsave, col0, stride = saved[g]
+            nbytes = L.ign_shapelet_bwd_workspace_bytes(B, C, T, K, Lg, stride, mode)
+            if nbytes == 0:
+                raise _lib.IgnError(f"shapelet backward: no launch plan for K={K} L={Lg} stride={stride}")
+            work = torch.empty(nbytes // 4, device=xn.device, dtype=torch.float32)
+            gw = torch.empty_like(w)
+            _lib.check(L.ign_shapelet_bwd(_ptr(xn), _ptr(w), _ptr(gP), _ptr(P), _ptr(D), ld, col0,
+                                          _ptr(tstar), _ptr(zmu), _ptr(dsave), _ptr(gw), _ptr(work),
+                                          B, C, T, K, Lg, stride, eps, mode, _stream()), "ign_shapelet_bwd")
+            grads_w.append(gw)
+            if mode & GATE_LTS:       # dP/dthr = sigma'(thr - m) = P(1-P);  IGN/model/Shapelet.py:109
+                Pg = P[:, col0:col0 + K * C]
+                grads_t.append((gP[:, col0:col0 + K * C] * Pg * (1 - Pg)).sum(0).view(1, K, C))
+        return (None, None, None, None, None, *grads_w, *grads_t)
+
+
+def shapelet_bank(xn, weights, eps, mode=DIST_L1 | GATE_RBF, strides=None, thresholds=None):
+    G = len(weights)
+    strides = strides or [1] * G
+    params = list(weights) + (list(thresholds) if (mode & GATE_LTS) else [])
+    return ShapeletBankFn.apply(xn, eps, mode, tuple(strides), G, *params)

@@ -1,0 +1,59 @@
+"""Interpretability-gated mixture of the SBM expert and a deep expert (IGN/model/InterpGN.py:13-66)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ign_hip import ops
+from models.FullyConvNet import FullyConvNetwork
+from models.Shapelet import ShapeBottleneckModel
+from utils.shapelet_util import ModelInfo
+
+
+def _lazy(name):
+    def ctor(configs):
+        import importlib
+        return importlib.import_module(f"models.{name}").Model(configs)
+    return ctor
+
+
+# registry keys of IGN/model/InterpGN.py:13-19
+dnn_dict = {
+    'PatchTST': _lazy('PatchTST'),
+    'FCN': FullyConvNetwork,
+    'TimesNet': _lazy('TimesNet'),
+    'Transformer': _lazy('Transformer'),
+    'ResNet': _lazy('ResNet'),
+}
+
+
+def gini_gate(sbm_out, deep_out, gating_value=None):
+    """eta = (N * sum softmax(sbm)^2 - 1) / (N - 1); out = eta*sbm + (1-eta)*dnn   (InterpGN.py:44-52).
+    At test time ``gating_value`` snaps eta to 1 where it exceeds the threshold."""
+    q = F.softmax(sbm_out, dim=-1)
+    n = sbm_out.shape[-1]
+    eta = (n * q.pow(2).sum(-1, keepdim=True) - 1) / (n - 1)
+    if gating_value is not None:
+        hard = (eta > gating_value).float()
+        eta = hard + eta * (1 - hard)
+    return eta * sbm_out + (1.0 - eta) * deep_out, eta
+
+
+class InterpGN(nn.Module):
+    def __init__(self, configs, num_shapelet=[5, 5, 5, 5], shapelet_len=[0.1, 0.2, 0.3, 0.5]):
+        super().__init__()
+        self.configs = configs
+        self.sbm = ShapeBottleneckModel(configs=configs, num_shapelet=num_shapelet, shapelet_len=shapelet_len)
+        self.deep_model = dnn_dict[configs.dnn_type](configs)
+
+    def forward(self, x, x_mark_enc=None, x_dec=None, x_mark_dec=None, mask=None, gating_value=None):
+        sbm_out, info = self.sbm(x)
+        deep_out = self.deep_model(x, x_mark_enc, x_dec, x_mark_dec, mask)
+        out, eta = gini_gate(sbm_out, deep_out, gating_value)
+        return out, ModelInfo(d=info.d, p=info.p, eta=eta, shapelet_preds=sbm_out, dnn_preds=deep_out,
+                              preds=out, loss=self.loss().unsqueeze(0))
+
+    def loss(self):
+        return self.sbm.loss()
+
+    def step(self):
+        self.sbm.step()

@@ -1,0 +1,145 @@
+"""GPU parity of the drop-in models (same classes / state_dict keys as the reference) against the golden
+fixtures the reference produced: outputs, ModelInfo fields, training loss, every parameter gradient, and
+three Adam steps.  Tolerance 1e-4 (north_star)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden, make_cfg, sd_from
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _close(a, b, tol=1e-4, msg=""):
+    a = a.detach().cpu().numpy()
+    np.testing.assert_allclose(a, np.asarray(b), rtol=tol, atol=tol, err_msg=msg)
+
+
+def _grads_close(model, g, tol=2e-4):
+    for n, p in model.named_parameters():
+        ref = g["grad." + n]
+        scale = max(float(np.abs(ref).max()), 1e-7)
+        err = float(np.abs(p.grad.detach().cpu().numpy() - ref).max())
+        assert err <= tol * scale + 1e-8, f"{n}: err {err:.3e} scale {scale:.3e}"
+
+
+def _train_loss(name, out, info, y):
+    if name == 'DNN':
+        return F.cross_entropy(out, y)
+    loss = F.cross_entropy(out, y) + info.loss.mean()
+    if name == 'InterpGN':
+        loss = loss + 1.0 * F.cross_entropy(info.shapelet_preds, y)
+    return loss
+
+
+@pytest.mark.parametrize("name,sbm_cls,lts", [("sbm_linear", "linear", False), ("sbm_bilinear", "bilinear", False),
+                                              ("sbm_attention", "attention", False), ("lts", "linear", True)])
+def test_sbm_heads(name, sbm_cls, lts):
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models.Shapelet import ShapeBottleneckModel, DistThresholdSBM
+    g = golden(name)
+    k = int(g["num_shapelet"])
+    cls = DistThresholdSBM if lts else ShapeBottleneckModel
+    m = cls(make_cfg(sbm_cls=sbm_cls), [k] * 6, [0.05, 0.1, 0.2, 0.3, 0.5, 0.8])
+    assert set(m.state_dict().keys()) == {k_[3:] for k_ in g if k_.startswith("sd.")}
+    m.load_state_dict(sd_from(g))
+    m.to(dev).train()
+    x, y = _t(g["x"], dev), _t(g["y"], dev)
+    out, info = m(x)
+    loss = F.cross_entropy(out, y) + info.loss.mean()
+    loss.backward()
+    _close(out, g["out"], 2e-4)
+    _close(info.p, g["p"])
+    _close(info.d, g["d"])
+    _close(info.loss, g["model_loss"])
+    assert info.loss.shape == (1,)
+    assert abs(loss.item() - float(g["train_loss"])) < 1e-4
+    _grads_close(m, g)
+
+
+def test_ign_fcn_bm_golden():
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models.InterpGN import InterpGN
+    g = golden("ign_fcn_bm")
+    m = InterpGN(make_cfg())
+    assert set(m.state_dict().keys()) == {k[3:] for k in g if k.startswith("sd.")}
+    m.load_state_dict(sd_from(g))
+    m.to(dev).train()
+    x, y = _t(g["x"], dev), _t(g["y"], dev)
+    out, info = m(x, torch.ones(8, 100, device=dev), None, None)
+    loss = _train_loss('InterpGN', out, info, y)
+    loss.backward()
+    for k, v in (("out", out), ("eta", info.eta), ("shapelet_preds", info.shapelet_preds),
+                 ("dnn_preds", info.dnn_preds), ("p", info.p), ("d", info.d), ("model_loss", info.loss)):
+        _close(v, g[k], 2e-4, k)
+    assert abs(loss.item() - float(g["train_loss"])) < 1e-4
+    _grads_close(m, g)
+    for k, v in m.state_dict().items():      # BatchNorm running statistics after one train-mode forward
+        _close(v.float(), g["sd_after." + k].astype(np.float32), 1e-4, k)
+    m.eval()
+    with torch.no_grad():
+        oe, ie = m(x, None, None, None)
+        og, ig = m(x, None, None, None, gating_value=0.05)
+    _close(oe, g["eval_out"], 2e-4)
+    _close(og, g["gated_out"], 2e-4)
+    _close(ig.eta, g["gated_eta"], 2e-4)
+
+
+def test_ign_fcn_chisco_shape_golden():
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models.InterpGN import InterpGN
+    g = golden("ign_fcn_ch")
+    m = InterpGN(make_cfg(enc_in=122, seq_len=1000, num_class=3, c_out=3))
+    m.load_state_dict(sd_from(g))
+    m.to(dev).train()
+    x, y = _t(g["x"], dev), _t(g["y"], dev)
+    out, info = m(x, None, None, None)
+    loss = _train_loss('InterpGN', out, info, y)
+    loss.backward()
+    _close(out, g["out"], 2e-4)
+    _close(info.p, g["p"])
+    _close(info.d, g["d"])
+    _close(info.eta, g["eta"], 2e-4)
+    assert abs(loss.item() - float(g["train_loss"])) < 1e-4
+    _grads_close(m, g, tol=3e-4)
+
+
+@pytest.mark.parametrize("tag,posw", [("", False), ("_posw", True)])
+def test_three_adam_steps(tag, posw):
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models.InterpGN import InterpGN
+    g = golden("train_step_ign" + tag)
+    m = InterpGN(make_cfg())
+    m.load_state_dict(sd_from(g, "sd0."))
+    m.to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=5e-3)
+    xs, ys = _t(g["xs"], dev), _t(g["ys"], dev)
+    for i in range(3):
+        out, info = m(xs[i], None, None, None)
+        loss = _train_loss('InterpGN', out, info, ys[i])
+        loss.backward()
+        opt.step()
+        if posw:
+            m.step()
+        opt.zero_grad()
+        assert abs(loss.item() - g["losses"][i]) < 2e-4 * max(1.0, abs(g["losses"][i]))
+    for k, v in m.state_dict().items():
+        # Adam normalises by sqrt(v): entries whose gradient is ~0 amplify last-bit differences
+        np.testing.assert_allclose(v.detach().cpu().numpy(), g["sd3." + k], rtol=5e-3, atol=5e-4, err_msg=k)

@@ -1,0 +1,218 @@
+"""GPU parity of the HIP shapelet path (through the C ABI) against the golden fixtures produced by the
+reference and against the CPU oracle on seeded inputs.  Tolerance: 1e-4 (north_star: "within 1e-4 fp32")."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, make_cfg, sd_from
+
+pytestmark = pytest.mark.gpu
+
+RTOL = ATOL = 1e-4
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _t(a, dev=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(dev) if dev is not None else t
+
+
+def _close(a, b, rtol=RTOL, atol=ATOL, msg=""):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=msg)
+
+
+def _grad_close(a, b, msg="", tol=1e-4):
+    """gradients: 1e-4 relative to the tensor's own scale (entries are sums of O(B*Tw) signed terms)."""
+    a = a.detach().cpu().numpy()
+    b = np.asarray(b)
+    scale = max(float(np.abs(b).max()), 1e-12)
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale + 1e-9, f"{msg}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def test_library_loaded_is_in_tree():
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import _lib
+    assert _lib.lib_path().endswith("speech-imagery-eeg_amd/csrc/libign_hip.so")
+    assert _lib.lib().ign_abi_version() == 1
+
+
+def test_cpu_tensor_is_refused():
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops, _lib
+    with pytest.raises(_lib.IgnError):
+        ops.instance_norm(torch.randn(2, 10, 3))
+
+
+def test_instance_norm_matches_oracle():
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    from oracle import ign_oracle as O
+    g = torch.Generator().manual_seed(1)
+    for (B, T, C) in [(3, 100, 6), (2, 1000, 122), (5, 37, 17), (1, 64, 1)]:
+        x = torch.randn(B, T, C, generator=g) * 3.0 + 50.0        # large offset: two-pass variance matters
+        xn, xt = ops.instance_norm(x.to(dev), want_raw=True)
+        _close(xn, O.instance_norm(x), rtol=2e-4, atol=2e-4, msg=f"{B},{T},{C}")
+        assert torch.equal(xt.cpu(), x.permute(0, 2, 1).contiguous())
+
+
+@pytest.mark.parametrize("name,mode", [("l1", 0), ("mse", 1)])
+def test_shapelet_golden_small(name, mode):
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    g = golden(f"shapelet_{name}")
+    xn, r = _t(g["xn"], dev), _t(g["r"], dev)
+    w = _t(g["w"], dev).requires_grad_(True)
+    p, dmin = ops.shapelet_bank(xn, [w], float(g["eps"]), mode)
+    (p * r).sum().backward()
+    _close(p, g["p"])
+    _close(dmin, g["dmin"])
+    _grad_close(w.grad, g["grad_w"], name)
+
+
+def test_shapelet_golden_lts():
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    g = golden("shapelet_lts")
+    xn, r = _t(g["xn"], dev), _t(g["r"], dev)
+    w = _t(g["w"], dev).requires_grad_(True)
+    thr = _t(g["thr"], dev).requires_grad_(True)
+    p, dmin = ops.shapelet_bank(xn, [w], float(g["eps"]), ops.DIST_L1 | ops.GATE_LTS, thresholds=[thr])
+    (p * r).sum().backward()
+    _close(p, g["p"])
+    _close(dmin, g["dmin"])
+    _grad_close(w.grad, g["grad_w"], "lts w")
+    _grad_close(thr.grad, g["grad_thr"], "lts thr")
+
+
+def test_shapelet_bm_groups_one_bank():
+    """The four driver-default groups of the BasicMotions shape in ONE bank call (column offsets, K=5 tiles)."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    g = golden("shapelet_bm")
+    xn, _ = ops.instance_norm(_t(g["x"], dev))
+    _close(xn, g["xn"])
+    ws = [_t(g[f"w{i}"], dev).requires_grad_(True) for i in range(4)]
+    p, dmin = ops.shapelet_bank(xn, ws, 1.0)
+    r = torch.cat([_t(g[f"r{i}"], dev) for i in range(4)], dim=1)
+    (p * r).sum().backward()
+    _close(p, np.concatenate([g[f"p{i}"] for i in range(4)], axis=1))
+    _close(dmin, np.concatenate([g[f"dmin{i}"] for i in range(4)], axis=1))
+    for i in range(4):
+        _grad_close(ws[i].grad, g[f"grad_w{i}"], f"group {i}")
+
+
+@pytest.mark.parametrize("B,C,T,K,L,mode", [
+    (4, 122, 1000, 5, 100, 0),     # CHISCO shape, TT=15
+    (3, 122, 1000, 5, 500, 0),     # TT=8, JJ=8 backward
+    (3, 7, 1000, 10, 300, 0),      # two K-tiles of 5
+    (5, 3, 200, 7, 33, 0),         # K = 5 + 2 tiles, odd L (tail loop)
+    (2, 4, 1300, 3, 10, 0),        # Tw = 1291 > 1024: two passes, K = 2 + 1 tiles
+    (3, 5, 300, 4, 50, 1),         # MSE
+    (3, 5, 120, 6, 3, 0),          # minimum shapelet length
+    (2, 3, 50, 2, 50, 0),          # L == T: a single window
+])
+def test_shapelet_vs_oracle_random(B, C, T, K, L, mode):
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    from oracle import ign_oracle as O
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    x = torch.randn(B, T, C, generator=g)
+    w0 = torch.randn(K, C, L, generator=g)
+    r = torch.randn(B, K * C, generator=g)
+    xn_o = O.instance_norm(x)
+    wo = w0.clone().requires_grad_(True)
+    po, do = O.rbf_straight_through_max(O.window_distance(xn_o, wo, 1, mode, chunk=8), 0.8)
+    (po * r).sum().backward()
+    xn, _ = ops.instance_norm(x.to(dev))
+    wg = w0.clone().to(dev).requires_grad_(True)
+    p, dmin = ops.shapelet_bank(xn, [wg], 0.8, mode)
+    (p * r.to(dev)).sum().backward()
+    _close(p, po)
+    _close(dmin, do)
+    _grad_close(wg.grad, wo.grad.numpy(), f"B{B} C{C} T{T} K{K} L{L}")
+
+
+def test_strided_windows_forward():
+    """seq_len >= 3000 switches the reference to stride int(log2(L)) (Shapelet.py:162): TT=1 kernel path."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    from oracle import ign_oracle as O
+    g = torch.Generator().manual_seed(9)
+    xn = torch.randn(2, 3, 3100, generator=g)
+    w = torch.randn(4, 3, 310, generator=g)
+    stride = 8
+    po, do = O.rbf_straight_through_max(O.window_distance(xn, w, stride, 0, chunk=32), 1.0)
+    with torch.no_grad():
+        p, dmin = ops.shapelet_bank(xn.to(dev), [w.to(dev)], 1.0, 0, strides=[stride])
+    _close(p, po)
+    _close(dmin, do)
+
+
+def test_full_size_properties():
+    """B=256, C=122, T=1000 (BASELINE config 1): size-independent checks the oracle cannot reach in seconds."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    torch.manual_seed(0)
+    B, C, T, K = 256, 122, 1000, 5
+    x = torch.randn(B, T, C, device=dev)
+    xn, _ = ops.instance_norm(x)
+    assert abs(float(xn.mean())) < 1e-5 and abs(float(xn.std(dim=-1, unbiased=True).mean()) - 1.0) < 1e-4
+    ws = [torch.randn(K, C, L, device=dev, requires_grad=True) for L in (100, 200, 300, 500)]
+    # plant shapelet 0 of group 1 at t=123 of row 7, channel 11: distance 0, p = 1, arg-max = 123
+    with torch.no_grad():
+        ws[1][0, 11] = xn[7, 11, 123:323]
+    p, dmin = ops.shapelet_bank(xn, ws, 1.0)
+    col = K * C + 0 * C + 11
+    assert float(dmin[7, col]) == 0.0 and float(p[7, col]) == 1.0
+    # RBF is monotone: max_t p == exp(-(eps * min_t d)^2)
+    _close(p, torch.exp(-dmin.double() ** 2).float(), rtol=1e-5, atol=1e-6)
+    assert bool(((p > 0) & (p <= 1)).all())
+    g1 = torch.randn_like(p)
+    g2 = torch.randn_like(p)
+    grads1 = torch.autograd.grad(p, ws, g1, retain_graph=True)
+    grads1b = torch.autograd.grad(p, ws, g1, retain_graph=True)
+    grads2 = torch.autograd.grad(p, ws, g2, retain_graph=True)
+    grads12 = torch.autograd.grad(p, ws, g1 + g2)
+    for a, b in zip(grads1, grads1b):
+        assert torch.equal(a, b), "backward is not bitwise reproducible"
+    for a, b, c in zip(grads1, grads2, grads12):            # backward is linear in the upstream gradient
+        scale = float(c.abs().max())
+        assert float((a + b - c).abs().max()) <= 2e-4 * scale
+    # batch-chunk additivity: grad over the batch == sum of grads over two halves
+    p_a, _ = ops.shapelet_bank(xn[:128].contiguous(), ws, 1.0)
+    p_b, _ = ops.shapelet_bank(xn[128:].contiguous(), ws, 1.0)
+    assert torch.equal(torch.cat([p_a, p_b]), p)
+    ga = torch.autograd.grad(p_a, ws, g1[:128].contiguous())
+    gb = torch.autograd.grad(p_b, ws, g1[128:].contiguous())
+    for a, b, c in zip(ga, gb, grads1):
+        assert float((a + b - c).abs().max()) <= 2e-4 * float(c.abs().max())
+
+
+def test_abi_argument_errors():
+    dev = _dev()
+    import ctypes
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import _lib
+    L = _lib.lib()
+    x = torch.zeros(16, device=dev)
+    pp = ctypes.c_void_p(x.data_ptr())
+    assert L.ign_instnorm_fwd(None, pp, None, 1, 4, 4, 1e-8, None) == -1001
+    assert L.ign_shapelet_fwd(pp, pp, None, pp, pp, 4, 0, pp, pp, None, 1, 2, 8, 2, 9, 1, 1.0, 0, None) == -1001  # L > T
+    assert L.ign_shapelet_fwd(pp, pp, None, pp, pp, 4, 0, pp, pp, None, 1, 2, 8, 2, 3, 1, 1.0, 2, None) == -1002  # cosine
+    assert b"cosine" in L.ign_last_error()
+    assert L.ign_shapelet_bwd_workspace_bytes(1, 2, 8, 2, 3, 2, 0) == 0
