@@ -52,6 +52,26 @@ def shapelet_algorithmic_flops(B, C, T, groups):
     return 2 * E, 3 * E
 
 
+def host_cores():
+    """CPU cores this process may actually use: min(affinity, cgroup quota) -- os.cpu_count() reports the whole
+    machine inside a container and oversubscribing torch's thread pool makes the CPU baseline meaningless."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def cpu_baseline(cfg, sample_b, threads):
     """The CPU oracle (a restatement of the reference path, kind="port") timed on the host: one full training step
     (fwd + bwd + Adam) on `sample_b` samples of the same synthetic distribution."""
@@ -98,6 +118,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    torch.set_num_threads(host_cores())
     import speech_imagery_eeg_amd  # noqa: F401
     from ign_hip import _lib
     from ign_hip.ddp import FlatParamBucket
@@ -111,7 +132,9 @@ def main():
     opt = torch.optim.Adam(model.parameters(), lr=5e-3, fused=True)
 
     n_batches = min(args.steps + args.warmup, max(1, N_TRAIN // (B * world)))
+    log(f"generating {n_batches} synthetic batches on the host ...")
     xs, ys = synth_batches(n_batches, B, T, C, cfg.num_class, rank, world, dev)
+    log("warm-up ...")
     mask = torch.ones(B, T, device=dev)
 
     def step(i):
@@ -133,6 +156,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log("timed region ...")
     _lib.timing_enable(True)
     fence()
     t0 = time.perf_counter()
@@ -177,7 +201,8 @@ def main():
                                         "ms_per_step": fwd_ms / max(1, args.steps), "launches": fwd_n}},
         }
         if world == 1 and args.cpu_sample > 0:
-            res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, os.cpu_count() or 1)
+            log("cpu baseline ...")
+            res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, host_cores())
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

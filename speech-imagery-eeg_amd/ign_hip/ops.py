@@ -59,7 +59,7 @@ class ShapeletBankFn(torch.autograd.Function):
         ld = sum(w.shape[0] * C for w in ws)
         P = torch.empty(B, ld, device=xn.device, dtype=torch.float32)
         D = torch.empty_like(P)
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need_grad = any(ctx.needs_input_grad[5:])     # grad mode is off inside forward(); ask the node instead
         L = _lib.lib()
         saved, col0 = [], 0
         for g, w in enumerate(ws):
