@@ -215,10 +215,12 @@ static int plan_bwd(int B, int C, int T, int K, int L, int Tw, BwdPlan* p) {
         p->lds = ((size_t)p->xs_len + (size_t)p->kb * p->twpad) * 4;
     }
     if (p->lds > 64 * 1024) return IGN_E_TOOBIG;
-    // batch slices: enough blocks to fill 256 CUs a few times over, >= 2 rows per slice when possible
-    int nbs = (2048 + C * p->nkt - 1) / (C * p->nkt);
-    nbs = std::max(1, std::min(nbs, std::max(1, B / 2)));
-    p->nbs = std::min(nbs, B);
+    // batch slices: a few rows per block.  Many small blocks (thousands) keep the last scheduling round of the
+    // 256 CUs short -- with ~2000 blocks of 2-5 waves a third of the launch was tail (profiles/r1a) -- while 4 rows
+    // still amortise the per-block weight load / partial store.  Partials: nbs*K*C*L floats (<= 80 MB here).
+    int nbs = (B + 3) / 4;
+    while (nbs > 1 && (size_t)nbs * K * C * L * 4 > ((size_t)256 << 20)) nbs = (nbs + 1) / 2;
+    p->nbs = std::max(1, std::min(nbs, B));
     return 0;
 }
 

@@ -75,12 +75,12 @@ __global__ void __launch_bounds__(512) shp_bwd_kernel(const ShpBwdArgs a) {
                     float dldd;
                     if (a.gate == GATE_RBF) {
                         const float u = a.eps * dv;
-                        const float p = expf(-(u * u));
-                        const float e = expf(p);
+                        const float p = __expf(-(u * u));
+                        const float e = __expf(p);
                         const float coef = gv * ((t == ts ? 1.f : 0.f) + e * invZ * (p - mu));
                         dldd = coef * (-two_eps2 * dv * p);
                     } else {
-                        const float s = expf(dmin - dv) * invZ;
+                        const float s = __expf(dmin - dv) * invZ;
                         dldd = gm * ((t == ts ? 1.f : 0.f) + s * (mu - dv));
                     }
                     A = (DIST == DIST_L1) ? -dldd * a.invL : -2.f * dldd * a.invL;

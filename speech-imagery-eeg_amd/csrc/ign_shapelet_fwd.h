@@ -132,8 +132,8 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
                         const float dv = acc[k][t] * a.invL;
                         if (drow && row_ok) drow[tg] = dv;
                         const float u = a.eps * dv;
-                        const float p = expf(-(u * u));
-                        const float e = expf(p);
+                        const float p = __expf(-(u * u));
+                        const float e = __expf(p);
                         r_Z[k] += e;
                         r_M[k] = fmaf(e, p, r_M[k]);
                         if (p > r_best[k]) { r_best[k] = p; r_idx[k] = tg; }
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
                     // r_best holds -(running min) so the arg-min tie rule is "first index"
                     const float mold = r_dmin[k];
                     const float mnew = fminf(mold, pmin);
-                    const float sc = (mold < INFINITY) ? expf(mnew - mold) : 0.f;
+                    const float sc = (mold < INFINITY) ? __expf(mnew - mold) : 0.f;
                     r_Z[k] *= sc; r_M[k] *= sc;
 #pragma unroll
                     for (int t = 0; t < TT; ++t) {
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
                         if (tg < a.Tw) {
                             const float dv = acc[k][t] * a.invL;
                             if (drow && row_ok) drow[tg] = dv;
-                            const float e = expf(mnew - dv);
+                            const float e = __expf(mnew - dv);
                             r_Z[k] += e;
                             r_M[k] = fmaf(e, dv, r_M[k]);
                             if (-dv > r_best[k]) { r_best[k] = -dv; r_idx[k] = tg; }
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
         const float dmin = wave_min(r_dmin[k]);
         float Z = r_Z[k], M = r_M[k];
         if (a.gate == GATE_LTS) {
-            const float sc = (r_dmin[k] < INFINITY) ? expf(dmin - r_dmin[k]) : 0.f;
+            const float sc = (r_dmin[k] < INFINITY) ? __expf(dmin - r_dmin[k]) : 0.f;
             Z *= sc; M *= sc;
         }
         Z = wave_sum(Z);
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
                 pout = best;                       // = p[t*] * (1 + s - s): Shapelet.py:81-82
             } else {
                 const float th = a.thr[(size_t)kk * a.C + c];
-                pout = 1.f / (1.f + expf(-(th - dmin)));
+                pout = 1.f / (1.f + __expf(-(th - dmin)));
             }
             a.p_out[col] = pout;
             a.dmin_out[col] = dmin;
