@@ -274,6 +274,10 @@ class OracleSBM(nn.Module):
             loss = loss + (torch.exp(-dist) * mask).mean()
         return loss
 
+    def get_shapelets(self):   # Shapelet.py:232-238
+        return [(s.weights.data[k, c, :].cpu().numpy(), c) for s in self.shapelets
+                for k in range(s.weights.shape[0]) for c in range(s.weights.shape[1])]
+
     def loss(self):
         reg = self.output_layer.weight.abs().mean()
         div = self.diversity() if self.lambda_div > 0. else 0.

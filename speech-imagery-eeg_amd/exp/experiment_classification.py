@@ -1,0 +1,335 @@
+"""Classification experiment harness -- drop-in for IGN/exp/experiment_classification.py.
+
+Same surface: ``Experiment(args)`` with ``model_dict``, ``train()``, ``validation()``, ``test(save_csv, result_dir)``,
+``checkpoint_dir``, ``model``; same loss composition (:319-329), accumulation / clipping / Adam / clamp order
+(:331-341), early stopping on ``-val_accuracy`` and best-checkpoint reload (:360-376), checkpoint path scheme
+(:140-152).  What is new underneath: the models run the HIP shapelet kernels, and under ``torch.distributed``
+(one process per GPU) gradients are averaged with one flat RCCL all-reduce per step (ign_hip.ddp) instead of
+``nn.DataParallel``.
+
+Deliberate repairs of fork defects: dataset parameters are taken from the dataset object for
+UEA too (D5); ``EEGCNN`` receives (B,C,T) and no mask (D9); ``np.Inf`` is not used (D12).  Reproduced as-is: IGN is
+built WITHOUT the ``--num_shapelet`` lists (D4), ``--amp`` switches bf16 autocast OFF (D3).
+"""
+import os
+import sys
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from data_provider.data_factory import data_provider
+from ign_hip.ddp import FlatParamBucket
+from models.FullyConvNet import FullyConvNetwork
+from models.InterpGN import InterpGN, dnn_dict
+from models.Shapelet import DistThresholdSBM, ShapeBottleneckModel
+from utils.shapelet_util import ClassificationResult
+from utils.tools import EarlyStopping, convert_to_hms, gini_coefficient  # noqa: F401
+
+
+def compute_beta(epoch, max_epoch, schedule='cosine'):
+    """Weight of the auxiliary SBM cross-entropy (IGN/exp/experiment_classification.py:19-26)."""
+    if schedule == 'cosine':
+        return 1 / 2 * (1 + np.cos(np.pi * epoch / max_epoch))
+    if schedule == 'linear':
+        return 1 - epoch / max_epoch
+    return 1
+
+
+def compute_shapelet_score(shapelet_distances, cls_weights, y_pred, y_true):
+    """:29-34 -- mean class-weighted distance score over correctly classified samples."""
+    score = shapelet_distances @ F.relu(cls_weights.T) / shapelet_distances.shape[-1]
+    ok = y_pred == y_true
+    return score[ok].gather(-1, y_true[ok].unsqueeze(1)).mean().item()
+
+
+def get_dnn_model(configs):
+    return dnn_dict[configs.dnn_type](configs)
+
+
+def get_eegcnn_model(configs):
+    from models.eegcnn import EEGCNNTransformer
+    return EEGCNNTransformer(configs)
+
+
+def accuracy_score(pred, true):
+    pred, true = np.asarray(pred), np.asarray(true)
+    return float((pred == true).mean()) if len(true) else 0.0
+
+
+class Experiment(object):
+    model_dict = {
+        'InterpGN': InterpGN,
+        'SBM': ShapeBottleneckModel,
+        'LTS': DistThresholdSBM,
+        'DNN': get_dnn_model,
+        'EEGCNN': get_eegcnn_model,
+    }
+
+    def __init__(self, args):
+        self.args = args
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.rank = dist.get_rank() if self.distributed else 0
+        self.world = dist.get_world_size() if self.distributed else 1
+        if torch.cuda.is_available():
+            self.device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)) if self.distributed else 0)
+        else:
+            self.device = torch.device('cpu')
+
+        self.train_data, self.train_loader = data_provider(args, flag="train")
+        self.val_data, self.val_loader = data_provider(args, flag="val")
+        self.test_data, self.test_loader = data_provider(args, flag="test")
+        self._get_params_from_data()
+
+        self.model = self._build_model().to(self.device)
+        self.bucket = None
+        if self.distributed:
+            self.bucket = FlatParamBucket(self.model, self.world)
+            self.bucket.broadcast_state(0)
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.args.lr)
+        self.scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(self.optimizer, T_0=self.args.train_epochs)
+        self.checkpoint_dir = "./checkpoints/{}/{}/dnn-{}_seed-{}_k-{}_div-{}_reg-{}_eps-{}_beta-{}_dfunc-{}_cls-{}".format(
+            args.model, args.dataset, args.dnn_type, args.seed, args.num_shapelet, args.lambda_div, args.lambda_reg,
+            args.epsilon, args.beta_schedule, args.distance_func, args.sbm_cls)
+        if self.rank == 0:
+            os.makedirs(self.checkpoint_dir, exist_ok=True)
+        self.loss_fn = nn.CrossEntropyLoss()
+        self.epoch_stop = 0
+        print(f"Experiment: model={args.model} dnn={getattr(args, 'dnn_type', None)} device={self.device} "
+              f"world={self.world} seq_len={args.seq_len} enc_in={args.enc_in} num_class={args.num_class} "
+              f"train/val/test={len(self.train_data)}/{len(self.val_data)}/{len(self.test_data)}")
+
+    # ------------------------------------------------------------------------------------------------
+    def _get_params_from_data(self):
+        """seq_len / enc_in / num_class from the dataset object (intended behaviour of :166-249; the UEA attribute
+        names are honoured as in IGN/exp/experiment_regression.py:90-96)."""
+        d = self.train_data
+        if hasattr(d, 'seq_len'):
+            self.args.seq_len = int(d.seq_len)
+        elif hasattr(d, 'max_seq_len'):
+            self.args.seq_len = int(d.max_seq_len)
+        else:
+            self.args.seq_len = int(d[0][0].shape[0])
+        if hasattr(d, 'enc_in'):
+            self.args.enc_in = int(d.enc_in)
+        elif hasattr(d, 'feature_df'):
+            self.args.enc_in = int(d.feature_df.shape[1])
+        else:
+            self.args.enc_in = int(d[0][0].shape[1])
+        if hasattr(d, 'num_classes'):
+            self.args.num_class = int(d.num_classes)
+        elif hasattr(d, 'class_names'):
+            self.args.num_class = len(d.class_names)
+        else:
+            raise ValueError("dataset exposes neither num_classes nor class_names")
+        self.args.pred_len = 0
+        self.args.label_len = 0
+        self.args.c_out = self.args.num_class
+        self.args.original_fs = getattr(d, 'original_fs', 500)
+        self.args.target_fs = getattr(d, 'target_fs', 256)
+
+    def _build_model(self):
+        a = self.args
+        if a.model not in self.model_dict:
+            raise ValueError(f"model {a.model!r} not in {list(self.model_dict)}")
+        if a.model in ('SBM', 'LTS'):               # :264-270
+            lens = [0.05, 0.1, 0.2, 0.3, 0.5, 0.8]
+            model = self.model_dict[a.model](configs=a, num_shapelet=[a.num_shapelet] * len(lens), shapelet_len=lens)
+        else:                                        # InterpGN gets NO shapelet lists (D4): 4 groups x 5
+            model = self.model_dict[a.model](a)
+        if getattr(a, 'multi_gpu', False) and not self.distributed:
+            print("--multi_gpu: nn.DataParallel is replaced by one process per GPU; launch with "
+                  "`python -m torch.distributed.run --nproc-per-node N run.py ...` (running single-GPU now)")
+        return model
+
+    def print_args(self):
+        for k in sorted(vars(self.args)):
+            print(f"  {k}: {getattr(self.args, k)}")
+
+    # ------------------------------------------------------------------------------------------------
+    def _forward(self, batch_x, padding_mask, gating_value=None, test=False):
+        a = self.args
+        if a.model == 'DNN':
+            return self.model(batch_x, padding_mask, None, None), None
+        if a.model == 'EEGCNN':
+            return self.model(batch_x.permute(0, 2, 1).contiguous())      # (B,C,T), no mask (D9)
+        if test:
+            return self.model(batch_x, padding_mask, None, None, gating_value=gating_value)
+        return self.model(batch_x, padding_mask, None, None)
+
+    def _to_device(self, batch_x, label, padding_mask):
+        batch_x = batch_x.float().to(self.device, non_blocking=True)
+        label = label.long().to(self.device, non_blocking=True)
+        if label.dim() > 1:
+            label = label.squeeze(-1)
+        padding_mask = padding_mask.float().to(self.device, non_blocking=True)
+        return batch_x, label, padding_mask
+
+    def train(self):
+        a = self.args
+        torch.set_float32_matmul_precision('medium')          # :297 (affects only torch's own GEMMs)
+        early_stopping = EarlyStopping(patience=a.patience, verbose=self.rank == 0, delta=0)
+        t_start = time.time()
+        train_step = 0
+        amp = a.amp and self.device.type == 'cuda'
+        for epoch in range(a.train_epochs):
+            self.model.train()
+            if len(self.train_loader) == 0:
+                continue
+            losses = []
+            for batch_x, label, padding_mask in self.train_loader:
+                train_step += 1
+                batch_x, label, padding_mask = self._to_device(batch_x, label, padding_mask)
+                with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=amp):
+                    logits, info = self._forward(batch_x, padding_mask)
+                    loss = F.cross_entropy(logits, label)
+                    if a.model != 'DNN':
+                        loss = loss + info.loss.mean()
+                    if a.model == 'InterpGN':
+                        beta = compute_beta(epoch, a.train_epochs, a.beta_schedule)
+                        loss = loss + beta * F.cross_entropy(info.shapelet_preds, label)
+                if a.gradient_accumulation_steps > 1:
+                    loss = loss / a.gradient_accumulation_steps
+                loss.backward()
+                if train_step % a.gradient_accumulation_steps == 0:
+                    if self.bucket is not None:
+                        self.bucket.allreduce()
+                    if a.gradient_clip > 0:
+                        nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=a.gradient_clip)
+                    self.optimizer.step()
+                    if a.pos_weight:
+                        self.model.step()
+                    if self.bucket is not None:
+                        self.bucket.zero_grad()
+                    else:
+                        self.optimizer.zero_grad()
+                losses.append(loss.detach())
+            if not losses:
+                continue
+            train_loss = torch.stack(losses).mean().item()      # one host sync per epoch (the reference syncs per step)
+            val_loss, val_acc = self.validation()
+            remain = (time.time() - t_start) * (a.train_epochs - epoch) / (epoch + 1)
+            if (epoch + 1) % a.log_interval == 0 and self.rank == 0:
+                print(f"Epoch {epoch + 1}/{a.train_epochs} | Train Loss {train_loss:.4f} | Val Loss {val_loss:.4f} | "
+                      f"Val Acc {val_acc:.4f} | Time Rem {convert_to_hms(remain)}")
+            if a.lr_decay:
+                self.scheduler.step()
+            if epoch >= a.min_epochs:
+                if self.rank == 0:
+                    early_stopping(-val_acc, self.model, self.checkpoint_dir)
+                else:                                           # same decision on every rank, only rank 0 writes
+                    early_stopping.save_checkpoint = lambda *_: None
+                    early_stopping(-val_acc, self.model, self.checkpoint_dir)
+            self.epoch_stop = epoch
+            if early_stopping.early_stop:
+                if self.rank == 0:
+                    print("Early stopping")
+                break
+            sys.stdout.flush()
+        if self.distributed:
+            dist.barrier()
+        best = os.path.join(self.checkpoint_dir, 'checkpoint.pth')
+        if os.path.exists(best):
+            self.model.load_state_dict(torch.load(best, map_location=self.device, weights_only=True))
+        return self.model
+
+    def validation(self):
+        if len(self.val_loader) == 0:
+            return float('inf'), 0.0
+        a = self.args
+        amp = a.amp and self.device.type == 'cuda'
+        total, preds, trues = [], [], []
+        self.model.eval()
+        with torch.no_grad():
+            for batch_x, label, padding_mask in self.val_loader:
+                batch_x, label, padding_mask = self._to_device(batch_x, label, padding_mask)
+                with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=amp):
+                    logits, info = self._forward(batch_x, padding_mask)
+                    loss = F.cross_entropy(logits, label, reduction='none')
+                    if a.model != 'DNN':
+                        loss = loss + info.loss.mean()
+                total.append(loss.flatten().float())
+                preds.append(logits.float())
+                trues.append(label)
+        loss = torch.cat(total).mean().item()
+        pred = torch.cat(preds).argmax(dim=1).cpu().numpy()
+        acc = accuracy_score(pred, torch.cat(trues).flatten().cpu().numpy())
+        self.model.train()
+        return loss, acc
+
+    def test(self, save_csv=True, result_dir=None):
+        """-> (test_loss, ClassificationResult, None)   (:828-1138; ``gating_value`` is applied here only)."""
+        if result_dir is not None:
+            os.makedirs(result_dir, exist_ok=True)
+        if len(self.test_loader.dataset) == 0:
+            return float('inf'), None, None
+        a = self.args
+        amp = a.amp and self.device.type == 'cuda'
+
+        @dataclass
+        class Buffer:
+            x_data: list = field(default_factory=list)
+            trues: list = field(default_factory=list)
+            preds: list = field(default_factory=list)
+            shapelet_preds: list = field(default_factory=list)
+            dnn_preds: list = field(default_factory=list)
+            p: list = field(default_factory=list)
+            d: list = field(default_factory=list)
+            eta: list = field(default_factory=list)
+            loss: list = field(default_factory=list)
+
+        buf = Buffer()
+        self.model.eval()
+        with torch.no_grad():
+            for batch_x, label, padding_mask in self.test_loader:
+                if batch_x.size(0) == 0:
+                    continue
+                batch_x, label, padding_mask = self._to_device(batch_x, label, padding_mask)
+                ok = (label >= 0) & (label < a.num_class)           # drop out-of-range labels (:905-925)
+                if not bool(ok.all()):
+                    if not bool(ok.any()):
+                        continue
+                    batch_x, label, padding_mask = batch_x[ok], label[ok], padding_mask[ok]
+                with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=amp):
+                    logits, info = self._forward(batch_x, padding_mask, gating_value=a.gating_value, test=True)
+                    loss = F.cross_entropy(logits, label, reduction='none')
+                    if a.model != 'DNN':
+                        loss = loss + info.loss.mean()
+                buf.loss.append(loss.flatten().float().cpu())
+                buf.x_data.append(batch_x.cpu())
+                buf.trues.append(label.cpu())
+                buf.preds.append(logits.float().cpu())
+                if a.model in ('InterpGN', 'SBM', 'LTS'):
+                    buf.p.append(info.p.cpu())
+                    buf.d.append(info.d.cpu())
+                    buf.shapelet_preds.append(info.shapelet_preds.float().cpu())
+                    if a.model == 'InterpGN':
+                        buf.eta.append(info.eta.float().cpu())
+                        buf.dnn_preds.append(info.dnn_preds.float().cpu())
+        if not buf.trues:
+            return float('inf'), None, None
+        trues = torch.cat(buf.trues).flatten()
+        logits = torch.cat(buf.preds)
+        predictions = logits.argmax(dim=1)
+        accuracy = accuracy_score(predictions.numpy(), trues.numpy())
+        test_loss = torch.cat(buf.loss).mean().item()
+        if self.rank == 0:
+            base = 100.0 / a.num_class
+            print(f"Test: n={len(trues)} loss={test_loss:.6f} acc={accuracy:.4f} ({accuracy * 100:.2f}%; "
+                  f"random baseline {base:.2f}%)")
+        res = ClassificationResult(x_data=torch.cat(buf.x_data), trues=trues, preds=predictions, loss=test_loss,
+                                   accuracy=accuracy)
+        if buf.p:
+            res.p, res.d = torch.cat(buf.p), torch.cat(buf.d)
+            res.shapelet_preds = torch.cat(buf.shapelet_preds)
+            sbm = self.model.sbm if a.model == 'InterpGN' else self.model
+            res.w = sbm.output_layer.weight.detach().cpu()
+            res.shapelets = sbm.get_shapelets()
+            if a.model == 'InterpGN':
+                res.eta = torch.cat(buf.eta)
+                res.dnn_preds = torch.cat(buf.dnn_preds)
+        return test_loss, res, None

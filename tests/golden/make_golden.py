@@ -298,10 +298,39 @@ def case_eegcnn(R):
 CASES = dict(shapelet_modes=case_shapelet_modes, shapelet_bm=case_shapelet_bm, sbm=case_sbm, ign=case_ign,
              ign_ch=case_ign_ch, train_steps=case_train_steps, transformer=case_transformer, eegcnn=case_eegcnn)
 
+def case_run_flags(R=None):
+    """CLI contract: (flag, default, action) of every add_argument in the reference's run.py, read from its text
+    (importing run.py would execute its argparse/`exit(1)` side effects).  Stored as JSON data."""
+    import ast
+    import json
+    src = open(os.path.join(REF, "run.py"), encoding="utf-8").read()
+    tree = ast.parse(src)
+    flags = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Call) and getattr(node.func, "attr", "") == "add_argument" and node.args:
+            name = ast.literal_eval(node.args[0])
+            kw = {}
+            for k in node.keywords:
+                if k.arg in ("default", "action", "choices", "nargs"):
+                    try:
+                        kw[k.arg] = ast.literal_eval(k.value)
+                    except Exception:
+                        kw[k.arg] = None
+                elif k.arg == "type":
+                    kw["type"] = getattr(k.value, "id", None)
+            flags[name] = kw
+    path = os.path.join(HERE, "run_flags.json")
+    json.dump(flags, open(path, "w"), indent=1, sort_keys=True)
+    print(f"wrote {path} ({len(flags)} flags)")
+
+
+CASES["run_flags"] = case_run_flags
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    R = import_reference()
     names = sys.argv[1:] or list(CASES)
+    R = import_reference() if any(n != "run_flags" for n in names) else None
     for n in names:
         print(f"== {n}")
         CASES[n](R)
