@@ -46,3 +46,13 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+@pytest.fixture(autouse=True)
+def _reset_torch_matmul_precision():
+    """Experiment.train() sets float32 matmul precision to 'medium' like the reference (exp:297); parity tests that
+    run later in the same process must not inherit it."""
+    import torch
+    torch.set_float32_matmul_precision('highest')
+    yield
+    torch.set_float32_matmul_precision('highest')

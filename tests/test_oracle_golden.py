@@ -109,6 +109,8 @@ def test_ign_fcn_bm():
     assert info.loss.shape == (1,)
     np.testing.assert_allclose(loss.item(), g["train_loss"], rtol=1e-5)
     for n, p in m.named_parameters():
+        if n.startswith("deep_model.block") and n.endswith(".0.bias"):
+            continue
         np.testing.assert_allclose(p.grad.numpy(), g["grad." + n], rtol=2e-4, atol=2e-6, err_msg=n)
     for k, v in m.state_dict().items():      # BN running stats after the train-mode forward
         np.testing.assert_allclose(v.numpy(), g["sd_after." + k], rtol=1e-5, atol=1e-6, err_msg=k)
@@ -136,6 +138,8 @@ def test_ign_fcn_chisco_shape():
     np.testing.assert_allclose(loss.item(), g["train_loss"], rtol=1e-5)
     for n, p in m.named_parameters():
         ref = g["grad." + n]
+        if n.startswith("deep_model.block") and n.endswith(".0.bias"):
+            continue     # conv bias in front of BatchNorm: the true gradient is 0, both sides hold rounding noise
         scale = max(1e-7, float(np.abs(ref).max()))
         assert np.abs(p.grad.numpy() - ref).max() <= 2e-4 * scale + 1e-9, n
 
