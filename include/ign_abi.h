@@ -6,7 +6,7 @@
  *
  * Conventions
  *  - every pointer is a DEVICE pointer owned by the caller (contiguous fp32 unless noted); the library never
- *    allocates or frees device memory and keeps no mutable global state;
+ *    allocates or frees device memory; its only mutable state is the optional timing registry (ign_timing_*);
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are enqueued and the call
  *    returns immediately;
  *  - return 0 on success; IGN_E_* (<0) on argument errors (nothing was launched); -(hipError_t) on a launch error;
@@ -75,9 +75,29 @@ int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const float* g_out
                      float* gw_kcl, void* workspace,
                      int B, int C, int T, int K, int L, int stride, float eps, int mode, void* stream);
 
+/* Fused attention core softmax(scale * Q K^T) V, exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32), scores never
+ * materialised.  Replaces IGN/layers/SelfAttention_Family.py:56-75 (FullAttention: no mask, dropout 0) and the
+ * attention inside nn.TransformerEncoderLayer of IGN/model/eegcnn.py:219-228.
+ *   q (B,L,H,E), k/v (B,S,H,E): unit stride over E, stride E over H; *_sb / *_sl are the ELEMENT strides of the
+ *   batch and sequence axes (multiples of 4), so packed qkv projections can be passed without a copy.
+ *   out (B,L,H,E) contiguous; lse (B,H,L) log-sum-exp of the scaled scores (saved for the backward).
+ *   E in {16, 32, 64, 128}; all pointers 16-byte aligned.                                                          */
+int ign_attn_fwd(const float* q, const float* k, const float* v, float* out, float* lse,
+                 int B, int L, int S, int H, int E,
+                 long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl,
+                 float scale, void* stream);
+/* Backward: gq (B,L,H,E), gk/gv (B,S,H,E) contiguous outputs (overwritten); gout (B,L,H,E) contiguous;
+ * delta_ws: B*H*L floats of workspace.  dQ recomputes the scores instead of using float atomics: deterministic.  */
+int ign_attn_bwd(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* gout,
+                 float* gq, float* gk, float* gv, float* delta_ws,
+                 int B, int L, int S, int H, int E,
+                 long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl,
+                 float scale, void* stream);
+
 /* Per-kernel HIP-event timing (measurement only; off by default).  When enabled every kernel launch made by
  * this library is bracketed by hipEventRecord on the caller's stream.  ign_timing_read() waits for the recorded
- * events of `label` ("shp_fwd", "shp_bwd", "reduce_parts", "instnorm"), and returns the accumulated
+ * events of `label` ("shp_fwd", "shp_bwd", "reduce_parts", "instnorm", "attn_fwd", "attn_bwd_dkdv", "attn_bwd_dq",
+ * "attn_delta"), and returns the accumulated
  * device milliseconds and launch count since the last enable.  Not for use under graph capture.             */
 int ign_timing_enable(int on);
 int ign_timing_read(const char* label, double* total_ms, long long* launches);

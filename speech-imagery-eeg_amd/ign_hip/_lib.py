@@ -13,7 +13,7 @@ _LIB = None
 
 c_f = ctypes.POINTER(ctypes.c_float)
 c_i32 = ctypes.POINTER(ctypes.c_int32)
-vp, ci, cf, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+vp, ci, cf, sz, ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_longlong
 
 # name -> (restype, argtypes); must list every symbol include/ign_abi.h declares (tests/test_abi_symbols.py)
 SIGNATURES = {
@@ -22,6 +22,8 @@ SIGNATURES = {
     "ign_instnorm_fwd": (ci, [vp, vp, vp, ci, ci, ci, cf, vp]),
     "ign_shapelet_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),
     "ign_shapelet_bwd_workspace_bytes": (sz, [ci, ci, ci, ci, ci, ci, ci]),
+    "ign_attn_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
+    "ign_attn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
     "ign_timing_enable": (ci, [ci]),
     "ign_timing_read": (ci, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
     "ign_shapelet_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),

@@ -117,3 +117,52 @@ def shapelet_bank(xn, weights, eps, mode=DIST_L1 | GATE_RBF, strides=None, thres
     strides = strides or [1] * G
     params = list(weights) + (list(thresholds) if (mode & GATE_LTS) else [])
     return ShapeletBankFn.apply(xn, eps, mode, tuple(strides), G, *params)
+
+
+def _bl_strides(t, name):
+    """(B,L,H,E) tensor -> element strides of the batch and sequence axes; inner (H,E) block must be dense."""
+    B, L, H, E = t.shape
+    if t.stride(3) != 1 or t.stride(2) != E:
+        raise _lib.IgnError(f"attention: {name} needs unit stride over E and stride E over H, got {t.stride()}")
+    return t.stride(0), t.stride(1)
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(scale * Q K^T) V with q (B,L,H,E), k/v (B,S,H,E) -> (B,L,H,E); IGN/layers/SelfAttention_Family.py:56-75."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        _need_gpu("attention", q, k, v)
+        B, L, H, E = q.shape
+        S = k.shape[1]
+        fix = lambda t: t if (t.stride(3) == 1 and t.stride(2) == E and t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0
+                              and t.data_ptr() % 16 == 0) else t.contiguous()
+        q, k, v = fix(q), fix(k), fix(v)
+        out = torch.empty(B, L, H, E, device=q.device, dtype=torch.float32)
+        lse = torch.empty(B, H, L, device=q.device, dtype=torch.float32)
+        (qb, ql), (kb, kl), (vb, vl) = _bl_strides(q, "q"), _bl_strides(k, "k"), _bl_strides(v, "v")
+        _lib.check(_lib.lib().ign_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, L, S, H, E,
+                                           qb, ql, kb, kl, vb, vl, float(scale), _stream()), "ign_attn_fwd")
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        q, k, v, out, lse = ctx.saved_tensors
+        B, L, H, E = q.shape
+        S = k.shape[1]
+        gout = gout.contiguous()
+        gq = torch.empty(B, L, H, E, device=q.device, dtype=torch.float32)
+        gk = torch.empty(B, S, H, E, device=q.device, dtype=torch.float32)
+        gv = torch.empty_like(gk)
+        delta = torch.empty(B, H, L, device=q.device, dtype=torch.float32)
+        (qb, ql), (kb, kl), (vb, vl) = _bl_strides(q, "q"), _bl_strides(k, "k"), _bl_strides(v, "v")
+        _lib.check(_lib.lib().ign_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(gout), _ptr(gq), _ptr(gk),
+                                           _ptr(gv), _ptr(delta), B, L, S, H, E, qb, ql, kb, kl, vb, vl, ctx.scale,
+                                           _stream()), "ign_attn_bwd")
+        return gq, gk, gv, None
+
+
+def attention(q, k, v, scale):
+    return AttentionFn.apply(q, k, v, scale)

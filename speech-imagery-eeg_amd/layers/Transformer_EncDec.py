@@ -1,0 +1,46 @@
+"""Encoder stack of the Transformer baseline (IGN/layers/Transformer_EncDec.py:27-80): post-norm layers with a
+1x1-Conv1d feed-forward, and a final LayerNorm.  Decoder / ConvLayer of the reference file are unused by the
+classification path and not rebuilt."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, attention, d_model, d_ff=None, dropout=0.1, activation="relu"):
+        super().__init__()
+        d_ff = d_ff or 4 * d_model
+        self.attention = attention
+        self.conv1 = nn.Conv1d(in_channels=d_model, out_channels=d_ff, kernel_size=1)
+        self.conv2 = nn.Conv1d(in_channels=d_ff, out_channels=d_model, kernel_size=1)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout = nn.Dropout(dropout)
+        self.activation = F.relu if activation == "relu" else F.gelu
+
+    def forward(self, x, attn_mask=None, tau=None, delta=None):
+        new_x, attn = self.attention(x, x, x, attn_mask=attn_mask, tau=tau, delta=delta)
+        x = self.norm1(x + self.dropout(new_x))
+        # the k=1 convolutions are plain GEMMs over (B*T, d): apply them without the two transposes
+        y = F.linear(x, self.conv1.weight.squeeze(-1), self.conv1.bias)
+        y = self.dropout(self.activation(y))
+        y = self.dropout(F.linear(y, self.conv2.weight.squeeze(-1), self.conv2.bias))
+        return self.norm2(x + y), attn
+
+
+class Encoder(nn.Module):
+    def __init__(self, attn_layers, conv_layers=None, norm_layer=None):
+        super().__init__()
+        if conv_layers is not None:
+            raise NotImplementedError("distilling conv layers are not used by the classification path")
+        self.attn_layers = nn.ModuleList(attn_layers)
+        self.conv_layers = None
+        self.norm = norm_layer
+
+    def forward(self, x, attn_mask=None, tau=None, delta=None):
+        attns = []
+        for layer in self.attn_layers:
+            x, attn = layer(x, attn_mask=attn_mask, tau=tau, delta=delta)
+            attns.append(attn)
+        if self.norm is not None:
+            x = self.norm(x)
+        return x, attns

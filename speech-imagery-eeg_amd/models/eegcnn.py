@@ -1,0 +1,150 @@
+"""EEG-CNN + Transformer-encoder baseline (IGN/model/eegcnn.py:11-397), working semantics only.
+
+What "working" means for the reference: the input is (B, C, T); no padding mask (the mask
+down-sampling of eegcnn.py:260-263 cannot match the CNN output length, so the only path that runs is mask=None ->
+all-ones); the CNN hyper-parameters are the constructor defaults F1=8, D=8, k1=125, k2=25, P1=2, P2=5 because
+``run.py`` defines ``--eegcnn_cnn_f1`` ... while the model reads ``cnn_filter1`` ... (D11); the "positional" code is
+indexed by BATCH position and broadcast over time (D10: ``pe[:x.size(0)]`` on a batch-first tensor).  All of that is
+reproduced, since parity is defined against what the reference computes.  The per-forward debug prints are not.
+
+State-dict keys match the reference (``eegcnn.block1_conv1.weight`` ... ``transformer_encoder.layers.{i}.self_attn.
+in_proj_weight`` ... ``classifier.weight``).  The encoder layers are evaluated explicitly (post-norm, relu) so the
+attention core can run on the fused fp32-MFMA kernel instead of ``nn.MultiheadAttention``'s materialised scores.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ign_hip import ops
+from utils.shapelet_util import ModelInfo
+
+
+class PositionalEncoding(nn.Module):
+    def __init__(self, d_model, dropout=0.1, max_len=5000):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        pos = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(max_len, d_model)
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        self.register_buffer('pe', pe.unsqueeze(0).transpose(0, 1))      # (max_len, 1, d)
+
+    def forward(self, x):
+        # x is batch-first (B, S, d): the slice is taken along the BATCH axis and broadcast over S (D10)
+        return self.dropout(x + self.pe[:x.size(0), :])
+
+
+class EEGcnn(nn.Module):
+    """Temporal conv 1xk1 -> BN -> depthwise spatial Cx1 -> BN/ELU/AvgPool(P1) -> depthwise 1xk2 -> pointwise ->
+    BN/ELU/AvgPool(P2)   (IGN/model/eegcnn.py:67-108).  (B, C, T) -> (B, F2, T/(P1*P2))."""
+
+    def __init__(self, Chans=122, kernLength1=125, kernLength2=25, F1=8, D=8, F2=64, P1=2, P2=5, dropoutRate=0.1):
+        super().__init__()
+        Chans = int(Chans)
+        self.block1_conv1 = nn.Conv2d(1, F1, (1, kernLength1), padding='same', bias=False)
+        self.block1_bn1 = nn.BatchNorm2d(F1)
+        self.block1_depthwise = nn.Conv2d(F1, D * F1, (Chans, 1), groups=F1, bias=False)
+        self.block1_bn2 = nn.BatchNorm2d(D * F1)
+        self.block1_elu = nn.ELU()
+        self.block1_pool = nn.AvgPool2d((1, P1))
+        self.block1_drop = nn.Dropout(p=dropoutRate)
+        self.block2_conv1 = nn.Conv2d(D * F1, D * F1, (1, kernLength2), padding='same', groups=D * F1, bias=False)
+        self.block2_conv2 = nn.Conv2d(D * F1, F2, 1, bias=False)
+        self.block2_bn = nn.BatchNorm2d(F2)
+        self.block2_elu = nn.ELU()
+        self.block2_pool = nn.AvgPool2d((1, P2))
+        self.block2_drop = nn.Dropout(p=dropoutRate)
+
+    def forward(self, x):
+        x = x.unsqueeze(1)                                           # (B,1,C,T)
+        x = self.block1_bn1(self.block1_conv1(x))
+        x = self.block1_bn2(self.block1_depthwise(x))
+        x = self.block1_drop(self.block1_pool(self.block1_elu(x)))
+        x = self.block2_conv2(self.block2_conv1(x))
+        x = self.block2_drop(self.block2_pool(self.block2_elu(self.block2_bn(x))))
+        return x.squeeze(2)                                          # (B,F2,T')
+
+
+def _encoder_layer_forward(layer, x, n_heads):
+    """One post-norm nn.TransformerEncoderLayer (relu) evaluated with the fused attention core."""
+    B, S, d = x.shape
+    sa = layer.self_attn
+    qkv = F.linear(x, sa.in_proj_weight, sa.in_proj_bias).view(B, S, 3, n_heads, d // n_heads)
+    o = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 1.0 / math.sqrt(d // n_heads))
+    a = F.linear(o.reshape(B, S, d), sa.out_proj.weight, sa.out_proj.bias)
+    x = layer.norm1(x + layer.dropout1(a))
+    ff = layer.linear2(layer.dropout(F.relu(layer.linear1(x))))
+    return layer.norm2(x + layer.dropout2(ff))
+
+
+class EEGCNNTransformer(nn.Module):
+    def __init__(self, configs=None, **kwargs):
+        super().__init__()
+        g = (lambda *names, default=None: next((getattr(configs, n) for n in names if hasattr(configs, n)), default)) \
+            if configs is not None and hasattr(configs, '__dict__') else \
+            (lambda *names, default=None: next((kwargs[n] for n in names if n in kwargs), default))
+        input_channels = g('enc_in', 'input_channels', default=122)
+        seq_len = g('seq_len', default=845)
+        num_classes = g('c_out', 'num_class', 'num_classes', default=3)
+        dropout1 = g('eegcnn_dropout1', 'dropout1', default=0.1)
+        dropout2 = g('eegcnn_dropout2', 'dropout2', default=0.1)
+        num_layers = g('eegcnn_layers', 'num_layers', default=0)
+        pooling = g('eegcnn_pooling', 'pooling', default=None)
+        f1 = g('cnn_filter1', 'F1', default=8)                       # D11: NOT --eegcnn_cnn_f1
+        dmul = g('cnn_filter2', 'D', default=8)
+        k1 = g('kernel_length1', 'kernLength1', default=125)
+        k2 = g('kernel_length2', 'kernLength2', default=25)
+        p1 = g('pooling1', 'P1', default=2)
+        p2 = g('pooling2', 'P2', default=5)
+        d_model = g('d_model', default=None)
+        self.n_heads = g('eegcnn_n_heads', 'n_heads', default=8)
+        d_ff = g('eegcnn_d_ff', 'dim_feedforward', default=256)
+        self.output_attention = g('output_attention', default=False)
+
+        self.input_channels, self.seq_len, self.num_classes = input_channels, seq_len, num_classes
+        self.num_layers, self.pooling = num_layers, pooling
+        self.eegcnn = EEGcnn(Chans=input_channels, kernLength1=k1, kernLength2=k2, F1=f1, D=dmul, F2=f1 * dmul,
+                             P1=p1, P2=p2, dropoutRate=dropout1)
+        self.cnn_out_channels = f1 * dmul
+        if num_layers > 0:
+            d_model = d_model or self.cnn_out_channels
+            self.pos_encoder = PositionalEncoding(d_model, dropout=dropout2, max_len=5000)
+            layer = nn.TransformerEncoderLayer(d_model=d_model, nhead=self.n_heads, dim_feedforward=d_ff,
+                                               dropout=dropout2, batch_first=True)
+            self.transformer_encoder = nn.TransformerEncoder(layer, num_layers=num_layers)
+            self.cnn_projection = nn.Linear(self.cnn_out_channels, d_model) if self.cnn_out_channels != d_model \
+                else nn.Identity()
+            self.d_model = d_model
+        else:
+            self.d_model = self.cnn_out_channels
+        self.classifier = nn.Linear((seq_len if pooling is None else 1) * self.d_model, num_classes)
+
+    def features(self, x):
+        """(B,C,T) -> encoder output (B,S,d)."""
+        h = self.eegcnn(x).permute(0, 2, 1)
+        if self.num_layers > 0:
+            h = self.pos_encoder(self.cnn_projection(h))
+            for layer in self.transformer_encoder.layers:
+                h = _encoder_layer_forward(layer, h, self.n_heads)
+        return h
+
+    def forward(self, x, padding_mask=None, *unused, **kw):
+        if padding_mask is not None:
+            raise ValueError("EEGCNNTransformer: the reference's mask path cannot run (mask length 498 vs 100 CNN steps, "
+                             "SURVEY D9); call it with the (B,C,T) tensor only")
+        h = self.features(x)
+        if self.pooling is None:
+            h = h.reshape(h.shape[0], -1)
+        elif self.pooling == "mean":
+            h = h.sum(dim=1) / h.shape[1]            # masked mean with an all-ones mask
+        elif self.pooling == "sum":
+            h = h.sum(dim=1)
+        elif self.pooling == "top":
+            h = h[:, 0, :]
+        else:
+            raise ValueError(f"Unsupported pooling method: {self.pooling}")
+        logits = self.classifier(h)
+        return logits, ModelInfo(loss=torch.zeros((), device=logits.device), preds=logits)

@@ -1,0 +1,150 @@
+"""GPU parity of the two baselines: the fused fp32-MFMA attention core, the Transformer-encoder model and the EEG-CNN
+model, against golden fixtures produced by the reference and against a plain fp32 torch reference of the same op."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden, make_cfg, sd_from
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu()
+    b = torch.as_tensor(np.asarray(b)).double() if not torch.is_tensor(b) else b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _attn_ref(q, k, v, scale):
+    """The reference formula (SelfAttention_Family.py:56-75) in float64 on the CPU."""
+    q, k, v = (t.detach().double().cpu() for t in (q, k, v))
+    s = torch.einsum("blhe,bshe->bhls", q, k)
+    return torch.einsum("bhls,bshd->blhd", torch.softmax(scale * s, dim=-1), v)
+
+
+def test_attention_core_golden():
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    g = golden("attention_core")
+    q, k, v = (_t(g[n], dev).requires_grad_(True) for n in ("q", "k", "v"))
+    o = ops.attention(q, k, v, 1.0 / math.sqrt(q.shape[-1]))
+    (o * _t(g["go"], dev)).sum().backward()
+    assert _rel(o, g["o"]) < 1e-4
+    assert _rel(q.grad, g["gq"]) < 1e-4 and _rel(k.grad, g["gk"]) < 1e-4 and _rel(v.grad, g["gv"]) < 1e-4
+
+
+@pytest.mark.parametrize("B,L,S,H,E", [(2, 1000, 1000, 8, 64), (3, 100, 100, 8, 64), (2, 130, 75, 2, 32),
+                                       (1, 33, 257, 3, 16), (2, 64, 64, 1, 128)])
+def test_attention_vs_fp64_reference(B, L, S, H, E):
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    g = torch.Generator().manual_seed(L * 7 + E)
+    q = torch.randn(B, L, H, E, generator=g).to(dev).requires_grad_(True)
+    k = torch.randn(B, S, H, E, generator=g).to(dev).requires_grad_(True)
+    v = torch.randn(B, S, H, E, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(B, L, H, E, generator=g)
+    scale = 1.0 / math.sqrt(E)
+    o = ops.attention(q, k, v, scale)
+    (o * go.to(dev)).sum().backward()
+    qr, kr, vr = (t.detach().double().cpu().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("blhe,bshe->bhls", qr, kr)
+    oref = torch.einsum("bhls,bshd->blhd", torch.softmax(scale * s, dim=-1), vr)
+    (oref * go.double()).sum().backward()
+    assert _rel(o, oref) < 2e-5, "forward"
+    for name, a, b in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+        assert _rel(a, b) < 5e-5, name
+
+
+def test_attention_packed_qkv_strides_and_determinism():
+    """q/k/v as strided views of one packed (B,S,3,H,E) projection (the nn.MultiheadAttention in_proj layout)."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    torch.manual_seed(3)
+    B, S, H, E = 4, 100, 8, 64
+    qkv = torch.randn(B, S, 3, H, E, device=dev, requires_grad=True)
+    o1 = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0.125)
+    g1, = torch.autograd.grad(o1.sum() + (o1 * o1).sum(), qkv, retain_graph=True)
+    o2 = ops.attention(qkv[:, :, 0].contiguous(), qkv[:, :, 1].contiguous(), qkv[:, :, 2].contiguous(), 0.125)
+    assert torch.equal(o1, o2)
+    g2, = torch.autograd.grad(o1.sum() + (o1 * o1).sum(), qkv)
+    assert torch.equal(g1, g2), "backward not bitwise reproducible"
+    oref = _attn_ref(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0.125)
+    assert _rel(o1, oref) < 2e-5
+
+
+def test_transformer_baseline_golden():
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models.Transformer import Model
+    g = golden("transformer_bm")
+    m = Model(make_cfg())
+    assert set(m.state_dict().keys()) == {k[3:] for k in g if k.startswith("sd.")}
+    m.load_state_dict(sd_from(g))
+    m.to(dev).train()
+    x, mask, y = _t(g["x"], dev), _t(g["mask"], dev), _t(g["y"], dev)
+    out = m(x, mask, None, None)
+    loss = F.cross_entropy(out, y)
+    loss.backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=2e-4, atol=2e-4)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    for n, p in m.named_parameters():
+        if "grad." + n not in g:                 # temporal_embedding: constructed but never called on this path
+            assert p.grad is None, n
+            continue
+        ref = g["grad." + n]
+        scale = max(float(np.abs(ref).max()), 1e-7)
+        err = float(np.abs(p.grad.cpu().numpy() - ref).max())
+        assert err <= 3e-4 * scale + 1e-8, f"{n}: {err:.3e} vs scale {scale:.3e}"
+
+
+def test_eegcnn_baseline_golden():
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models.eegcnn import EEGCNNTransformer
+    g = golden("eegcnn_ch")
+    m = EEGCNNTransformer(make_cfg(enc_in=122, seq_len=1000, num_class=3, c_out=3, d_model=128))
+    sd = sd_from(g)
+    missing = set(m.state_dict().keys()) - set(sd)
+    assert missing == {"pos_encoder.pe"}, missing           # the sin/cos table is deterministic, not in the fixture
+    m.load_state_dict(sd, strict=False)
+    m.to(dev).train()
+    x, y = _t(g["x"], dev), _t(g["y"], dev)
+    out, info = m(x)
+    loss = F.cross_entropy(out, y) + info.loss.mean()
+    loss.backward()
+    feat = m.eegcnn(x)              # same order as the fixture script: two train-mode passes update the BN stats twice
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), g["feat"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=3e-4, atol=3e-4)
+    assert abs(loss.item() - float(g["loss"])) < 2e-4
+    for n, p in m.named_parameters():
+        ref = g["grad." + n]
+        scale = max(float(np.abs(ref).max()), 1e-7)
+        if scale < 1e-5:       # e.g. block1_bn1.bias: a per-channel constant removed again by block1_bn2 -> true grad 0
+            assert float(p.grad.abs().max()) < 1e-5, f"{n}: not noise-level"
+            continue
+        err = float(np.abs(p.grad.cpu().numpy() - ref).max())
+        assert err <= 1e-3 * scale + 1e-7, f"{n}: {err:.3e} vs scale {scale:.3e}"
+    for k in (k for k in g if k.startswith("sd_after.")):
+        np.testing.assert_allclose(m.state_dict()[k[9:]].cpu().numpy(), g[k], rtol=1e-3, atol=1e-4, err_msg=k)
+    m.eval()
+    with torch.no_grad():
+        oe, _ = m(x)
+    np.testing.assert_allclose(oe.cpu().numpy(), g["eval_out"], rtol=3e-4, atol=3e-4)
+    with pytest.raises(ValueError):
+        m(x, torch.ones(4, 1000, device=dev))                # the reference's mask path cannot run (D9)
