@@ -121,7 +121,7 @@ def main():
     torch.set_num_threads(host_cores())
     import speech_imagery_eeg_amd  # noqa: F401
     from ign_hip import _lib
-    from ign_hip.ddp import FlatParamBucket
+    from ign_hip.ddp import FlatAdam, FlatParamBucket
     from models.InterpGN import InterpGN
 
     cfg = ch_config()
@@ -129,7 +129,7 @@ def main():
     torch.manual_seed(0)                       # same initial replica on every rank
     model = InterpGN(cfg).to(dev).train()
     bucket = FlatParamBucket(model, world)     # flat fp32 grad bucket: one RCCL all-reduce per step
-    opt = torch.optim.Adam(model.parameters(), lr=5e-3, fused=True)
+    opt = FlatAdam(bucket, lr=5e-3)            # one ign_adam_step launch over the flat parameter buffer
 
     n_batches = min(args.steps + args.warmup, max(1, N_TRAIN // (B * world)))
     log(f"generating {n_batches} synthetic batches on the host ...")

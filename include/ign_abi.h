@@ -94,10 +94,32 @@ int ign_attn_bwd(const float* q, const float* k, const float* v, const float* ou
                  long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl,
                  float scale, void* stream);
 
+/* Skinny expert-head GEMM  out[b,n] = sum_f X[b,f] W[n,f] (+ bias[n]),  N <= 16 classes, F % 4 == 0, row pitch ldx.
+ * Replaces nn.Linear at IGN/model/Shapelet.py:171,200 (SBM head), IGN/model/Transformer.py:72,109,
+ * IGN/model/FullyConvNet.py:50,58.  Backward: gX (B,ldx) and/or gW (N,F), gbias (N) (any may be NULL); sums over the
+ * batch run in ascending order (deterministic).                                                                    */
+int ign_head_fwd(const float* X, const float* W, const float* bias, float* out, int B, int F, int N, long long ldx,
+                 void* stream);
+int ign_head_bwd(const float* g_out, const float* X, const float* W, float* gX, float* gW, float* gbias,
+                 int B, int F, int N, long long ldx, void* stream);
+
+/* Gini-index gate of the two experts, forward and backward.  Replaces IGN/model/InterpGN.py:44-52:
+ * eta = (N*sum softmax(sbm)^2 - 1)/(N-1); if use_gating_value and eta > gating_value: eta = 1 (test time);
+ * out = eta*sbm + (1-eta)*dnn.   out (B,N), eta (B).  Backward: geta (B) may be NULL.                              */
+int ign_gate_fwd(const float* sbm, const float* dnn, float* out, float* eta, int B, int N, float gating_value,
+                 int use_gating_value, void* stream);
+int ign_gate_bwd(const float* sbm, const float* dnn, const float* gout, const float* geta, float* gsbm, float* gdnn,
+                 int B, int N, float gating_value, int use_gating_value, void* stream);
+
+/* One Adam step over flat buffers (torch.optim.Adam semantics, no weight decay / amsgrad): replaces the per-tensor
+ * optimizer.step() of IGN/exp/experiment_classification.py:338.  `step` is the 1-based step count.               */
+int ign_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                  float beta1, float beta2, float eps, int step, void* stream);
+
 /* Per-kernel HIP-event timing (measurement only; off by default).  When enabled every kernel launch made by
  * this library is bracketed by hipEventRecord on the caller's stream.  ign_timing_read() waits for the recorded
  * events of `label` ("shp_fwd", "shp_bwd", "reduce_parts", "instnorm", "attn_fwd", "attn_bwd_dkdv", "attn_bwd_dq",
- * "attn_delta"), and returns the accumulated
+ * "attn_delta", "head_fwd", "head_bwd_x", "head_bwd_w", "adam"), and returns the accumulated
  * device milliseconds and launch count since the last enable.  Not for use under graph capture.             */
 int ign_timing_enable(int on);
 int ign_timing_read(const char* label, double* total_ms, long long* launches);

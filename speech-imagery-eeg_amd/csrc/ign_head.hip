@@ -1,0 +1,272 @@
+// Expert-head GEMMs, the gini gate and the flat Adam update: the small HBM-bound pieces of the training step.
+//
+//  * head GEMM  out[b,n] = sum_f X[b,f] W[n,f] (+ bias[n])  with N = number of classes (3..16) -- "skinny":
+//    IGN/model/Shapelet.py:171,200 (SBM head, F = G*K*C = 2440), IGN/model/Transformer.py:72,109 (F = T*d = 512000),
+//    IGN/model/FullyConvNet.py:50,58.  N is far too small for an MFMA tile to pay (a 32x32 tile would be >90 % padding)
+//    and the op moves 4*(B*F + N*F) bytes for 2*B*F*N flops (intensity ~N/2 flop/byte): HBM/L2 bound, so it is a
+//    coalesced float4 streaming kernel with N accumulators per thread and a block reduction.
+//  * gini gate  eta = (N*sum softmax(s)^2 - 1)/(N-1); out = eta*s + (1-eta)*d   IGN/model/InterpGN.py:44-52, fwd + bwd.
+//  * Adam       one launch over the flat parameter / gradient / moment buffers (torch.optim.Adam semantics,
+//    IGN/exp/experiment_classification.py:136,338).
+#include "ign_common.h"
+
+constexpr int HEAD_NMAX = 16;
+
+// ------------------------------------------------------------------------------------------------ head forward
+__global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       int B, int F, int N, long long ldx) {
+    __shared__ float red[4][HEAD_NMAX];
+    const int b = blockIdx.x;
+    const float* x = X + (long long)b * ldx;
+    float acc[HEAD_NMAX];
+#pragma unroll
+    for (int n = 0; n < HEAD_NMAX; ++n) acc[n] = 0.f;
+    const int F4 = F & ~3;
+    for (int f = threadIdx.x * 4; f < F4; f += 1024) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + f);
+#pragma unroll
+        for (int n = 0; n < HEAD_NMAX; ++n)
+            if (n < N) {
+                const float4 wv = *reinterpret_cast<const float4*>(W + (long long)n * F + f);
+                acc[n] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+            }
+    }
+    for (int f = F4 + threadIdx.x; f < F; f += 256)
+#pragma unroll
+        for (int n = 0; n < HEAD_NMAX; ++n)
+            if (n < N) acc[n] += x[f] * W[(long long)n * F + f];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < HEAD_NMAX; ++n) {
+        float v = acc[n];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave][n] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        const int n = threadIdx.x;
+        out[(long long)b * N + n] = red[0][n] + red[1][n] + red[2][n] + red[3][n] + (bias ? bias[n] : 0.f);
+    }
+}
+
+// gX[b,f] = sum_n g[b,n] W[n,f]
+__global__ void __launch_bounds__(256) head_bwd_x_kernel(const float* __restrict__ g, const float* __restrict__ W,
+                                                         float* __restrict__ gX, int B, int F, int N, long long ldx) {
+    const int b = blockIdx.y;
+    const int f = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (f >= F) return;
+    float gn[HEAD_NMAX];
+#pragma unroll
+    for (int n = 0; n < HEAD_NMAX; ++n) gn[n] = n < N ? g[(long long)b * N + n] : 0.f;
+    if (f + 3 < F) {
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int n = 0; n < HEAD_NMAX; ++n)
+            if (n < N) {
+                const float4 wv = *reinterpret_cast<const float4*>(W + (long long)n * F + f);
+                r.x += gn[n] * wv.x; r.y += gn[n] * wv.y; r.z += gn[n] * wv.z; r.w += gn[n] * wv.w;
+            }
+        *reinterpret_cast<float4*>(gX + (long long)b * ldx + f) = r;
+    } else {
+        for (int ff = f; ff < F; ++ff) {
+            float r = 0.f;
+            for (int n = 0; n < N; ++n) r += gn[n] * W[(long long)n * F + ff];
+            gX[(long long)b * ldx + ff] = r;
+        }
+    }
+}
+
+// gW[n,f] = sum_b g[b,n] X[b,f]   (b ascending: deterministic);  gbias[n] = sum_b g[b,n]
+__global__ void __launch_bounds__(256) head_bwd_w_kernel(const float* __restrict__ g, const float* __restrict__ X,
+                                                         float* __restrict__ gW, float* __restrict__ gbias, int B, int F,
+                                                         int N, long long ldx) {
+    extern __shared__ float gs[];               // [B*N]
+    for (int i = threadIdx.x; i < B * N; i += 256) gs[i] = g[i];
+    __syncthreads();
+    if (gbias && blockIdx.x == 0 && threadIdx.x < N) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += gs[b * N + threadIdx.x];
+        gbias[threadIdx.x] = s;
+    }
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    float acc[HEAD_NMAX];
+#pragma unroll
+    for (int n = 0; n < HEAD_NMAX; ++n) acc[n] = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float xv = X[(long long)b * ldx + f];
+#pragma unroll
+        for (int n = 0; n < HEAD_NMAX; ++n)
+            if (n < N) acc[n] = fmaf(gs[b * N + n], xv, acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < HEAD_NMAX; ++n)
+        if (n < N) gW[(long long)n * F + f] = acc[n];
+}
+
+// ------------------------------------------------------------------------------------------------ gini gate
+// forward: q = softmax(s); G = sum q^2; eta = (N G - 1)/(N - 1); [eta > thr -> 1]; out = eta s + (1 - eta) d
+// backward: d eta / d s_j = (2N/(N-1)) q_j (q_j - G); ds = eta*gout + (sum_n gout_n (s_n - d_n)) * deta/ds ; dd = (1-eta)*gout
+__global__ void __launch_bounds__(256) gate_fwd_kernel(const float* __restrict__ s, const float* __restrict__ d,
+                                                       float* __restrict__ out, float* __restrict__ eta_out, int B, int N,
+                                                       float thr, int use_thr) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* sr = s + (long long)b * N;
+    float mx = -INFINITY;
+    for (int n = 0; n < N; ++n) mx = fmaxf(mx, sr[n]);
+    float z = 0.f, z2 = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float e = expf(sr[n] - mx);
+        z += e;
+        z2 += e * e;
+    }
+    float eta = ((float)N * (z2 / (z * z)) - 1.f) / (float)(N - 1);
+    if (use_thr && eta > thr) eta = 1.f;
+    eta_out[b] = eta;
+    for (int n = 0; n < N; ++n) out[(long long)b * N + n] = eta * sr[n] + (1.f - eta) * d[(long long)b * N + n];
+}
+
+__global__ void __launch_bounds__(256) gate_bwd_kernel(const float* __restrict__ s, const float* __restrict__ d,
+                                                       const float* __restrict__ gout, const float* __restrict__ geta,
+                                                       float* __restrict__ gs, float* __restrict__ gd, int B, int N,
+                                                       float thr, int use_thr) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* sr = s + (long long)b * N;
+    const float* dr = d + (long long)b * N;
+    const float* gr = gout + (long long)b * N;
+    float mx = -INFINITY;
+    for (int n = 0; n < N; ++n) mx = fmaxf(mx, sr[n]);
+    float z = 0.f, z2 = 0.f, dot = geta ? geta[b] : 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float e = expf(sr[n] - mx);
+        z += e;
+        z2 += e * e;
+        dot += gr[n] * (sr[n] - dr[n]);
+    }
+    const float G = z2 / (z * z);
+    float eta = ((float)N * G - 1.f) / (float)(N - 1);
+    float c = 2.f * (float)N / (float)(N - 1) * dot;
+    if (use_thr && eta > thr) { eta = 1.f; c = 0.f; }         // the hard branch has no gradient through eta
+    for (int n = 0; n < N; ++n) {
+        const float q = expf(sr[n] - mx) / z;
+        gs[(long long)b * N + n] = eta * gr[n] + c * q * (q - G);
+        gd[(long long)b * N + n] = (1.f - eta) * gr[n];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float lr, float b1, float b2,
+                                                   float eps, float bc1, float bc2_sqrt) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float step = lr / bc1;
+    if (i + 3 < n) {
+        float4 pv = *reinterpret_cast<float4*>(p + i);
+        const float4 gv = *reinterpret_cast<const float4*>(g + i);
+        float4 mv = *reinterpret_cast<float4*>(m + i);
+        float4 vv = *reinterpret_cast<float4*>(v + i);
+#define ADAM1(P, G, M, V)                                   \
+        M = b1 * M + (1.f - b1) * G;                         \
+        V = b2 * V + (1.f - b2) * G * G;                     \
+        P -= step * M / (sqrtf(V) / bc2_sqrt + eps);
+        ADAM1(pv.x, gv.x, mv.x, vv.x) ADAM1(pv.y, gv.y, mv.y, vv.y) ADAM1(pv.z, gv.z, mv.z, vv.z) ADAM1(pv.w, gv.w, mv.w, vv.w)
+        *reinterpret_cast<float4*>(p + i) = pv;
+        *reinterpret_cast<float4*>(m + i) = mv;
+        *reinterpret_cast<float4*>(v + i) = vv;
+    } else {
+        for (long long j = i; j < n; ++j) {
+            float pv = p[j], gv = g[j], mv = m[j], vv = v[j];
+            ADAM1(pv, gv, mv, vv)
+            p[j] = pv; m[j] = mv; v[j] = vv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" int ign_head_fwd(const float* X, const float* W, const float* bias, float* out, int B, int F, int N,
+                            long long ldx, void* stream) {
+    if (!X || !W || !out || B <= 0 || F <= 0 || N <= 0 || ldx < F) {
+        ign_set_error("ign_head_fwd: null pointer or bad dimension (B=%d F=%d N=%d ldx=%lld)", B, F, N, ldx);
+        return IGN_E_ARG;
+    }
+    if (N > HEAD_NMAX) { ign_set_error("ign_head_fwd: N=%d classes > %d", N, HEAD_NMAX); return IGN_E_UNSUP; }
+    if ((ldx & 3) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15) || (F & 3)) {
+        ign_set_error("ign_head_fwd: X/W must be 16-byte aligned with F and ldx multiples of 4 (F=%d ldx=%lld)", F, ldx);
+        return IGN_E_ARG;
+    }
+    IgnScopedTimer tm("head_fwd", (hipStream_t)stream);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, X, W, bias, out, B, F, N, ldx);
+    return ign_check_launch("head_fwd_kernel");
+}
+
+extern "C" int ign_head_bwd(const float* g, const float* X, const float* W, float* gX, float* gW, float* gbias, int B,
+                            int F, int N, long long ldx, void* stream) {
+    if (!g || !X || !W || B <= 0 || F <= 0 || N <= 0 || ldx < F) {
+        ign_set_error("ign_head_bwd: null pointer or bad dimension");
+        return IGN_E_ARG;
+    }
+    if (N > HEAD_NMAX) { ign_set_error("ign_head_bwd: N=%d classes > %d", N, HEAD_NMAX); return IGN_E_UNSUP; }
+    if ((ldx & 3) || (F & 3) || ((uintptr_t)W & 15) || (gX && ((uintptr_t)gX & 15))) {
+        ign_set_error("ign_head_bwd: W/gX must be 16-byte aligned with F and ldx multiples of 4");
+        return IGN_E_ARG;
+    }
+    if ((size_t)B * N * 4 > 64 * 1024) { ign_set_error("ign_head_bwd: B*N=%d too large for the LDS copy of g", B * N); return IGN_E_TOOBIG; }
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (gX) {
+        IgnScopedTimer tm("head_bwd_x", s);
+        hipLaunchKernelGGL(head_bwd_x_kernel, dim3((F / 4 + 255) / 256, B), dim3(256), 0, s, g, W, gX, B, F, N, ldx);
+        if ((rc = ign_check_launch("head_bwd_x_kernel"))) return rc;
+    }
+    if (gW) {
+        IgnScopedTimer tm("head_bwd_w", s);
+        hipLaunchKernelGGL(head_bwd_w_kernel, dim3((F + 255) / 256), dim3(256), (size_t)B * N * 4, s, g, X, gW, gbias, B, F, N, ldx);
+        if ((rc = ign_check_launch("head_bwd_w_kernel"))) return rc;
+    }
+    return 0;
+}
+
+extern "C" int ign_gate_fwd(const float* sbm, const float* dnn, float* out, float* eta, int B, int N, float gating_value,
+                            int use_gating_value, void* stream) {
+    if (!sbm || !dnn || !out || !eta || B <= 0 || N < 2) {
+        ign_set_error("ign_gate_fwd: null pointer or bad dimension (B=%d N=%d)", B, N);
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, sbm, dnn, out, eta, B, N,
+                       gating_value, use_gating_value);
+    return ign_check_launch("gate_fwd_kernel");
+}
+
+extern "C" int ign_gate_bwd(const float* sbm, const float* dnn, const float* gout, const float* geta, float* gsbm,
+                            float* gdnn, int B, int N, float gating_value, int use_gating_value, void* stream) {
+    if (!sbm || !dnn || !gout || !gsbm || !gdnn || B <= 0 || N < 2) {
+        ign_set_error("ign_gate_bwd: null pointer or bad dimension (B=%d N=%d)", B, N);
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, sbm, dnn, gout, geta, gsbm,
+                       gdnn, B, N, gating_value, use_gating_value);
+    return ign_check_launch("gate_bwd_kernel");
+}
+
+extern "C" int ign_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                             float eps, int step, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step <= 0) {
+        ign_set_error("ign_adam_step: null pointer, n <= 0 or step <= 0");
+        return IGN_E_ARG;
+    }
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) {
+        ign_set_error("ign_adam_step: buffers must be 16-byte aligned");
+        return IGN_E_ARG;
+    }
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    IgnScopedTimer tm("adam", (hipStream_t)stream);
+    const long long blocks = (n / 4 + 256) / 256;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+                       eps, (float)bc1, (float)sqrt(bc2));
+    return ign_check_launch("adam_kernel");
+}

@@ -24,6 +24,11 @@ SIGNATURES = {
     "ign_shapelet_bwd_workspace_bytes": (sz, [ci, ci, ci, ci, ci, ci, ci]),
     "ign_attn_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
     "ign_attn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
+    "ign_head_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ll, vp]),
+    "ign_head_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]),
+    "ign_gate_fwd": (ci, [vp, vp, vp, vp, ci, ci, cf, ci, vp]),
+    "ign_gate_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp]),
+    "ign_adam_step": (ci, [vp, vp, vp, vp, ll, cf, cf, cf, cf, ci, vp]),
     "ign_timing_enable": (ci, [ci]),
     "ign_timing_read": (ci, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
     "ign_shapelet_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),

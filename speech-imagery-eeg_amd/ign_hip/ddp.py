@@ -63,3 +63,46 @@ def shard_indices(n, rank, world, epoch=0, seed=0, shuffle=True):
         perm = torch.arange(n)
     per = n // world
     return perm[rank * per:(rank + 1) * per]
+
+
+class FlatAdam:
+    """Adam over ONE flat parameter buffer: a single `ign_adam_step` launch per optimizer step instead of torch's
+    per-tensor (or multi-tensor) update -- torch.optim.Adam semantics (betas (0.9, 0.999), eps 1e-8, no weight decay),
+    as constructed at IGN/exp/experiment_classification.py:136.
+
+    Parameters become views into `flat_param` (same trick as the gradient bucket), so the model, its state_dict and
+    checkpoints are unaffected.  Needs the bucket (its flat gradient is the kernel's input).
+    """
+
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        from . import _lib
+        self._lib = _lib
+        self.bucket, self.lr, self.betas, self.eps = bucket, lr, betas, eps
+        self.step_count = 0
+        ps = bucket.params
+        if not ps[0].is_cuda:
+            raise _lib.IgnError("FlatAdam runs on the GPU only")
+        self.flat_param = torch.empty_like(bucket.flat_grad)
+        off = 0
+        with torch.no_grad():
+            for p in ps:
+                n = p.numel()
+                self.flat_param[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_param[off:off + n].view_as(p)
+                off += n
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        self.param_groups = [{"lr": lr}]          # so lr schedulers that poke param_groups keep working
+
+    def step(self):
+        import ctypes
+        self.step_count += 1
+        lr = self.param_groups[0]["lr"]
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+        self._lib.check(self._lib.lib().ign_adam_step(
+            ptr(self.flat_param), ptr(self.bucket.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+            self.flat_param.numel(), lr, self.betas[0], self.betas[1], self.eps, self.step_count,
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ign_adam_step")
+
+    def zero_grad(self, set_to_none=False):
+        self.bucket.zero_grad()

@@ -166,3 +166,80 @@ class AttentionFn(torch.autograd.Function):
 
 def attention(q, k, v, scale):
     return AttentionFn.apply(q, k, v, scale)
+
+
+class HeadLinearFn(torch.autograd.Function):
+    """Skinny expert-head GEMM x (B,F) @ W(N,F)^T + bias -> (B,N) on ign_head_fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        _need_gpu("head_linear", x, w, bias)
+        x = x if (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
+        w = w.contiguous()
+        B, F_ = x.shape
+        N = w.shape[0]
+        out = torch.empty(B, N, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().ign_head_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), B, F_, N, x.stride(0), _stream()),
+                   "ign_head_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        B, F_ = x.shape
+        N = w.shape[0]
+        g = g.contiguous()
+        gx = torch.empty(B, F_, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        gb = torch.empty(N, device=x.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if gb is not None and gw is None:
+            gw = torch.empty_like(w)
+        _lib.check(_lib.lib().ign_head_bwd(_ptr(g), _ptr(x), _ptr(w), _ptr(gx), _ptr(gw), _ptr(gb), B, F_, N, x.stride(0),
+                                           _stream()), "ign_head_bwd")
+        # gx was written with row pitch x.stride(0); it is dense only if x was (the common case)
+        if gx is not None and x.stride(0) != F_:
+            raise _lib.IgnError("head_linear backward: padded input rows are not supported")
+        return gx, (gw if ctx.needs_input_grad[1] else None), gb
+
+
+def head_linear(x, w, bias=None):
+    """nn.Linear with few outputs (class logits).  Shapes the streaming kernel does not cover go to torch's GEMM
+    (still on the GPU; there is no CPU path)."""
+    if x.dim() != 2 or x.shape[1] % 4 or w.shape[0] > 16 or not x.is_cuda or x.dtype != torch.float32 \
+            or w.dtype != torch.float32 or torch.is_autocast_enabled():
+        return torch.nn.functional.linear(x, w, bias)
+    return HeadLinearFn.apply(x, w, bias)
+
+
+class GiniGateFn(torch.autograd.Function):
+    """(sbm_out, dnn_out) -> (mixture, eta); IGN/model/InterpGN.py:44-52."""
+
+    @staticmethod
+    def forward(ctx, sbm, dnn, gating_value):
+        _need_gpu("gini_gate", sbm, dnn)
+        sbm, dnn = sbm.contiguous(), dnn.contiguous()
+        B, N = sbm.shape
+        out = torch.empty_like(sbm)
+        eta = torch.empty(B, 1, device=sbm.device, dtype=torch.float32)
+        use, gv = (0, 0.0) if gating_value is None else (1, float(gating_value))
+        _lib.check(_lib.lib().ign_gate_fwd(_ptr(sbm), _ptr(dnn), _ptr(out), _ptr(eta), B, N, gv, use, _stream()), "ign_gate_fwd")
+        ctx.save_for_backward(sbm, dnn)
+        ctx.gv = (use, gv)
+        return out, eta
+
+    @staticmethod
+    def backward(ctx, gout, geta):
+        sbm, dnn = ctx.saved_tensors
+        B, N = sbm.shape
+        use, gv = ctx.gv
+        gs, gd = torch.empty_like(sbm), torch.empty_like(dnn)
+        geta = geta.contiguous() if geta is not None else None
+        _lib.check(_lib.lib().ign_gate_bwd(_ptr(sbm), _ptr(dnn), _ptr(gout.contiguous()), _ptr(geta), _ptr(gs), _ptr(gd), B, N,
+                                           gv, use, _stream()), "ign_gate_bwd")
+        return gs, gd, None
+
+
+def gini_gate(sbm_out, dnn_out, gating_value=None):
+    return GiniGateFn.apply(sbm_out.float(), dnn_out.float(), gating_value)

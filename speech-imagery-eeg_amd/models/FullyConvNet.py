@@ -7,6 +7,8 @@ SURVEY K7 is the next kernel on this path.  ``x_bct`` lets InterpGN hand over th
 """
 import torch.nn as nn
 
+from ign_hip import ops
+
 
 class FullyConvNetwork(nn.Module):
     def __init__(self, configs):
@@ -21,4 +23,4 @@ class FullyConvNetwork(nn.Module):
     def forward(self, x, x_mark_enc=None, x_dec=None, x_mark_dec=None, mask=None, x_bct=None):
         h = x_bct if x_bct is not None else x.permute(0, 2, 1)
         h = self.block3(self.block2(self.block1(h)))
-        return self.fc(self.pooling(h).flatten(start_dim=1))
+        return ops.head_linear(self.pooling(h).flatten(start_dim=1), self.fc.weight, self.fc.bias)

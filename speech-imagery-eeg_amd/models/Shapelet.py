@@ -126,9 +126,12 @@ class ShapeBottleneckModel(nn.Module):
         self.lambda_div = configs.lambda_div
 
     # -- hot path ---------------------------------------------------------------------------------
-    def shapelet_features(self, x):
-        """x (B,T,C) on the GPU -> (p, d_min) of every group, concatenated in the reference's order."""
-        xn, _ = ops.instance_norm(x)
+    def shapelet_features(self, x, xn=None):
+        """x (B,T,C) on the GPU -> (p, d_min) of every group, concatenated in the reference's order.
+        `xn`: the instance-normalised (B,C,T) tensor if the caller already ran ign_instnorm_fwd (InterpGN does, to
+        share the transpose with the FCN expert)."""
+        if xn is None:
+            xn, _ = ops.instance_norm(x)
         first = self.shapelets[0]
         thr = [s.threshold for s in self.shapelets] if first.gate == ops.GATE_LTS else None
         return ops.shapelet_bank(xn, [s.weights for s in self.shapelets], first.eps, first.mode(),
@@ -137,13 +140,13 @@ class ShapeBottleneckModel(nn.Module):
     def head(self, p):
         cls = self.configs.sbm_cls
         if cls == 'linear':
-            return self.output_layer(self.dropout(p))
+            return ops.head_linear(self.dropout(p), self.output_layer.weight)
         if cls == 'bilinear':
             return self.output_layer(self.dropout(p)) + self.output_bilinear(self.dropout(p), self.dropout(p))
         return self.output_layer(self.dropout(self.attention(p)))
 
-    def forward(self, x, *args, **kwargs):
-        p, d = self.shapelet_features(x)
+    def forward(self, x, *args, xn=None, **kwargs):
+        p, d = self.shapelet_features(x, xn)
         out = self.head(p)
         return out, ModelInfo(d=d, p=p, shapelet_preds=out, preds=out, loss=self.loss().unsqueeze(0))
 

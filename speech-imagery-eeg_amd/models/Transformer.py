@@ -3,6 +3,8 @@ embed -> e_layers x (MHA + FFN, post-norm) -> LayerNorm -> gelu -> x mask -> fla
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ign_hip import ops
+
 from layers.Embed import DataEmbedding
 from layers.SelfAttention_Family import AttentionLayer, FullAttention
 from layers.Transformer_EncDec import Encoder, EncoderLayer
@@ -34,7 +36,7 @@ class Model(nn.Module):
         enc_out, _ = self.encoder(enc_out, attn_mask=None)
         out = self.dropout(self.act(enc_out))
         out = out * x_mark_enc.unsqueeze(-1)            # zero the padded steps
-        return self.projection(out.reshape(out.shape[0], -1))
+        return ops.head_linear(out.reshape(out.shape[0], -1), self.projection.weight, self.projection.bias)
 
     def forward(self, x_enc, x_mark_enc, x_dec=None, x_mark_dec=None, mask=None):
         return self.classification(x_enc, x_mark_enc)

@@ -162,3 +162,52 @@ def test_three_adam_steps(tag, posw):
         bad = diff > (5e-4 + 5e-3 * np.abs(b))
         assert bad.mean() <= 0.05, f"{k}: {bad.mean():.3%} of entries outside tolerance"
         assert diff.max() <= 3 * 2 * 5e-3 + 1e-6, f"{k}: max diff {diff.max():.3e}"
+
+
+def test_head_linear_gate_and_flat_adam_vs_torch():
+    """The small HIP pieces of the step against torch's own ops on the same device (fp32, 1e-5)."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    from ign_hip.ddp import FlatAdam, FlatParamBucket
+    from models.InterpGN import gini_gate
+    torch.manual_seed(0)
+    for (B, Fdim, N, bias) in [(256, 2440, 3, False), (8, 120, 4, True), (5, 51200, 3, True), (7, 16, 16, True)]:
+        x = torch.randn(B, Fdim, device=dev, requires_grad=True)
+        w = torch.randn(N, Fdim, device=dev, requires_grad=True)
+        b = torch.randn(N, device=dev, requires_grad=True) if bias else None
+        g = torch.randn(B, N, device=dev)
+        o1 = ops.head_linear(x, w, b)
+        gr1 = torch.autograd.grad(o1, [x, w] + ([b] if bias else []), g)
+        o2 = F.linear(x.double(), w.double(), b.double() if bias else None)
+        gr2 = torch.autograd.grad(o2, [x, w] + ([b] if bias else []), g.double())
+        assert float((o1 - o2).abs().max() / o2.abs().max()) < 1e-5
+        for a, c in zip(gr1, gr2):
+            assert float((a - c).abs().max() / c.abs().max()) < 1e-5
+    for gv in (None, 0.3):
+        s = (torch.randn(64, 5, device=dev) * 2).requires_grad_(True)
+        d = torch.randn(64, 5, device=dev, requires_grad=True)
+        go, ge = torch.randn(64, 5, device=dev), torch.randn(64, 1, device=dev)
+        o1, e1 = ops.gini_gate(s, d, gv)
+        o2, e2 = gini_gate(s.double(), d.double(), gv)
+        g1 = torch.autograd.grad((o1 * go).sum() + (e1 * ge).sum(), [s, d])
+        g2 = torch.autograd.grad((o2 * go.double()).sum() + (e2 * ge.double()).sum(), [s, d])
+        assert float((o1 - o2).abs().max()) < 1e-5 and float((e1 - e2).abs().max()) < 1e-5
+        for a, c in zip(g1, g2):
+            assert float((a - c).abs().max()) < 2e-5
+    # Adam: 5 steps on a small MLP, flat kernel vs torch.optim.Adam
+    torch.manual_seed(1)
+    net1 = torch.nn.Sequential(torch.nn.Linear(10, 33), torch.nn.Tanh(), torch.nn.Linear(33, 3)).to(dev)
+    net2 = torch.nn.Sequential(torch.nn.Linear(10, 33), torch.nn.Tanh(), torch.nn.Linear(33, 3)).to(dev)
+    net2.load_state_dict(net1.state_dict())
+    bucket = FlatParamBucket(net1, 1)
+    opt1, opt2 = FlatAdam(bucket, lr=5e-3), torch.optim.Adam(net2.parameters(), lr=5e-3)
+    xs = torch.randn(5, 16, 10, device=dev)
+    for i in range(5):
+        net1(xs[i]).square().mean().backward()
+        opt1.step(); opt1.zero_grad()
+        net2(xs[i]).square().mean().backward()
+        opt2.step(); opt2.zero_grad()
+    for (n, p), q in zip(net1.named_parameters(), net2.parameters()):
+        assert float((p - q).abs().max()) < 1e-5, n
+    assert all(k in net1.state_dict() for k in net2.state_dict())
