@@ -6,7 +6,11 @@
 // where A = -(dl/dd_t)/L and dl/dd_t follows from the saved distances d_t, the row statistics
 // {t*, Z, mu} and the upstream gradient of the gate output.
 //
-// Mapping (fp32 VALU bound, 3 ops per (b,c,k,t,j) element for L1: v_cmp, v_cndmask, v_add):
+// Mapping (fp32 VALU bound).  L1 inner step per (b,c,k,t,j) element: `v_cmpx_gt_f32 x, w` (EXEC <- x > w),
+// `v_add_f32 acc, acc, A` under that mask, `s_mov_b64 exec, -1` -- 2 VALU + 1 SALU instead of the compiler's
+// v_cmp / s_nop / v_cndmask / v_add (3 VALU + a hazard nop); measured 24 vs 19-20 T elements/s
+// (profiles/r1_valu_microbench.txt).  It accumulates P_j = sum_{t: x>w} A_t; with S = sum_t A_t the signed sum is
+// sum_t A_t sign(x-w) = 2 P_j - S.
 //   * a block owns one channel c (and a tile of `kb` shapelets) and walks a slice of the batch;
 //   * lane <-> (k, chunk of JJ consecutive j): its JJ accumulators and JJ weights stay in registers for
 //     the whole batch slice, so there is NO cross-lane reduction -- only a fixed-order reduction over
@@ -29,16 +33,18 @@ __global__ void __launch_bounds__(512) shp_bwd_kernel(const ShpBwdArgs a) {
     const int kbase = blockIdx.z * a.kb;
     const int kcount = min(a.kb, a.K - kbase);
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int kl = tid / a.cpk;
+    int kl = tid / a.cpk;
     const int jc = tid - kl * a.cpk;
     const bool active = kl < kcount;
+    if (!active) kl = kcount - 1;            // padding lanes shadow a valid shapelet: EXEC stays full in the hot loop
     const int jbase = jc * JJ;
 
     float wreg[JJ], acc[JJ];
+    float ssum = 0.f;                         // S = sum_t A_t of this lane's shapelet (L1 path)
 #pragma unroll
     for (int jj = 0; jj < JJ; ++jj) {
         const int j = jbase + jj;
-        wreg[jj] = (active && j < a.L) ? a.w[((size_t)(kbase + kl) * a.C + c) * a.L + j] : INFINITY;
+        wreg[jj] = (j < a.L) ? a.w[((size_t)(kbase + kl) * a.C + c) * a.L + j] : INFINITY;
         acc[jj] = 0.f;
     }
 
@@ -90,7 +96,7 @@ __global__ void __launch_bounds__(512) shp_bwd_kernel(const ShpBwdArgs a) {
         }
         __syncthreads();
 
-        if (active) {
+        {
             const float* Ak = As + kl * a.twpad;
             const float* xl = xs + jbase;
             float W[JJ + TT];
@@ -111,11 +117,23 @@ __global__ void __launch_bounds__(512) shp_bwd_kernel(const ShpBwdArgs a) {
 #pragma unroll
                 for (int t = 0; t < TT; ++t) {
                     const float av = A[t];
-                    const float nav = -av;
+                    if (DIST == DIST_L1) {
+                        ssum += av;
+                        // one statement per 4 elements: hipcc pads every asm boundary with an s_nop
 #pragma unroll
-                    for (int jj = 0; jj < JJ; ++jj) {
-                        if (DIST == DIST_L1) acc[jj] += (W[t + jj] > wreg[jj]) ? av : nav;
-                        else                 acc[jj] = fmaf(av, W[t + jj] - wreg[jj], acc[jj]);
+                        for (int jj = 0; jj < JJ; jj += 4)
+                            asm volatile(
+                                "v_cmpx_gt_f32 %4, %8\n\tv_add_f32 %0, %0, %12\n\ts_mov_b64 exec, -1\n\t"
+                                "v_cmpx_gt_f32 %5, %9\n\tv_add_f32 %1, %1, %12\n\ts_mov_b64 exec, -1\n\t"
+                                "v_cmpx_gt_f32 %6, %10\n\tv_add_f32 %2, %2, %12\n\ts_mov_b64 exec, -1\n\t"
+                                "v_cmpx_gt_f32 %7, %11\n\tv_add_f32 %3, %3, %12\n\ts_mov_b64 exec, -1"
+                                : "+v"(acc[jj]), "+v"(acc[jj + 1]), "+v"(acc[jj + 2]), "+v"(acc[jj + 3])
+                                : "v"(W[t + jj]), "v"(W[t + jj + 1]), "v"(W[t + jj + 2]), "v"(W[t + jj + 3]),
+                                  "v"(wreg[jj]), "v"(wreg[jj + 1]), "v"(wreg[jj + 2]), "v"(wreg[jj + 3]), "v"(av)
+                                : "vcc");
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < JJ; ++jj) acc[jj] = fmaf(av, W[t + jj] - wreg[jj], acc[jj]);
                     }
                 }
 #pragma unroll
@@ -128,7 +146,7 @@ __global__ void __launch_bounds__(512) shp_bwd_kernel(const ShpBwdArgs a) {
         float* out = a.part + (((size_t)bs * a.K + (kbase + kl)) * a.C + c) * a.L;
 #pragma unroll
         for (int jj = 0; jj < JJ; ++jj)
-            if (jbase + jj < a.L) out[jbase + jj] = acc[jj];
+            if (jbase + jj < a.L) out[jbase + jj] = (DIST == DIST_L1) ? 2.f * acc[jj] - ssum : acc[jj];
     }
 }
 
