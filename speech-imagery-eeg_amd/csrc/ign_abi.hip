@@ -180,12 +180,13 @@ extern "C" int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const f
 
 // ------------------------------------------------------------------------------------------ backward
 struct BwdPlan {
-    int JJ, cpk, kb, nkt, threads, twpad, xs_len, nbs;
+    int JJ, cpk, kb, nkt, threads, tc, xs_len, nbs;
     size_t lds;
 };
 
 static int plan_bwd(int B, int C, int T, int K, int L, int Tw, BwdPlan* p) {
-    // JJ: j's per lane.  Prefer 8 (A operand amortised over more work) unless 4 fills the waves better.
+    // JJ: shapelet positions per lane.  8 amortises the A / x operand reads over more work; 4 fills the waves better
+    // for short shapelets (K*ceil(L/JJ) lanes are rounded up to whole waves).
     int best = 0;
     double best_eff = -1.0;
     const int cand[2] = {8, 4};
@@ -196,24 +197,40 @@ static int plan_bwd(int B, int C, int T, int K, int L, int Tw, BwdPlan* p) {
         const int kb = std::max(1, std::min(K, 512 / cpk));
         const int threads = ((kb * cpk + 63) / 64) * 64;
         double eff = (double)kb * L / ((double)threads * JJ);
-        if (JJ == 8) eff *= 1.10;            // (3*JJ+overhead)/3*JJ: per-t overhead is amortised over JJ
+        if (JJ == 8) eff *= 1.10;
         if (eff > best_eff) { best_eff = eff; best = JJ; }
     }
     if (!best) return IGN_E_TOOBIG;
-    p->JJ = best;
-    p->cpk = (L + best - 1) / best;
-    p->kb = std::max(1, std::min(K, 512 / p->cpk));
+    const int JJ = best;
+    p->JJ = JJ;
+    p->cpk = (L + JJ - 1) / JJ;
+    // shapelets per block: the tile that wastes the fewest lanes when kb*cpk is rounded up to whole waves; on ties the
+    // SMALLER block (measured: 1-wave blocks at L=500 beat 5-wave blocks, 17 -> 24 T elements/s -- less barrier skew).
+    {
+        int best_kb = 1;
+        double best_u = -1.0;
+        for (int kb = 1; kb <= K && kb * p->cpk <= 512; ++kb) {
+            const int thr = ((kb * p->cpk + 63) / 64) * 64;
+            const int ntile = (K + kb - 1) / kb;
+            const double u = (double)K * p->cpk / ((double)ntile * thr);      // useful lanes over all tiles of this size
+            if (u > best_u + 1e-9) { best_u = u; best_kb = kb; }
+        }
+        p->kb = best_kb;
+    }
     p->nkt = (K + p->kb - 1) / p->kb;
     p->threads = ((p->kb * p->cpk + 63) / 64) * 64;
-    p->twpad = ((Tw + IGN_BWD_TT - 1) / IGN_BWD_TT) * IGN_BWD_TT;
-    p->xs_len = (p->cpk * best + p->twpad + 3) & ~3;
-    p->lds = ((size_t)p->xs_len + (size_t)p->kb * p->twpad) * 4;
-    while (p->lds > 64 * 1024 && p->kb > 1) {       // shrink the shapelet tile until LDS fits
-        p->kb = (p->kb + 1) / 2;
-        p->nkt = (K + p->kb - 1) / p->kb;
-        p->threads = ((p->kb * p->cpk + 63) / 64) * 64;
-        p->lds = ((size_t)p->xs_len + (size_t)p->kb * p->twpad) * 4;
-    }
+    // LDS budget ~5 KB per wave keeps 7-8 waves per SIMD resident (the v_cmpx loop is latency-bound per wave):
+    // stage the window axis in chunks of tc positions, equalised over ceil(Tw / tc_max) chunks.
+    const size_t budget = std::max<size_t>(8 * 1024, (size_t)(p->threads / 64) * 5 * 1024);
+    const long fixed = (long)p->cpk * JJ + 8 * p->kb + 8;                      // floats besides the tc-proportional part
+    long tc_max = ((long)(budget / 4) - fixed) / (1 + p->kb);
+    tc_max = std::max<long>(2 * JJ, (tc_max / (2 * JJ)) * (2 * JJ));
+    const int nchunk = (int)((Tw + tc_max - 1) / tc_max);
+    int tc = (Tw + nchunk - 1) / nchunk;
+    tc = ((tc + 2 * JJ - 1) / (2 * JJ)) * (2 * JJ);
+    p->tc = tc;
+    p->xs_len = (p->cpk * JJ + tc + 3) & ~3;
+    p->lds = ((size_t)p->xs_len + (size_t)p->kb * tc + 8 * (size_t)p->kb) * 4;
     if (p->lds > 64 * 1024) return IGN_E_TOOBIG;
     // batch slices: a few rows per block.  Many small blocks (thousands) keep the last scheduling round of the
     // 256 CUs short -- with ~2000 blocks of 2-5 waves a third of the launch was tail (profiles/r1a) -- while 4 rows
@@ -268,7 +285,7 @@ extern "C" int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const f
     a.xn = xn_bct; a.w = w_kcl; a.g = g_out; a.p = p_out; a.dmin = dmin_out; a.tstar = tstar; a.zmu = zmu; a.d = d_save;
     a.part = (float*)workspace;
     a.B = B; a.C = C; a.T = T; a.K = K; a.L = L; a.Tw = Tw; a.ld = ld; a.col0 = col0;
-    a.nbs = p.nbs; a.kb = p.kb; a.cpk = p.cpk; a.twpad = p.twpad; a.xs_len = p.xs_len; a.gate = gate;
+    a.nbs = p.nbs; a.kb = p.kb; a.cpk = p.cpk; a.tc = p.tc; a.xs_len = p.xs_len; a.gate = gate;
     a.eps = eps; a.invL = 1.0f / (float)L;
     {
         IgnScopedTimer tm("shp_bwd", (hipStream_t)stream);

@@ -58,13 +58,12 @@ struct ShpBwdArgs {
     int nbs;              // batch slices (gridDim.y)
     int kb;               // shapelets per block (gridDim.z tiles)
     int cpk;              // j-chunks per shapelet = ceil(L/JJ)
-    int twpad;            // Tw rounded up to TT
-    int xs_len;           // floats of x staging (multiple of 4)
+    int tc;               // window positions staged per LDS chunk (multiple of 2*JJ)
+    int xs_len;           // floats of x staging per chunk = cpk*JJ + tc (multiple of 4)
     int gate;
     float eps, invL;
 };
 typedef void (*shp_bwd_launch_t)(const ShpBwdArgs&, dim3 grid, dim3 block, size_t lds, hipStream_t);
 shp_bwd_launch_t ign_get_bwd_launcher(int dist, int JJ);            // JJ in {4,8}
-constexpr int IGN_BWD_TT = 16;
 
 void ign_launch_reduce_parts(const float* part, float* out, int nparts, size_t n, hipStream_t s);

@@ -15,24 +15,76 @@
 //   * lane <-> (k, chunk of JJ consecutive j): its JJ accumulators and JJ weights stay in registers for
 //     the whole batch slice, so there is NO cross-lane reduction -- only a fixed-order reduction over
 //     batch slices afterwards (deterministic, no float atomics);
-//   * per batch row the block stages x[b,c,:] and A[k,:] (computed cooperatively from d, once per
-//     (b,k,c,t)) in LDS; each lane then slides over t in steps of TT with a register window of
-//     x[jbase+t .. jbase+t+TT+JJ), reading A[k][t..t+TT) as an LDS broadcast.
+//   * per batch row and per chunk of `tc` window positions the block stages x[b,c,t0:t0+tc+L) and
+//     A[k,t0:t0+tc) (computed cooperatively from d, once per (b,k,c,t), with its per-shapelet sum S) in LDS; each
+//     lane then slides over the chunk in steps of JJ with a ping-pong register window of 2*JJ samples (no register
+//     moves), reading A[k][t..t+JJ) as an LDS broadcast;
+//   * the v_cmpx sequence is latency-bound per wave (EXEC round trip), so the kernel is built for occupancy:
+//     <= 72 VGPRs and an LDS budget of ~5 KB per wave (the t-chunking) give 7-8 waves per SIMD.  Blocks are kept as
+//     small as lane utilisation allows (one wave per shapelet at L=500: 17 -> 24 T elements/s vs a 5-wave block).
+//     Measured alternatives (tests/diag_shapelet.py, ms per step at the benchmark shape): 16-step unchunked 6.9;
+//     chunked multi-wave 6.3; + small blocks 5.66 (this); one-wave blocks straddling shapelets 6.2 (A staged twice).
 #pragma once
 #include "ign_common.h"
 
+template <int JJ>
+__device__ __forceinline__ void bwd_l1_step(float (&acc)[JJ], const float (&wa)[JJ], const float (&wb)[JJ],
+                                            const float (&wreg)[JJ], const float (&A)[JJ]) {
+    // window sample for (t, jj) is wa[t + jj] when t + jj < JJ, else wb[t + jj - JJ]
+#pragma unroll
+    for (int t = 0; t < JJ; ++t) {
+#pragma unroll
+        for (int jj = 0; jj < JJ; jj += 4) {
+#define IGN_WIN(q) ((t + jj + (q)) < JJ ? wa[(t + jj + (q)) % JJ] : wb[(t + jj + (q)) % JJ])
+            // one asm statement per 4 elements: hipcc pads every asm boundary with an s_nop
+            asm volatile(
+                "v_cmpx_gt_f32 %4, %8\n\tv_add_f32 %0, %0, %12\n\ts_mov_b64 exec, -1\n\t"
+                "v_cmpx_gt_f32 %5, %9\n\tv_add_f32 %1, %1, %12\n\ts_mov_b64 exec, -1\n\t"
+                "v_cmpx_gt_f32 %6, %10\n\tv_add_f32 %2, %2, %12\n\ts_mov_b64 exec, -1\n\t"
+                "v_cmpx_gt_f32 %7, %11\n\tv_add_f32 %3, %3, %12\n\ts_mov_b64 exec, -1"
+                : "+v"(acc[jj]), "+v"(acc[jj + 1]), "+v"(acc[jj + 2]), "+v"(acc[jj + 3])
+                : "v"(IGN_WIN(0)), "v"(IGN_WIN(1)), "v"(IGN_WIN(2)), "v"(IGN_WIN(3)),
+                  "v"(wreg[jj]), "v"(wreg[jj + 1]), "v"(wreg[jj + 2]), "v"(wreg[jj + 3]), "v"(A[t])
+                : "vcc");
+#undef IGN_WIN
+        }
+    }
+}
+
+template <int JJ>
+__device__ __forceinline__ void bwd_mse_step(float (&acc)[JJ], const float (&wa)[JJ], const float (&wb)[JJ],
+                                             const float (&wreg)[JJ], const float (&A)[JJ]) {
+#pragma unroll
+    for (int t = 0; t < JJ; ++t)
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) {
+            const float xv = (t + jj) < JJ ? wa[(t + jj) % JJ] : wb[(t + jj) % JJ];
+            acc[jj] = fmaf(A[t], xv - wreg[jj], acc[jj]);
+        }
+}
+
+template <int JJ>
+__device__ __forceinline__ void lds_load(float (&dst)[JJ], const float* p) {
+#pragma unroll
+    for (int i = 0; i < JJ; i += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p + i);
+        dst[i] = v.x; dst[i + 1] = v.y; dst[i + 2] = v.z; dst[i + 3] = v.w;
+    }
+}
+
 template <int JJ, int DIST>
-__global__ void __launch_bounds__(512) shp_bwd_kernel(const ShpBwdArgs a) {
-    constexpr int TT = IGN_BWD_TT;
-    static_assert(JJ % 4 == 0 && TT % 4 == 0, "float4 LDS reads need 4-float alignment");
+__global__ void __launch_bounds__(512, 2) shp_bwd_kernel(const ShpBwdArgs a) {
+    static_assert(JJ % 4 == 0, "float4 LDS reads need 4-float alignment");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;                       // [xs_len]
-    float* As = smem + a.xs_len;            // [kb][twpad]
+    float* xs = smem;                        // [xs_len]      x[b,c,t0 + i]
+    float* As = smem + a.xs_len;             // [kb][tc]      A[k][t0 + t]
+    float* Sp = As + a.kb * a.tc;            // [kb][8]       per-wave partial sums of A (fixed order -> deterministic)
 
     const int c = blockIdx.x, bs = blockIdx.y;
     const int kbase = blockIdx.z * a.kb;
     const int kcount = min(a.kb, a.K - kbase);
     const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
     int kl = tid / a.cpk;
     const int jc = tid - kl * a.cpk;
     const bool active = kl < kcount;
@@ -40,7 +92,7 @@ __global__ void __launch_bounds__(512) shp_bwd_kernel(const ShpBwdArgs a) {
     const int jbase = jc * JJ;
 
     float wreg[JJ], acc[JJ];
-    float ssum = 0.f;                         // S = sum_t A_t of this lane's shapelet (L1 path)
+    float ssum = 0.f;                        // S = sum_t A_t of this lane's shapelet over the batch slice (L1)
 #pragma unroll
     for (int jj = 0; jj < JJ; ++jj) {
         const int j = jbase + jj;
@@ -53,91 +105,71 @@ __global__ void __launch_bounds__(512) shp_bwd_kernel(const ShpBwdArgs a) {
     const float two_eps2 = 2.f * a.eps * a.eps;
 
     for (int b = b_begin; b < b_end; ++b) {
-        __syncthreads();                    // previous row fully consumed
-        {
-            const float* row = a.xn + ((size_t)b * a.C + c) * a.T;
-            for (int i = tid; i < a.xs_len; i += nthr) xs[i] = (i < a.T) ? row[i] : 0.f;
-        }
-        for (int k2 = 0; k2 < kcount; ++k2) {
-            const int k = kbase + k2;
-            const size_t sidx = ((size_t)b * a.K + k) * a.C + c;
-            const size_t col = (size_t)b * a.ld + a.col0 + (size_t)k * a.C + c;
-            const float gv = a.g[col];
-            const int ts = a.tstar[sidx];
-            const float invZ = 1.f / a.zmu[2 * sidx];
-            const float mu = a.zmu[2 * sidx + 1];
-            float gm = 0.f, dmin = 0.f;
-            if (a.gate == GATE_LTS) {
-                const float P = a.p[col];
-                gm = -gv * P * (1.f - P);       // dP/dm = -sigma'(thr - m)
-                dmin = a.dmin[col];
-            }
-            const float* drow = a.d + (((size_t)b * a.C + c) * a.K + k) * a.Tw;
-            float* Ak = As + k2 * a.twpad;
-            for (int t = tid; t < a.twpad; t += nthr) {
-                float A = 0.f;
-                if (t < a.Tw) {
-                    const float dv = drow[t];
-                    float dldd;
-                    if (a.gate == GATE_RBF) {
-                        const float u = a.eps * dv;
-                        const float p = __expf(-(u * u));
-                        const float e = __expf(p);
-                        const float coef = gv * ((t == ts ? 1.f : 0.f) + e * invZ * (p - mu));
-                        dldd = coef * (-two_eps2 * dv * p);
-                    } else {
-                        const float s = __expf(dmin - dv) * invZ;
-                        dldd = gm * ((t == ts ? 1.f : 0.f) + s * (mu - dv));
-                    }
-                    A = (DIST == DIST_L1) ? -dldd * a.invL : -2.f * dldd * a.invL;
+        const float* row = a.xn + ((size_t)b * a.C + c) * a.T;
+        for (int t0 = 0; t0 < a.Tw; t0 += a.tc) {
+            __syncthreads();                 // previous chunk fully consumed
+            for (int i = tid; i < a.xs_len; i += nthr) xs[i] = (t0 + i < a.T) ? row[t0 + i] : 0.f;
+            for (int k2 = 0; k2 < kcount; ++k2) {
+                const int k = kbase + k2;
+                const size_t sidx = ((size_t)b * a.K + k) * a.C + c;
+                const size_t col = (size_t)b * a.ld + a.col0 + (size_t)k * a.C + c;
+                const float gv = a.g[col];
+                const int ts = a.tstar[sidx];
+                const float invZ = 1.f / a.zmu[2 * sidx];
+                const float mu = a.zmu[2 * sidx + 1];
+                float gm = 0.f, dmin = 0.f;
+                if (a.gate == GATE_LTS) {
+                    const float P = a.p[col];
+                    gm = -gv * P * (1.f - P);       // dP/dm = -sigma'(thr - m)
+                    dmin = a.dmin[col];
                 }
-                Ak[t] = A;
+                const float* drow = a.d + (((size_t)b * a.C + c) * a.K + k) * a.Tw;
+                float* Ak = As + k2 * a.tc;
+                float part = 0.f;
+                for (int tt = tid; tt < a.tc; tt += nthr) {
+                    const int t = t0 + tt;
+                    float A = 0.f;
+                    if (t < a.Tw) {
+                        const float dv = drow[t];
+                        float dldd;
+                        if (a.gate == GATE_RBF) {
+                            const float u = a.eps * dv;
+                            const float p = __expf(-(u * u));
+                            const float e = __expf(p);
+                            const float coef = gv * ((t == ts ? 1.f : 0.f) + e * invZ * (p - mu));
+                            dldd = coef * (-two_eps2 * dv * p);
+                        } else {
+                            const float s = __expf(dmin - dv) * invZ;
+                            dldd = gm * ((t == ts ? 1.f : 0.f) + s * (mu - dv));
+                        }
+                        A = (DIST == DIST_L1) ? -dldd * a.invL : -2.f * dldd * a.invL;
+                    }
+                    Ak[tt] = A;
+                    part += A;
+                }
+                if (DIST == DIST_L1) {
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                    if (lane == 0) Sp[k2 * 8 + wave] = part;
+                }
             }
-        }
-        __syncthreads();
+            __syncthreads();
 
-        {
-            const float* Ak = As + kl * a.twpad;
+            if (DIST == DIST_L1)
+                for (int wv = 0; wv < nwave; ++wv) ssum += Sp[kl * 8 + wv];
+            const float* Ak = As + kl * a.tc;
             const float* xl = xs + jbase;
-            float W[JJ + TT];
-#pragma unroll
-            for (int i = 0; i < JJ; i += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(xl + i);
-                W[i] = v.x; W[i + 1] = v.y; W[i + 2] = v.z; W[i + 3] = v.w;
-            }
-            for (int t0 = 0; t0 < a.twpad; t0 += TT) {
-                float A[TT];
-#pragma unroll
-                for (int i = 0; i < TT; i += 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(xl + t0 + JJ + i);
-                    W[JJ + i] = v.x; W[JJ + i + 1] = v.y; W[JJ + i + 2] = v.z; W[JJ + i + 3] = v.w;
-                    const float4 q = *reinterpret_cast<const float4*>(Ak + t0 + i);
-                    A[i] = q.x; A[i + 1] = q.y; A[i + 2] = q.z; A[i + 3] = q.w;
-                }
-#pragma unroll
-                for (int t = 0; t < TT; ++t) {
-                    const float av = A[t];
-                    if (DIST == DIST_L1) {
-                        ssum += av;
-                        // one statement per 4 elements: hipcc pads every asm boundary with an s_nop
-#pragma unroll
-                        for (int jj = 0; jj < JJ; jj += 4)
-                            asm volatile(
-                                "v_cmpx_gt_f32 %4, %8\n\tv_add_f32 %0, %0, %12\n\ts_mov_b64 exec, -1\n\t"
-                                "v_cmpx_gt_f32 %5, %9\n\tv_add_f32 %1, %1, %12\n\ts_mov_b64 exec, -1\n\t"
-                                "v_cmpx_gt_f32 %6, %10\n\tv_add_f32 %2, %2, %12\n\ts_mov_b64 exec, -1\n\t"
-                                "v_cmpx_gt_f32 %7, %11\n\tv_add_f32 %3, %3, %12\n\ts_mov_b64 exec, -1"
-                                : "+v"(acc[jj]), "+v"(acc[jj + 1]), "+v"(acc[jj + 2]), "+v"(acc[jj + 3])
-                                : "v"(W[t + jj]), "v"(W[t + jj + 1]), "v"(W[t + jj + 2]), "v"(W[t + jj + 3]),
-                                  "v"(wreg[jj]), "v"(wreg[jj + 1]), "v"(wreg[jj + 2]), "v"(wreg[jj + 3]), "v"(av)
-                                : "vcc");
-                    } else {
-#pragma unroll
-                        for (int jj = 0; jj < JJ; ++jj) acc[jj] = fmaf(av, W[t + jj] - wreg[jj], acc[jj]);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < JJ; ++i) W[i] = W[i + TT];
+            float Wa[JJ], Wb[JJ], A[JJ];
+            lds_load<JJ>(Wa, xl);
+            for (int t = 0; t < a.tc; t += 2 * JJ) {         // tc is a multiple of 2*JJ: two ping-pong steps
+                lds_load<JJ>(Wb, xl + t + JJ);
+                lds_load<JJ>(A, Ak + t);
+                if (DIST == DIST_L1) bwd_l1_step<JJ>(acc, Wa, Wb, wreg, A);
+                else                 bwd_mse_step<JJ>(acc, Wa, Wb, wreg, A);
+                lds_load<JJ>(Wa, xl + t + 2 * JJ);
+                lds_load<JJ>(A, Ak + t + JJ);
+                if (DIST == DIST_L1) bwd_l1_step<JJ>(acc, Wb, Wa, wreg, A);
+                else                 bwd_mse_step<JJ>(acc, Wb, Wa, wreg, A);
             }
         }
     }
