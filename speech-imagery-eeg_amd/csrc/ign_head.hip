@@ -78,11 +78,16 @@ __global__ void __launch_bounds__(256) head_bwd_x_kernel(const float* __restrict
     }
 }
 
-// gW[n,f] = sum_b g[b,n] X[b,f]   (b ascending: deterministic);  gbias[n] = sum_b g[b,n]
+// gW[n,f] = sum_b g[b,n] X[b,f];  gbias[n] = sum_b g[b,n].
+// Block = 32 consecutive f x 8 batch groups: each thread sums its group's rows in ascending order, the 8 partials are
+// combined in fixed order through LDS (deterministic).  32 f per block keeps F/32 blocks in flight (F=2440: 77 blocks;
+// a 256-f-per-block version ran 10 blocks and took 125 us of a 17.9 ms step).
 __global__ void __launch_bounds__(256) head_bwd_w_kernel(const float* __restrict__ g, const float* __restrict__ X,
                                                          float* __restrict__ gW, float* __restrict__ gbias, int B, int F,
                                                          int N, long long ldx) {
-    extern __shared__ float gs[];               // [B*N]
+    extern __shared__ float sm[];               // g copy [B*N], then partials [8][HEAD_NMAX][32]
+    float* gs = sm;
+    float* part = sm + B * N;
     for (int i = threadIdx.x; i < B * N; i += 256) gs[i] = g[i];
     __syncthreads();
     if (gbias && blockIdx.x == 0 && threadIdx.x < N) {
@@ -90,20 +95,33 @@ __global__ void __launch_bounds__(256) head_bwd_w_kernel(const float* __restrict
         for (int b = 0; b < B; ++b) s += gs[b * N + threadIdx.x];
         gbias[threadIdx.x] = s;
     }
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= F) return;
+    const int fl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int f = blockIdx.x * 32 + fl;
+    const int per = (B + 7) / 8;
+    const int b0 = grp * per, b1 = min(B, b0 + per);
     float acc[HEAD_NMAX];
 #pragma unroll
     for (int n = 0; n < HEAD_NMAX; ++n) acc[n] = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float xv = X[(long long)b * ldx + f];
+    if (f < F)
+        for (int b = b0; b < b1; ++b) {
+            const float xv = X[(long long)b * ldx + f];
 #pragma unroll
-        for (int n = 0; n < HEAD_NMAX; ++n)
-            if (n < N) acc[n] = fmaf(gs[b * N + n], xv, acc[n]);
-    }
+            for (int n = 0; n < HEAD_NMAX; ++n)
+                if (n < N) acc[n] = fmaf(gs[b * N + n], xv, acc[n]);
+        }
 #pragma unroll
     for (int n = 0; n < HEAD_NMAX; ++n)
-        if (n < N) gW[(long long)n * F + f] = acc[n];
+        if (n < N) part[(grp * HEAD_NMAX + n) * 32 + fl] = acc[n];
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * 32; i += 256) {
+        const int n = i >> 5, ff = i & 31;
+        if (blockIdx.x * 32 + ff < F) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += part[(q * HEAD_NMAX + n) * 32 + ff];
+            gW[(long long)n * F + blockIdx.x * 32 + ff] = s;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ gini gate
@@ -215,7 +233,7 @@ extern "C" int ign_head_bwd(const float* g, const float* X, const float* W, floa
         ign_set_error("ign_head_bwd: W/gX must be 16-byte aligned with F and ldx multiples of 4");
         return IGN_E_ARG;
     }
-    if ((size_t)B * N * 4 > 64 * 1024) { ign_set_error("ign_head_bwd: B*N=%d too large for the LDS copy of g", B * N); return IGN_E_TOOBIG; }
+    if ((size_t)B * N * 4 > 40 * 1024) { ign_set_error("ign_head_bwd: B*N=%d too large for the LDS copy of g", B * N); return IGN_E_TOOBIG; }
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (gX) {
@@ -225,7 +243,7 @@ extern "C" int ign_head_bwd(const float* g, const float* X, const float* W, floa
     }
     if (gW) {
         IgnScopedTimer tm("head_bwd_w", s);
-        hipLaunchKernelGGL(head_bwd_w_kernel, dim3((F + 255) / 256), dim3(256), (size_t)B * N * 4, s, g, X, gW, gbias, B, F, N, ldx);
+        hipLaunchKernelGGL(head_bwd_w_kernel, dim3((F + 31) / 32), dim3(256), ((size_t)B * N + 8 * HEAD_NMAX * 32) * 4, s, g, X, gW, gbias, B, F, N, ldx);
         if ((rc = ign_check_launch("head_bwd_w_kernel"))) return rc;
     }
     return 0;

@@ -1,11 +1,17 @@
 """FCN deep expert (IGN/model/FullyConvNet.py:7-59): 3 x (Conv1d + BatchNorm1d + ReLU) -> GAP -> Linear.
 
 State-dict keys match the reference (``block{1,2,3}.{0,1}.*``, ``fc.*``).  Interim status: the
-convolutions run through torch's ROCm backend (MIOpen); the hand-written implicit-GEMM MFMA kernel of
-SURVEY K7 is the next kernel on this path.  ``x_bct`` lets InterpGN hand over the (B,C,T) transpose that
-``ign_instnorm_fwd`` already produced instead of permuting again.
+convolutions run through torch's ROCm backend (MIOpen implicit-GEMM fp32-MFMA kernels, ~100-120 TFLOP/s measured); the
+hand-written implicit-GEMM kernel of SURVEY K7 is the next kernel on this path.
+
+Layout: the loader hands over x as (B, T, C), which IS the channels-last image (B, C, 1, T) -- so the whole expert runs
+as 2-D convolutions over that zero-copy view in NHWC, the layout MIOpen's igemm kernels compute in.  Feeding them
+(B, C, T) instead costs a transposed copy of the input plus 17 NCHW<->NHWC transposes of the activations per step
+(1.4 ms of 19 at the benchmark shape, profiles/r1c).
 """
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ign_hip import ops
 
@@ -20,7 +26,23 @@ class FullyConvNetwork(nn.Module):
         self.pooling = nn.AdaptiveAvgPool1d(1)
         self.fc = nn.Linear(128, configs.num_class)
 
+    @staticmethod
+    def _block(block, h):
+        conv, bn = block[0], block[1]
+        h = F.conv2d(h, conv.weight.unsqueeze(2), conv.bias)
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        h = F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training or not bn.track_running_stats,
+                         bn.momentum, bn.eps)
+        return F.relu(h)
+
     def forward(self, x, x_mark_enc=None, x_dec=None, x_mark_dec=None, mask=None, x_bct=None):
-        h = x_bct if x_bct is not None else x.permute(0, 2, 1)
-        h = self.block3(self.block2(self.block1(h)))
-        return ops.head_linear(self.pooling(h).flatten(start_dim=1), self.fc.weight, self.fc.bias)
+        if x.is_cuda and not torch.is_autocast_enabled():
+            h = x.permute(0, 2, 1).unsqueeze(2)                  # (B,C,1,T) view, channels-last strides, no copy
+            h = self._block(self.block3, self._block(self.block2, self._block(self.block1, h)))
+            pooled = h.mean(dim=(2, 3))
+        else:
+            h = x_bct if x_bct is not None else x.permute(0, 2, 1)
+            h = self.block3(self.block2(self.block1(h)))
+            pooled = self.pooling(h).flatten(start_dim=1)
+        return ops.head_linear(pooled, self.fc.weight, self.fc.bias)

@@ -46,13 +46,8 @@ class InterpGN(nn.Module):
         self.deep_model = dnn_dict[configs.dnn_type](configs)
 
     def forward(self, x, x_mark_enc=None, x_dec=None, x_mark_dec=None, mask=None, gating_value=None):
-        share = isinstance(self.deep_model, FullyConvNetwork)
-        xn, xt = ops.instance_norm(x, want_raw=share)      # one pass: normalised rows for the SBM, raw (B,C,T) for the FCN
-        sbm_out, info = self.sbm(x, xn=xn)
-        if share:
-            deep_out = self.deep_model(x, x_mark_enc, x_dec, x_mark_dec, mask, x_bct=xt)
-        else:
-            deep_out = self.deep_model(x, x_mark_enc, x_dec, x_mark_dec, mask)
+        sbm_out, info = self.sbm(x)
+        deep_out = self.deep_model(x, x_mark_enc, x_dec, x_mark_dec, mask)
         if torch.is_autocast_enabled():
             out, eta = gini_gate(sbm_out, deep_out, gating_value)
         else:
