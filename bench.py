@@ -180,6 +180,11 @@ def main():
         # length group; `achieved` aggregates the G launches of a step (algorithmic flops / measured device time).
         bwd_tflops = (f_bwd * args.steps) / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
         fwd_tflops = (f_fwd * args.steps) / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
+        traffic = None
+        try:        # HBM bytes per step of the dominant kernel, from the committed PMC passes (see profiles/traffic.json)
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["shp_bwd_kernel"]["bytes_per_step"]
+        except Exception:
+            pass
         res = {
             "metric": "epochs/sec (B=256, C=122, T=1000) IGN 3-class",
             "value": (args.steps * B * world / N_TRAIN) / dt,
@@ -194,7 +199,7 @@ def main():
                        "parallelism": f"dp{world}", "final_loss": float(last)},
             "roofline": {"bound": "valu", "kernel": "shp_bwd_kernel", "achieved": bwd_tflops,
                          "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": bwd_tflops / PEAK_FP32_VALU_TFLOPS,
-                         "traffic": None,
+                         "traffic": traffic,
                          "ms_per_step": bwd_ms / max(1, args.steps), "launches": bwd_n,
                          "fwd_kernel": {"kernel": "shp_fwd_kernel", "achieved": fwd_tflops,
                                         "frac": fwd_tflops / PEAK_FP32_VALU_TFLOPS,
