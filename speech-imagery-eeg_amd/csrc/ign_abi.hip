@@ -3,7 +3,6 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <algorithm>
-#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -139,11 +138,10 @@ extern "C" int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const f
     const int Tw = (T - L) / stride + 1;
     // TT windows per lane: one wave pass covers the row when Tw <= 1024; strided windows use TT = 1.
     int TT = (stride == 1) ? std::min(16, (Tw + 63) / 64) : 1;
-    if (stride == 1 && getenv("IGN_FWD_TT")) TT = std::max(1, std::min(16, atoi(getenv("IGN_FWD_TT"))));   // experiment knob
     const int npass = (Tw + 64 * TT - 1) / (64 * TT);
     int xs_len = (npass * 64 * TT - 1) * stride + (TT - 1) + L;
     xs_len = (xs_len + 3) & ~3;
-    int wpb = getenv("IGN_FWD_WPB") ? atoi(getenv("IGN_FWD_WPB")) : 4;   // experiment knob (waves per block)
+    int wpb = 1;      // one wave per block: waves share nothing, and the epilogue's __syncthreads() stays wave-local
     const size_t park = (npass > 1) ? (size_t)5 * 5 * 64 * 4 : 0;     // per wave: 5 stats x KT<=5 x 64 lanes
     while (wpb > 1 && (size_t)wpb * (xs_len * 4 + park) > 64 * 1024) wpb >>= 1;
     const size_t lds = (size_t)wpb * (xs_len * 4 + park);

@@ -121,52 +121,70 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
                 r_idx[k] = __float_as_int(park[(5 * k + 4) * blockDim.x]);
             }
         }
+        // Branch-free statistics.  Window positions past the end of the row (only in the last lanes) get d = +BIG:
+        // p = exp(-(eps BIG)^2) = 0 and exp(-(BIG - m)) = 0 never win the arg-max / arg-min and add nothing to M; the
+        // RBF soft-max weight exp(p) of such a slot is exactly 1, which is subtracted from Z afterwards.
+        const int nvalid = min(TT, max(0, a.Tw - tl));
+        const bool lds_store = (a.npass == 1) && a.d;          // x row no longer needed: reuse its LDS as a transpose buffer
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
             float* drow = a.d ? a.d + (((size_t)b * a.C + c) * a.K + (k0 + k)) * a.Tw : nullptr;
+            float dv[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) dv[t] = (t < nvalid) ? acc[k][t] * a.invL : 1e18f;
             if (a.gate == GATE_RBF) {
 #pragma unroll
                 for (int t = 0; t < TT; ++t) {
-                    const int tg = tl + t;
-                    if (tg < a.Tw) {
-                        const float dv = acc[k][t] * a.invL;
-                        if (drow && row_ok) drow[tg] = dv;
-                        const float u = a.eps * dv;
-                        const float p = __expf(-(u * u));
-                        const float e = __expf(p);
-                        r_Z[k] += e;
-                        r_M[k] = fmaf(e, p, r_M[k]);
-                        if (p > r_best[k]) { r_best[k] = p; r_idx[k] = tg; }
-                        r_dmin[k] = fminf(r_dmin[k], dv);
-                    }
-                    // keep the 2*KT*TT inlined expf bodies from being interleaved (register pressure, spills)
-                    __builtin_amdgcn_sched_barrier(0);
+                    const float u = a.eps * dv[t];
+                    const float p = __expf(-(u * u));
+                    const float e = __expf(p);
+                    r_Z[k] += e;
+                    r_M[k] = fmaf(e, p, r_M[k]);
+                    if (p > r_best[k]) { r_best[k] = p; r_idx[k] = tl + t; }
+                    r_dmin[k] = fminf(r_dmin[k], dv[t]);
+                    __builtin_amdgcn_sched_barrier(0);      // keep the inlined exp bodies from interleaving (VGPR pressure)
                 }
+                r_Z[k] -= (float)(TT - nvalid);
             } else {                                  // LTS: soft-min over d, stabilised by the running min
-                float pmin = INFINITY;
+                float pmin = dv[0];
 #pragma unroll
-                for (int t = 0; t < TT; ++t)
-                    if (tl + t < a.Tw) pmin = fminf(pmin, acc[k][t] * a.invL);
-                if (pmin < INFINITY) {
-                    // r_best holds -(running min) so the arg-min tie rule is "first index"
-                    const float mold = r_dmin[k];
-                    const float mnew = fminf(mold, pmin);
-                    const float sc = (mold < INFINITY) ? __expf(mnew - mold) : 0.f;
-                    r_Z[k] *= sc; r_M[k] *= sc;
+                for (int t = 1; t < TT; ++t) pmin = fminf(pmin, dv[t]);
+                // r_best holds -(running min) so the arg-min tie rule is "first index"
+                const float mold = r_dmin[k];
+                const float mnew = fminf(mold, pmin);
+                const float sc = (mold < INFINITY) ? __expf(mnew - mold) : 0.f;
+                r_Z[k] *= sc; r_M[k] *= sc;
+                if (mnew < 1e17f) {
 #pragma unroll
                     for (int t = 0; t < TT; ++t) {
-                        const int tg = tl + t;
-                        if (tg < a.Tw) {
-                            const float dv = acc[k][t] * a.invL;
-                            if (drow && row_ok) drow[tg] = dv;
-                            const float e = __expf(mnew - dv);
-                            r_Z[k] += e;
-                            r_M[k] = fmaf(e, dv, r_M[k]);
-                            if (-dv > r_best[k]) { r_best[k] = -dv; r_idx[k] = tg; }
-                        }
+                        const float e = __expf(mnew - dv[t]);
+                        r_Z[k] += e;
+                        r_M[k] = fmaf(e, dv[t], r_M[k]);
+                        if (-dv[t] > r_best[k]) { r_best[k] = -dv[t]; r_idx[k] = tl + t; }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     r_dmin[k] = mnew;
+                }
+            }
+            if (drow) {
+                if (lds_store) {
+                    // lane-major registers -> time-major LDS -> coalesced 256-B global stores.  (Storing straight from the
+                    // registers makes every store instruction touch 64 lines 4 bytes at a time: PMC WRITE_SIZE was 1.64x
+                    // the bytes actually written.)
+                    __syncthreads();
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) xs[lane * TT + t] = dv[t];
+                    __syncthreads();
+                    if (row_ok)
+#pragma unroll
+                        for (int i = 0; i < TT; ++i) {
+                            const int idx = lane + 64 * i;
+                            if (idx < a.Tw) drow[idx] = xs[idx];
+                        }
+                } else if (row_ok) {
+#pragma unroll
+                    for (int t = 0; t < TT; ++t)
+                        if (t < nvalid) drow[tl + t] = dv[t];
                 }
             }
         }
