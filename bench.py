@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--cpu-sample", type=int, default=4, help="samples for the CPU baseline step (0 = skip)")
+    ap.add_argument("--config", choices=["ign", "eegcnn", "transformer"], default="ign",
+                    help="ign = BASELINE.json's headline (config 1 / 5); eegcnn / transformer = the baselines of "
+                         "configs 3 / 4 on the same synthetic tensors")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,7 +130,17 @@ def main():
     cfg = ch_config()
     B, T, C = args.batch, cfg.seq_len, cfg.enc_in
     torch.manual_seed(0)                       # same initial replica on every rank
-    model = InterpGN(cfg).to(dev).train()
+    if args.config == "ign":
+        model = InterpGN(cfg)
+    elif args.config == "eegcnn":
+        from models.eegcnn import EEGCNNTransformer
+        cfg.eegcnn_layers, cfg.eegcnn_pooling, cfg.eegcnn_dropout1, cfg.eegcnn_dropout2 = 2, 'mean', 0.0, 0.0
+        cfg.eegcnn_n_heads, cfg.eegcnn_d_ff = 8, 256
+        model = EEGCNNTransformer(cfg)
+    else:
+        from models.Transformer import Model as TransformerModel
+        model = TransformerModel(cfg)
+    model = model.to(dev).train()
     bucket = FlatParamBucket(model, world)     # flat fp32 grad bucket: one RCCL all-reduce per step
     opt = FlatAdam(bucket, lr=5e-3)            # one ign_adam_step launch over the flat parameter buffer
 
@@ -139,8 +152,14 @@ def main():
 
     def step(i):
         x, y = xs[i % n_batches], ys[i % n_batches]
-        out, info = model(x, mask, None, None)
-        loss = F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y)
+        if args.config == "ign":
+            out, info = model(x, mask, None, None)
+            loss = F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y)
+        elif args.config == "eegcnn":
+            out, info = model(x.permute(0, 2, 1).contiguous())        # (B,C,T), no mask
+            loss = F.cross_entropy(out, y) + info.loss.mean()
+        else:
+            loss = F.cross_entropy(model(x, mask, None, None), y)
         loss.backward()
         bucket.allreduce()
         opt.step()
@@ -171,44 +190,65 @@ def main():
         dt = float(tt.item())
     fwd_ms, fwd_n = _lib.timing_read("shp_fwd")
     bwd_ms, bwd_n = _lib.timing_read("shp_bwd")
-    _lib.timing_enable(False)
 
+    attn = {k: _lib.timing_read(k) for k in ("attn_fwd", "attn_bwd_dkdv", "attn_bwd_dq")} if args.config != "ign" else {}
     if rank == 0:
-        groups = [(s.n, s.length) for s in model.sbm.shapelets]
-        f_fwd, f_bwd = shapelet_algorithmic_flops(B, C, T, groups)
-        # dominant kernel: the shapelet backward (3E of the 5E shapelet flops).  One step issues one launch per
-        # length group; `achieved` aggregates the G launches of a step (algorithmic flops / measured device time).
-        bwd_tflops = (f_bwd * args.steps) / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
-        fwd_tflops = (f_fwd * args.steps) / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
-        traffic = None
-        try:        # HBM bytes per step of the dominant kernel, from the committed PMC passes (see profiles/traffic.json)
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["shp_bwd_kernel"]["bytes_per_step"]
-        except Exception:
-            pass
         res = {
-            "metric": "epochs/sec (B=256, C=122, T=1000) IGN 3-class",
+            "metric": "epochs/sec (B=256, C=122, T=1000) IGN 3-class" if args.config == "ign" else
+                      f"epochs/sec (B=256, C=122, T=1000) {args.config} baseline 3-class",
             "value": (args.steps * B * world / N_TRAIN) / dt,
             "unit": "epochs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Synthetic CHISCO-shape EEG (122ch x 1000, 3-class) IGN(FCN expert), "
-                                   "driver-default groups K=5 x L{100,200,300,500}, Adam lr 5e-3, fp32",
-                       "per_gpu_batch": B, "global_batch": B * world, "samples_per_epoch": N_TRAIN,
-                       "parallelism": f"dp{world}", "final_loss": float(last)},
-            "roofline": {"bound": "valu", "kernel": "shp_bwd_kernel", "achieved": bwd_tflops,
-                         "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": bwd_tflops / PEAK_FP32_VALU_TFLOPS,
-                         "traffic": traffic,
-                         "ms_per_step": bwd_ms / max(1, args.steps), "launches": bwd_n,
-                         "fwd_kernel": {"kernel": "shp_fwd_kernel", "achieved": fwd_tflops,
-                                        "frac": fwd_tflops / PEAK_FP32_VALU_TFLOPS,
-                                        "ms_per_step": fwd_ms / max(1, args.steps), "launches": fwd_n}},
         }
-        if world == 1 and args.cpu_sample > 0:
+        common = {"per_gpu_batch": B, "global_batch": B * world, "samples_per_epoch": N_TRAIN,
+                  "parallelism": f"dp{world}", "final_loss": float(last)}
+        if args.config == "ign":
+            groups = [(s.n, s.length) for s in model.sbm.shapelets]
+            f_fwd, f_bwd = shapelet_algorithmic_flops(B, C, T, groups)
+            # dominant kernel: the shapelet backward (3E of the 5E shapelet flops).  One step issues one launch per
+            # length group; `achieved` aggregates the G launches of a step (algorithmic flops / measured device time).
+            bwd_tflops = (f_bwd * args.steps) / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
+            fwd_tflops = (f_fwd * args.steps) / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
+            traffic = None
+            try:    # HBM bytes per step of the dominant kernel, from the committed PMC passes (see profiles/traffic.json)
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["shp_bwd_kernel"]["bytes_per_step"]
+            except Exception:
+                pass
+            res["config"] = dict(common, workload="Synthetic CHISCO-shape EEG (122ch x 1000, 3-class) IGN(FCN expert), "
+                                 "driver-default groups K=5 x L{100,200,300,500}, Adam lr 5e-3, fp32")
+            res["roofline"] = {"bound": "valu", "kernel": "shp_bwd_kernel", "achieved": bwd_tflops,
+                               "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": bwd_tflops / PEAK_FP32_VALU_TFLOPS,
+                               "traffic": traffic, "ms_per_step": bwd_ms / max(1, args.steps), "launches": bwd_n,
+                               "fwd_kernel": {"kernel": "shp_fwd_kernel", "achieved": fwd_tflops,
+                                              "frac": fwd_tflops / PEAK_FP32_VALU_TFLOPS,
+                                              "ms_per_step": fwd_ms / max(1, args.steps), "launches": fwd_n}}
+        else:
+            # attention core: fwd 4*B*H*L*S*E flop per layer (QK^T + PV); the two backward kernels execute 7 products
+            # (S and dP are recomputed for dQ) but the ALGORITHMIC count is 5 products = 2.5x forward.
+            if args.config == "transformer":
+                Bh, Lq, E_, layers, desc = B * cfg.n_heads, T, cfg.d_model // cfg.n_heads, cfg.e_layers, \
+                    "Transformer-encoder baseline (d_model 512, 8 heads, d_ff 2048, 2 layers)"
+            else:
+                Bh, Lq, E_, layers, desc = B * 8, T // 10, cfg.d_model // 8, 2, \
+                    "EEG-CNN baseline (CNN 8x8 filters k=125/25 + 2-layer encoder d_model 512, 8 heads, d_ff 256)"
+            f_attn_fwd = 4.0 * Bh * Lq * Lq * E_ * layers
+            ms_f, ms_b = attn["attn_fwd"][0], attn["attn_bwd_dkdv"][0] + attn["attn_bwd_dq"][0]
+            tf_f = f_attn_fwd * args.steps / (ms_f * 1e-3) / 1e12 if ms_f > 0 else 0.0
+            tf_b = 2.5 * f_attn_fwd * args.steps / (ms_b * 1e-3) / 1e12 if ms_b > 0 else 0.0
+            res["config"] = dict(common, workload=f"Synthetic CHISCO-shape EEG (122ch x 1000, 3-class) {desc}, Adam lr 5e-3, fp32")
+            res["roofline"] = {"bound": "mfma", "kernel": "attn_bwd_dkdv_kernel+attn_bwd_dq_kernel", "achieved": tf_b,
+                               "peak": 157.3, "unit": "TFLOP/s", "frac": tf_b / 157.3, "traffic": None,
+                               "ms_per_step": ms_b / max(1, args.steps),
+                               "fwd_kernel": {"kernel": "attn_fwd_kernel", "achieved": tf_f, "frac": tf_f / 157.3,
+                                              "ms_per_step": ms_f / max(1, args.steps)}}
+        if world == 1 and args.cpu_sample > 0 and args.config == "ign":
             log("cpu baseline ...")
             res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, host_cores())
         print(json.dumps(res), flush=True)
+    _lib.timing_enable(False)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
