@@ -116,10 +116,33 @@ int ign_gate_bwd(const float* sbm, const float* dnn, const float* gout, const fl
 int ign_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                   float beta1, float beta2, float eps, int step, void* stream);
 
+/* EEG-CNN block 1 without its (B,F1,C,T) intermediate (1 GB at B=256) -- see csrc/ign_eegcnn.hip for the algebra.
+ * Replaces the BatchNorm-1 batch statistics of IGN/model/eegcnn.py:90-91 (block1_conv1 -> block1_bn1):
+ *   y1[r,f,t] = sum_j w1[f,j] xpad[r, t+j]   (rows r = (b,c); 'same' zero padding, pad_left on the left)
+ *   fwd:  m2[f]   = sum_{r,t} (y1 - mu[f])^2                     (mu = the batch mean, supplied by the caller)
+ *   bwd:  g[f,j]  = sum_{r,t} (y1 - mu[f]) xpad[r, t+j]          (= 1/2 d m2[f] / d w1[f,j])
+ * x (rows,T), w1 (F1,k1), mu (F1); workspace: ign_conv1_sumsq_workspace_bytes().  Deterministic reductions.       */
+size_t ign_conv1_sumsq_workspace_bytes(int rows, int F1, int k1);
+int ign_conv1_sumsq_fwd(const float* x, const float* w1, const float* mu, float* m2, void* workspace,
+                        int rows, int T, int F1, int k1, int pad_left, void* stream);
+int ign_conv1_sumsq_bwd(const float* x, const float* w1, const float* mu, float* g_fj, void* workspace,
+                        int rows, int T, int F1, int k1, int pad_left, void* stream);
+
+/* Depthwise (per-channel) 1-D convolution over time, zero 'same' padding: y[b,c,t] = sum_j w[c,j] xpad[b,c,t+j].
+ * Replaces the temporal convolutions of IGN/model/eegcnn.py:67 (after the channel contraction) and :78 (block2_conv1).
+ * flip=1 correlates with the reversed filter (gradient w.r.t. x: call with dy and pad_left = k-1-pad_left).
+ * bwd_weight: dw[c,j] = sum_{b,t} dy[b,c,t] xpad[b,c,t+j]  (workspace: ign_dwconv1d_bwd_weight_workspace_bytes()). */
+int ign_dwconv1d_fwd(const float* x, const float* w, float* y, int B, int C, int T, int k, int pad_left, int flip,
+                     void* stream);
+size_t ign_dwconv1d_bwd_weight_workspace_bytes(int B, int C, int k);
+int ign_dwconv1d_bwd_weight(const float* x, const float* dy, float* dw, void* workspace, int B, int C, int T, int k,
+                            int pad_left, void* stream);
+
 /* Per-kernel HIP-event timing (measurement only; off by default).  When enabled every kernel launch made by
  * this library is bracketed by hipEventRecord on the caller's stream.  ign_timing_read() waits for the recorded
  * events of `label` ("shp_fwd", "shp_bwd", "reduce_parts", "instnorm", "attn_fwd", "attn_bwd_dkdv", "attn_bwd_dq",
- * "attn_delta", "head_fwd", "head_bwd_x", "head_bwd_w", "adam"), and returns the accumulated
+ * "attn_delta", "head_fwd", "head_bwd_x", "head_bwd_w", "adam",
+ * "conv1_sumsq_fwd", "conv1_sumsq_bwd", "dwconv1d", "dwconv1d_bwd_w"), and returns the accumulated
  * device milliseconds and launch count since the last enable.  Not for use under graph capture.             */
 int ign_timing_enable(int on);
 int ign_timing_read(const char* label, double* total_ms, long long* launches);

@@ -1,0 +1,436 @@
+// EEG-CNN convolution block (IGN/model/eegcnn.py:67-108) without its 1 GB intermediates.
+//
+// Block 1 of the reference is  temporal conv (1 -> F1 filters, 1 x k1, 'same', no bias) -> BatchNorm2d(F1) ->
+// depthwise spatial conv (C x 1, groups F1, D outputs per group, no bias) -> BatchNorm2d(F1*D) -> ELU -> AvgPool.
+// The temporal conv has ONE input channel and the spatial conv only mixes the electrode axis, and BatchNorm is an
+// affine map per filter, so with  u[b,o,t] = sum_c w2[o,c] x[b,c,t]  (a 64 x 122 GEMM per time step)
+//     y2[b,o,t] = a_f * (w1[f] (*) u[b,o,:])[t] + b_f * sum_c w2[o,c],      f = o / D,
+// where a_f, b_f fold BatchNorm-1.  What cannot be moved behind the channel contraction are BatchNorm-1's BATCH
+// STATISTICS: mean and variance of y1[b,f,c,t] = (w1[f] (*) x[b,c,:])[t] over (b,c,t).  The mean is a closed form of
+// shifted sums of x (host side, autograd); the variance needs  sum (y1 - mu)^2  -- this file computes it, and its
+// gradient w.r.t. w1, by brute force on the VALU *without ever storing y1* (B*F1*C*T floats = 1 GB at B=256):
+//   ign_conv1_sumsq_fwd : M2[f] = sum_{rows,t} (y1 - mu_f)^2                      B*C*T*F1*k1 = 3.1e10 FMA
+//   ign_conv1_sumsq_bwd : G[f,j] = sum_{rows,t} (y1 - mu_f) * xpad[t + j]          2x that (recompute y1, correlate)
+// plus the depthwise temporal convolution used for  w1[f] (*) u  and for block 2 (IGN/model/eegcnn.py:78):
+//   ign_dwconv1d_fwd / _bwd_data / _bwd_weight : per-channel 1-D 'same' convolution, rows (b, channel) x time,
+//   coalesced row reads, the row staged once in LDS with its zero padding.
+// Both brute-force kernels reuse the sliding-register-window structure of the shapelet kernels (ign_shapelet_*.h):
+// lane <-> consecutive output times with the taps as wave-uniform SGPR operands (forward), lane <-> (filter, taps)
+// with the row values as LDS broadcasts (gradient); fp32 FMA, deterministic two-stage reductions.
+#include "ign_common.h"
+
+typedef const __attribute__((address_space(4))) float* cfloat_p;
+
+// ------------------------------------------------------------------------------------------------ sum (y1-mu)^2
+// block = 128 threads = one (b,c) row at a time, TT = 8 outputs per lane, FT = 8 filters per pass.
+constexpr int C1_TT = 8, C1_FT = 8, C1_J = 4, C1_THREADS = 128;
+
+template <bool STORE_Y>
+__device__ __forceinline__ void conv1_row(const float* xs, cfloat_p w, const float* mu, int T, int k1, int nf, int t0,
+                                          float (&acc)[C1_FT][C1_TT]) {
+    // acc[f][tt] = sum_j w[f*k1 + j] * xs[t0 + tt + j]   (xs already left-padded: xs[i] = xpad[i])
+#pragma unroll
+    for (int f = 0; f < C1_FT; ++f)
+#pragma unroll
+        for (int t = 0; t < C1_TT; ++t) acc[f][t] = 0.f;
+    float xw[C1_TT + C1_J - 1];
+#pragma unroll
+    for (int i = 0; i < C1_TT - 1; ++i) xw[i] = xs[t0 + i];
+    int j0 = 0;
+    for (; j0 + C1_J <= k1; j0 += C1_J) {
+#pragma unroll
+        for (int jj = 0; jj < C1_J; ++jj) xw[C1_TT - 1 + jj] = xs[t0 + j0 + C1_TT - 1 + jj];
+#pragma unroll
+        for (int jj = 0; jj < C1_J; ++jj)
+#pragma unroll
+            for (int f = 0; f < C1_FT; ++f) {
+                const float wv = (f < nf) ? w[f * k1 + j0 + jj] : 0.f;      // wave-uniform: SGPR operand
+#pragma unroll
+                for (int t = 0; t < C1_TT; ++t) acc[f][t] = fmaf(wv, xw[t + jj], acc[f][t]);
+            }
+#pragma unroll
+        for (int i = 0; i < C1_TT - 1; ++i) xw[i] = xw[i + C1_J];
+    }
+    for (; j0 < k1; ++j0) {
+        xw[C1_TT - 1] = xs[t0 + j0 + C1_TT - 1];
+#pragma unroll
+        for (int f = 0; f < C1_FT; ++f) {
+            const float wv = (f < nf) ? w[f * k1 + j0] : 0.f;
+#pragma unroll
+            for (int t = 0; t < C1_TT; ++t) acc[f][t] = fmaf(wv, xw[t], acc[f][t]);
+        }
+#pragma unroll
+        for (int i = 0; i < C1_TT - 1; ++i) xw[i] = xw[i + 1];
+    }
+}
+
+__global__ void __launch_bounds__(C1_THREADS) conv1_sumsq_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                                     const float* __restrict__ mu, float* __restrict__ part,
+                                                                     int rows, int T, int F1, int k1, int pl, int xs_len,
+                                                                     int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];          // xpad of the current row
+    __shared__ float red[C1_THREADS / 64][C1_FT];
+    const int tid = threadIdx.x;
+    const int f0 = blockIdx.y * C1_FT;
+    const int nf = min(C1_FT, F1 - f0);
+    const cfloat_p w = (cfloat_p)(uintptr_t)(w1 + (size_t)f0 * k1);
+    float muf[C1_FT], s2[C1_FT];
+#pragma unroll
+    for (int f = 0; f < C1_FT; ++f) { muf[f] = (f < nf) ? mu[f0 + f] : 0.f; s2[f] = 0.f; }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int r = r0; r < r1; ++r) {
+        __syncthreads();
+        const float* row = x + (size_t)r * T;
+        for (int i = tid; i < xs_len; i += C1_THREADS) {
+            const int s = i - pl;
+            xs[i] = (s >= 0 && s < T) ? row[s] : 0.f;
+        }
+        __syncthreads();
+        for (int t0 = tid * C1_TT; t0 < T; t0 += C1_THREADS * C1_TT) {
+            float acc[C1_FT][C1_TT];
+            conv1_row<false>(xs, w, muf, T, k1, nf, t0, acc);
+#pragma unroll
+            for (int f = 0; f < C1_FT; ++f)
+#pragma unroll
+                for (int t = 0; t < C1_TT; ++t)
+                    if (t0 + t < T) {
+                        const float dv = acc[f][t] - muf[f];
+                        s2[f] = fmaf(dv, dv, s2[f]);
+                    }
+        }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int f = 0; f < C1_FT; ++f) {
+        float v = s2[f];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave][f] = v;
+    }
+    __syncthreads();
+    if (tid < nf) {
+        float v = 0.f;
+        for (int wv = 0; wv < C1_THREADS / 64; ++wv) v += red[wv][tid];
+        part[(size_t)blockIdx.x * F1 + f0 + tid] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ gradient of the above
+// G[f,j] = sum_{rows,t} (y1[f,t] - mu_f) * xpad[t + j].  Block = 256 threads; per row: phase (a) recompute the centred
+// y1 row tile into LDS (thread <-> 4 consecutive t, all 8 filters), phase (b) lane <-> (f, 4 consecutive taps) slides
+// over t with the y1 values as LDS broadcasts and a ping-pong register window on xpad.
+constexpr int G_THREADS = 256, G_JJ = 4, G_TA = 4;
+
+__global__ void __launch_bounds__(G_THREADS) conv1_sumsq_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                                    const float* __restrict__ mu, float* __restrict__ part,
+                                                                    int rows, int T, int F1, int k1, int pl, int xs_len,
+                                                                    int tpad, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                       // [xs_len]   xpad (zero beyond the row)
+    float* ys = smem + xs_len;              // [C1_FT][tpad]  centred y1 of the row (zero beyond T)
+    const int tid = threadIdx.x;
+    const int f0 = blockIdx.y * C1_FT;
+    const int nf = min(C1_FT, F1 - f0);
+    const cfloat_p w = (cfloat_p)(uintptr_t)(w1 + (size_t)f0 * k1);
+    const int cpf = (k1 + G_JJ - 1) / G_JJ;                 // tap chunks per filter
+    int fl = tid / cpf;
+    const int jc = tid - fl * cpf;
+    const bool active = fl < nf;
+    if (!active) fl = nf - 1;
+    const int jbase = jc * G_JJ;
+    float acc[G_JJ];
+#pragma unroll
+    for (int q = 0; q < G_JJ; ++q) acc[q] = 0.f;
+
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int r = r0; r < r1; ++r) {
+        __syncthreads();
+        const float* row = x + (size_t)r * T;
+        for (int i = tid; i < xs_len; i += G_THREADS) {
+            const int s = i - pl;
+            xs[i] = (s >= 0 && s < T) ? row[s] : 0.f;
+        }
+        __syncthreads();
+        // (a) centred y1 tile
+        for (int t0 = tid * G_TA; t0 < tpad; t0 += G_THREADS * G_TA) {
+            float a[C1_FT][G_TA];
+#pragma unroll
+            for (int f = 0; f < C1_FT; ++f)
+#pragma unroll
+                for (int t = 0; t < G_TA; ++t) a[f][t] = 0.f;
+            if (t0 < T) {
+                float xw[G_TA + C1_J - 1];
+#pragma unroll
+                for (int i = 0; i < G_TA - 1; ++i) xw[i] = xs[t0 + i];
+                int j0 = 0;
+                for (; j0 + C1_J <= k1; j0 += C1_J) {
+#pragma unroll
+                    for (int jj = 0; jj < C1_J; ++jj) xw[G_TA - 1 + jj] = xs[t0 + j0 + G_TA - 1 + jj];
+#pragma unroll
+                    for (int jj = 0; jj < C1_J; ++jj)
+#pragma unroll
+                        for (int f = 0; f < C1_FT; ++f) {
+                            const float wv = (f < nf) ? w[f * k1 + j0 + jj] : 0.f;
+#pragma unroll
+                            for (int t = 0; t < G_TA; ++t) a[f][t] = fmaf(wv, xw[t + jj], a[f][t]);
+                        }
+#pragma unroll
+                    for (int i = 0; i < G_TA - 1; ++i) xw[i] = xw[i + C1_J];
+                }
+                for (; j0 < k1; ++j0) {
+                    xw[G_TA - 1] = xs[t0 + j0 + G_TA - 1];
+#pragma unroll
+                    for (int f = 0; f < C1_FT; ++f) {
+                        const float wv = (f < nf) ? w[f * k1 + j0] : 0.f;
+#pragma unroll
+                        for (int t = 0; t < G_TA; ++t) a[f][t] = fmaf(wv, xw[t], a[f][t]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < G_TA - 1; ++i) xw[i] = xw[i + 1];
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < C1_FT; ++f) {
+                float4 v;
+                const float m = (f < nf) ? mu[f0 + f] : 0.f;
+                v.x = (t0 + 0 < T) ? a[f][0] - m : 0.f;
+                v.y = (t0 + 1 < T) ? a[f][1] - m : 0.f;
+                v.z = (t0 + 2 < T) ? a[f][2] - m : 0.f;
+                v.w = (t0 + 3 < T) ? a[f][3] - m : 0.f;
+                *reinterpret_cast<float4*>(ys + f * tpad + t0) = v;
+            }
+        }
+        __syncthreads();
+        // (b) correlate: acc[q] += sum_t y[fl][t] * xpad[t + jbase + q]
+        {
+            const float* yl = ys + fl * tpad;
+            const float* xl = xs + jbase;
+            float Wa[G_JJ], Wb[G_JJ], A[G_JJ];
+            float4 v = *reinterpret_cast<const float4*>(xl);
+            Wa[0] = v.x; Wa[1] = v.y; Wa[2] = v.z; Wa[3] = v.w;
+            for (int t = 0; t < tpad; t += 2 * G_JJ) {
+                v = *reinterpret_cast<const float4*>(xl + t + G_JJ);
+                Wb[0] = v.x; Wb[1] = v.y; Wb[2] = v.z; Wb[3] = v.w;
+                v = *reinterpret_cast<const float4*>(yl + t);
+                A[0] = v.x; A[1] = v.y; A[2] = v.z; A[3] = v.w;
+#pragma unroll
+                for (int tt = 0; tt < G_JJ; ++tt)
+#pragma unroll
+                    for (int q = 0; q < G_JJ; ++q)
+                        acc[q] = fmaf(A[tt], (tt + q) < G_JJ ? Wa[(tt + q) % G_JJ] : Wb[(tt + q) % G_JJ], acc[q]);
+                v = *reinterpret_cast<const float4*>(xl + t + 2 * G_JJ);
+                Wa[0] = v.x; Wa[1] = v.y; Wa[2] = v.z; Wa[3] = v.w;
+                v = *reinterpret_cast<const float4*>(yl + t + G_JJ);
+                A[0] = v.x; A[1] = v.y; A[2] = v.z; A[3] = v.w;
+#pragma unroll
+                for (int tt = 0; tt < G_JJ; ++tt)
+#pragma unroll
+                    for (int q = 0; q < G_JJ; ++q)
+                        acc[q] = fmaf(A[tt], (tt + q) < G_JJ ? Wb[(tt + q) % G_JJ] : Wa[(tt + q) % G_JJ], acc[q]);
+            }
+        }
+    }
+    if (active) {
+        float* out = part + ((size_t)blockIdx.x * F1 + f0 + fl) * k1;
+#pragma unroll
+        for (int q = 0; q < G_JJ; ++q)
+            if (jbase + q < k1) out[jbase + q] = acc[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise 1-D conv
+// y[r, t] = sum_j w[ch(r), j] * xpad[r, t + j],  rows r = (b, ch), ch = r % Cc;  'same' zero padding pl / k-1-pl.
+// FLIP selects the correlation with the reversed filter (gradient w.r.t. the input: pl' = k-1-pl).
+template <bool FLIP>
+__global__ void __launch_bounds__(256) dwconv1d_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       float* __restrict__ y, int rows, int Cc, int T, int k, int pl,
+                                                       int xs_len) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xs = sm;                  // [xs_len]
+    float* ws = sm + xs_len;         // [k]
+    const int r = blockIdx.x;
+    const int ch = r % Cc;
+    const float* row = x + (size_t)r * T;
+    for (int i = threadIdx.x; i < xs_len; i += 256) {
+        const int s = i - pl;
+        xs[i] = (s >= 0 && s < T) ? row[s] : 0.f;
+    }
+    for (int j = threadIdx.x; j < k; j += 256) ws[j] = FLIP ? w[(size_t)ch * k + (k - 1 - j)] : w[(size_t)ch * k + j];
+    __syncthreads();
+    for (int t0 = threadIdx.x * 4; t0 < T; t0 += 1024) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float x0 = xs[t0], x1 = xs[t0 + 1], x2 = xs[t0 + 2];
+        for (int j = 0; j < k; ++j) {
+            const float x3 = xs[t0 + j + 3];
+            const float wv = ws[j];
+            a0 = fmaf(wv, x0, a0); a1 = fmaf(wv, x1, a1); a2 = fmaf(wv, x2, a2); a3 = fmaf(wv, x3, a3);
+            x0 = x1; x1 = x2; x2 = x3;
+        }
+        float* yo = y + (size_t)r * T + t0;
+        if (t0 + 3 < T) { yo[0] = a0; yo[1] = a1; yo[2] = a2; yo[3] = a3; }
+        else { if (t0 < T) yo[0] = a0; if (t0 + 1 < T) yo[1] = a1; if (t0 + 2 < T) yo[2] = a2; }
+    }
+}
+
+// dw[ch, j] partial over a slice of the batch: part[bs, ch, j] = sum_{b in slice} sum_t dy[b,ch,t] * xpad[b,ch,t + j]
+__global__ void __launch_bounds__(256) dwconv1d_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             float* __restrict__ part, int B, int Cc, int T, int k, int pl,
+                                                             int xs_len, int nbs) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xs = sm;                  // [xs_len]
+    float* gs = sm + xs_len;         // [T]
+    const int ch = blockIdx.x, bs = blockIdx.y;
+    const int b0 = (int)(((long long)B * bs) / nbs), b1 = (int)(((long long)B * (bs + 1)) / nbs);
+    const int j = threadIdx.x;       // taps beyond 256 loop below
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};                  // taps j, j+256, j+512, j+768 (k <= 1024)
+    for (int b = b0; b < b1; ++b) {
+        __syncthreads();
+        const float* row = x + ((size_t)b * Cc + ch) * T;
+        const float* grow = dy + ((size_t)b * Cc + ch) * T;
+        for (int i = threadIdx.x; i < xs_len; i += 256) {
+            const int s = i - pl;
+            xs[i] = (s >= 0 && s < T) ? row[s] : 0.f;
+        }
+        for (int i = threadIdx.x; i < T; i += 256) gs[i] = grow[i];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int jj = j + 256 * q;
+            if (jj < k) {
+                float a = acc[q];
+                for (int t = 0; t < T; ++t) a = fmaf(gs[t], xs[t + jj], a);
+                acc[q] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int jj = j + 256 * q;
+        if (jj < k) part[((size_t)bs * Cc + ch) * k + jj] = acc[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static int conv1_check(const char* who, const void* x, const void* w1, const void* mu, const void* out, const void* ws,
+                       int rows, int T, int F1, int k1, int pl) {
+    if (!x || !w1 || !mu || !out || !ws || rows <= 0 || T <= 0 || F1 <= 0 || k1 <= 0 || pl < 0 || pl >= k1) {
+        ign_set_error("%s: null pointer or bad dimension (rows=%d T=%d F1=%d k1=%d pl=%d)", who, rows, T, F1, k1, pl);
+        return IGN_E_ARG;
+    }
+    if ((size_t)(T + k1 + 64) * 4 * 10 > 160 * 1024) {
+        ign_set_error("%s: T=%d does not fit the LDS row tile", who, T);
+        return IGN_E_TOOBIG;
+    }
+    return 0;
+}
+
+static int conv1_blocks(int rows, int* rows_per_block) {
+    int rpb = (rows + 4095) / 4096;                  // ~4096 blocks: fills 256 CUs with a short tail
+    if (rpb < 1) rpb = 1;
+    *rows_per_block = rpb;
+    return (rows + rpb - 1) / rpb;
+}
+
+extern "C" size_t ign_conv1_sumsq_workspace_bytes(int rows, int F1, int k1) {
+    if (rows <= 0 || F1 <= 0 || k1 <= 0) return 0;
+    int rpb;
+    const int nb = conv1_blocks(rows, &rpb);
+    return (size_t)nb * F1 * k1 * sizeof(float);     // sized for the gradient; the forward uses nb*F1 of it
+}
+
+extern "C" int ign_conv1_sumsq_fwd(const float* x, const float* w1, const float* mu, float* m2, void* workspace, int rows,
+                                   int T, int F1, int k1, int pad_left, void* stream) {
+    static const char* who = "ign_conv1_sumsq_fwd";
+    int rc;
+    if ((rc = conv1_check(who, x, w1, mu, m2, workspace, rows, T, F1, k1, pad_left))) return rc;
+    int rpb;
+    const int nb = conv1_blocks(rows, &rpb);
+    const int tslots = ((T + C1_TT - 1) / C1_TT) * C1_TT;
+    const int xs_len = (tslots + k1 + C1_TT + 3) & ~3;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        IgnScopedTimer tm("conv1_sumsq_fwd", s);
+        hipLaunchKernelGGL(conv1_sumsq_fwd_kernel, dim3(nb, (F1 + C1_FT - 1) / C1_FT), dim3(C1_THREADS), (size_t)xs_len * 4, s, x,
+                           w1, mu, (float*)workspace, rows, T, F1, k1, pad_left, xs_len, rpb);
+    }
+    if ((rc = ign_check_launch("conv1_sumsq_fwd_kernel"))) return rc;
+    ign_launch_reduce_parts((const float*)workspace, m2, nb, (size_t)F1, s);
+    return ign_check_launch("reduce_parts_kernel");
+}
+
+extern "C" int ign_conv1_sumsq_bwd(const float* x, const float* w1, const float* mu, float* g_fj, void* workspace, int rows,
+                                   int T, int F1, int k1, int pad_left, void* stream) {
+    static const char* who = "ign_conv1_sumsq_bwd";
+    int rc;
+    if ((rc = conv1_check(who, x, w1, mu, g_fj, workspace, rows, T, F1, k1, pad_left))) return rc;
+    if (((k1 + G_JJ - 1) / G_JJ) * std::min(F1, C1_FT) > G_THREADS) {
+        ign_set_error("%s: F1*k1 = %d*%d exceeds the %d (filter, tap-chunk) lanes of a block", who, F1, k1, G_THREADS);
+        return IGN_E_UNSUP;
+    }
+    int rpb;
+    const int nb = conv1_blocks(rows, &rpb);
+    const int tpad = ((T + 2 * G_JJ - 1) / (2 * G_JJ)) * (2 * G_JJ);
+    const int xs_len = (tpad + k1 + 2 * G_JJ + 8 + 3) & ~3;
+    const size_t lds = ((size_t)xs_len + (size_t)C1_FT * tpad) * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)conv1_sumsq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        IgnScopedTimer tm("conv1_sumsq_bwd", s);
+        hipLaunchKernelGGL(conv1_sumsq_bwd_kernel, dim3(nb, (F1 + C1_FT - 1) / C1_FT), dim3(G_THREADS), lds, s, x, w1, mu,
+                           (float*)workspace, rows, T, F1, k1, pad_left, xs_len, tpad, rpb);
+    }
+    if ((rc = ign_check_launch("conv1_sumsq_bwd_kernel"))) return rc;
+    ign_launch_reduce_parts((const float*)workspace, g_fj, nb, (size_t)F1 * k1, s);
+    return ign_check_launch("reduce_parts_kernel");
+}
+
+static int dw_check(const char* who, const void* a, const void* b, const void* c, int B, int Cc, int T, int k, int pl) {
+    if (!a || !b || !c || B <= 0 || Cc <= 0 || T <= 0 || k <= 0 || k > 1024 || pl < 0 || pl >= k) {
+        ign_set_error("%s: null pointer or bad dimension (B=%d C=%d T=%d k=%d pl=%d)", who, B, Cc, T, k, pl);
+        return IGN_E_ARG;
+    }
+    if ((size_t)(2 * T + 2 * k + 16) * 4 > 64 * 1024) {
+        ign_set_error("%s: T=%d k=%d does not fit the LDS row tile", who, T, k);
+        return IGN_E_TOOBIG;
+    }
+    return 0;
+}
+
+extern "C" int ign_dwconv1d_fwd(const float* x, const float* w, float* y, int B, int Cc, int T, int k, int pad_left,
+                                int flip, void* stream) {
+    int rc;
+    if ((rc = dw_check("ign_dwconv1d_fwd", x, w, y, B, Cc, T, k, pad_left))) return rc;
+    const int xs_len = (T + k + 8 + 3) & ~3;
+    const size_t lds = ((size_t)xs_len + k) * 4;
+    hipStream_t s = (hipStream_t)stream;
+    IgnScopedTimer tm("dwconv1d", s);
+    if (flip) hipLaunchKernelGGL(dwconv1d_kernel<true>, dim3((unsigned)B * Cc), dim3(256), lds, s, x, w, y, B * Cc, Cc, T, k, pad_left, xs_len);
+    else      hipLaunchKernelGGL(dwconv1d_kernel<false>, dim3((unsigned)B * Cc), dim3(256), lds, s, x, w, y, B * Cc, Cc, T, k, pad_left, xs_len);
+    return ign_check_launch("dwconv1d_kernel");
+}
+
+extern "C" size_t ign_dwconv1d_bwd_weight_workspace_bytes(int B, int Cc, int k) {
+    if (B <= 0 || Cc <= 0 || k <= 0) return 0;
+    const int nbs = std::max(1, std::min(B, 32));
+    return (size_t)nbs * Cc * k * sizeof(float);
+}
+
+extern "C" int ign_dwconv1d_bwd_weight(const float* x, const float* dy, float* dw, void* workspace, int B, int Cc, int T,
+                                       int k, int pad_left, void* stream) {
+    int rc;
+    if ((rc = dw_check("ign_dwconv1d_bwd_weight", x, dy, dw, B, Cc, T, k, pad_left))) return rc;
+    if (!workspace) { ign_set_error("ign_dwconv1d_bwd_weight: null workspace"); return IGN_E_ARG; }
+    const int nbs = std::max(1, std::min(B, 32));
+    const int xs_len = (T + k + 8 + 3) & ~3;
+    const size_t lds = ((size_t)xs_len + T) * 4;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        IgnScopedTimer tm("dwconv1d_bwd_w", s);
+        hipLaunchKernelGGL(dwconv1d_bwd_w_kernel, dim3(Cc, nbs), dim3(256), lds, s, x, dy, (float*)workspace, B, Cc, T, k, pad_left,
+                           xs_len, nbs);
+    }
+    if ((rc = ign_check_launch("dwconv1d_bwd_w_kernel"))) return rc;
+    ign_launch_reduce_parts((const float*)workspace, dw, nbs, (size_t)Cc * k, s);
+    return ign_check_launch("reduce_parts_kernel");
+}

@@ -29,6 +29,12 @@ SIGNATURES = {
     "ign_gate_fwd": (ci, [vp, vp, vp, vp, ci, ci, cf, ci, vp]),
     "ign_gate_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp]),
     "ign_adam_step": (ci, [vp, vp, vp, vp, ll, cf, cf, cf, cf, ci, vp]),
+    "ign_conv1_sumsq_workspace_bytes": (sz, [ci, ci, ci]),
+    "ign_conv1_sumsq_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ign_conv1_sumsq_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ign_dwconv1d_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "ign_dwconv1d_bwd_weight_workspace_bytes": (sz, [ci, ci, ci]),
+    "ign_dwconv1d_bwd_weight": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ign_timing_enable": (ci, [ci]),
     "ign_timing_read": (ci, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
     "ign_shapelet_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),

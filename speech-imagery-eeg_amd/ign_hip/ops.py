@@ -243,3 +243,79 @@ class GiniGateFn(torch.autograd.Function):
 
 def gini_gate(sbm_out, dnn_out, gating_value=None):
     return GiniGateFn.apply(sbm_out.float(), dnn_out.float(), gating_value)
+
+
+class Conv1SumSqFn(torch.autograd.Function):
+    """m2[f] = sum_{rows,t} ((w1[f] (*) x_row)[t] - mu[f])^2 without storing the convolution (ign_conv1_sumsq_*).
+    d m2 / d mu = -2 sum (y1 - mu) = 0 when mu is the batch mean, which is the only use (BatchNorm-1 of EEG-CNN)."""
+
+    @staticmethod
+    def forward(ctx, x_rows, w1, mu, pad_left):
+        _need_gpu("conv1_sumsq", x_rows, w1, mu)
+        x_rows, w1, mu = x_rows.contiguous(), w1.contiguous(), mu.contiguous()
+        R, T = x_rows.shape
+        F1, k1 = w1.shape
+        L = _lib.lib()
+        ws = torch.empty(L.ign_conv1_sumsq_workspace_bytes(R, F1, k1) // 4, device=x_rows.device, dtype=torch.float32)
+        m2 = torch.empty(F1, device=x_rows.device, dtype=torch.float32)
+        _lib.check(L.ign_conv1_sumsq_fwd(_ptr(x_rows), _ptr(w1), _ptr(mu), _ptr(m2), _ptr(ws), R, T, F1, k1, int(pad_left),
+                                         _stream()), "ign_conv1_sumsq_fwd")
+        ctx.save_for_backward(x_rows, w1, mu)
+        ctx.pl = int(pad_left)
+        return m2
+
+    @staticmethod
+    def backward(ctx, g):
+        x_rows, w1, mu = ctx.saved_tensors
+        R, T = x_rows.shape
+        F1, k1 = w1.shape
+        L = _lib.lib()
+        ws = torch.empty(L.ign_conv1_sumsq_workspace_bytes(R, F1, k1) // 4, device=x_rows.device, dtype=torch.float32)
+        G = torch.empty(F1, k1, device=x_rows.device, dtype=torch.float32)
+        _lib.check(L.ign_conv1_sumsq_bwd(_ptr(x_rows), _ptr(w1), _ptr(mu), _ptr(G), _ptr(ws), R, T, F1, k1, ctx.pl, _stream()),
+                   "ign_conv1_sumsq_bwd")
+        return None, 2.0 * g.unsqueeze(1) * G, None, None
+
+
+def conv1_sumsq(x_rows, w1, mu, pad_left):
+    return Conv1SumSqFn.apply(x_rows, w1, mu, pad_left)
+
+
+class DwConv1dFn(torch.autograd.Function):
+    """Depthwise 'same' 1-D convolution y[b,c,t] = sum_j w[c,j] xpad[b,c,t+j]  (ign_dwconv1d_*)."""
+
+    @staticmethod
+    def forward(ctx, x, w, pad_left):
+        _need_gpu("dwconv1d", x, w)
+        x, w = x.contiguous(), w.contiguous()
+        B, C, T = x.shape
+        k = w.shape[1]
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().ign_dwconv1d_fwd(_ptr(x), _ptr(w), _ptr(y), B, C, T, k, int(pad_left), 0, _stream()),
+                   "ign_dwconv1d_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.pl = int(pad_left)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        B, C, T = x.shape
+        k = w.shape[1]
+        gy = gy.contiguous()
+        L = _lib.lib()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _lib.check(L.ign_dwconv1d_fwd(_ptr(gy), _ptr(w), _ptr(gx), B, C, T, k, k - 1 - ctx.pl, 1, _stream()),
+                       "ign_dwconv1d_fwd(flip)")
+        if ctx.needs_input_grad[1]:
+            ws = torch.empty(L.ign_dwconv1d_bwd_weight_workspace_bytes(B, C, k) // 4, device=x.device, dtype=torch.float32)
+            gw = torch.empty_like(w)
+            _lib.check(L.ign_dwconv1d_bwd_weight(_ptr(x), _ptr(gy), _ptr(gw), _ptr(ws), B, C, T, k, ctx.pl, _stream()),
+                       "ign_dwconv1d_bwd_weight")
+        return gx, gw, None
+
+
+def dwconv1d(x, w, pad_left):
+    return DwConv1dFn.apply(x, w, pad_left)

@@ -58,7 +58,67 @@ class EEGcnn(nn.Module):
         self.block2_pool = nn.AvgPool2d((1, P2))
         self.block2_drop = nn.Dropout(p=dropoutRate)
 
+    @staticmethod
+    def _bn_apply(bn, h):
+        """BatchNorm over (B, T) per channel of a (B, C, T) tensor with the BatchNorm2d module's parameters/buffers."""
+        if bn.training and bn.track_running_stats:
+            bn.num_batches_tracked.add_(1)
+        return F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training or not bn.track_running_stats,
+                            bn.momentum, bn.eps)
+
+    @staticmethod
+    def _shifted_sums(x, k, pl):
+        """S[j] = sum_{b,c,t} xpad[b,c,t+j]: total minus the samples a tap at offset j - pl never sees (zero padding)."""
+        T = x.shape[-1]
+        total = x.sum()
+        pr = k - 1 - pl
+        head = x[..., :pr].sum(dim=(0, 1)).cumsum(0) if pr > 0 else x.new_zeros(0)        # first o samples, o = 1..pr
+        tail = x[..., T - pl:].sum(dim=(0, 1)).flip(0).cumsum(0) if pl > 0 else x.new_zeros(0)   # last o samples
+        left = total - tail.flip(0)            # taps j = 0 .. pl-1  (offset j - pl < 0: the last pl - j samples fall outside)
+        right = total - head                   # taps j = pl+1 .. k-1
+        return torch.cat([left, total.reshape(1), right])
+
     def forward(self, x):
+        """(B, C, T) -> (B, F2, T / (P1*P2)).  GPU path: block 1 is evaluated as
+        y2 = a_f * (w1[f] (*) (W2 x)) + b_f * rowsum(W2)  (see csrc/ign_eegcnn.hip), block 2 as a depthwise HIP convolution +
+        a 64x64 channel GEMM; BatchNorm-1's batch variance comes from ign_conv1_sumsq_* so the (B,F1,C,T) tensor of the
+        reference (eegcnn.py:90-91) is never formed."""
+        if not x.is_cuda or torch.is_autocast_enabled():
+            return self._forward_reference_ops(x)
+        B, C, T = x.shape
+        bn1 = self.block1_bn1
+        w1 = self.block1_conv1.weight.reshape(self.block1_conv1.weight.shape[0], -1)          # (F1, k1)
+        w2 = self.block1_depthwise.weight.reshape(self.block1_depthwise.weight.shape[0], C)    # (F1*D, C)
+        F1, k1 = w1.shape
+        D = w2.shape[0] // F1
+        pl1 = (k1 - 1) // 2
+        x = x.contiguous()
+        if bn1.training or not bn1.track_running_stats:
+            n = B * C * T
+            mu1 = (w1 @ self._shifted_sums(x, k1, pl1)) / n
+            var1 = ops.conv1_sumsq(x.view(B * C, T), w1, mu1, pl1) / n
+            if bn1.track_running_stats:
+                with torch.no_grad():
+                    bn1.num_batches_tracked.add_(1)
+                    m = bn1.momentum
+                    bn1.running_mean.mul_(1 - m).add_(mu1.detach(), alpha=m)
+                    bn1.running_var.mul_(1 - m).add_(var1.detach() * (n / (n - 1)), alpha=m)
+        else:
+            mu1, var1 = bn1.running_mean, bn1.running_var
+        a1 = bn1.weight * torch.rsqrt(var1 + bn1.eps)
+        b1 = bn1.bias - a1 * mu1
+        u = torch.einsum('oc,bct->bot', w2, x)                                                 # channel contraction first
+        v = ops.dwconv1d(u, w1.repeat_interleave(D, dim=0), pl1)
+        y2 = v * a1.repeat_interleave(D).view(1, -1, 1) + (b1.repeat_interleave(D) * w2.sum(dim=1)).view(1, -1, 1)
+        h = F.avg_pool1d(F.elu(self._bn_apply(self.block1_bn2, y2)), self.block1_pool.kernel_size[1])
+        h = self.block1_drop(h)
+        w3 = self.block2_conv1.weight.reshape(self.block2_conv1.weight.shape[0], -1)           # (F1*D, k2)
+        g = ops.dwconv1d(h, w3, (w3.shape[1] - 1) // 2)
+        g = torch.einsum('oi,bit->bot', self.block2_conv2.weight.reshape(self.block2_conv2.weight.shape[0], -1), g)
+        g = F.avg_pool1d(F.elu(self._bn_apply(self.block2_bn, g)), self.block2_pool.kernel_size[1])
+        return self.block2_drop(g)
+
+    def _forward_reference_ops(self, x):
         x = x.unsqueeze(1)                                           # (B,1,C,T)
         x = self.block1_bn1(self.block1_conv1(x))
         x = self.block1_bn2(self.block1_depthwise(x))

@@ -148,3 +148,74 @@ def test_eegcnn_baseline_golden():
     np.testing.assert_allclose(oe.cpu().numpy(), g["eval_out"], rtol=3e-4, atol=3e-4)
     with pytest.raises(ValueError):
         m(x, torch.ones(4, 1000, device=dev))                # the reference's mask path cannot run (D9)
+
+
+@pytest.mark.parametrize("R,T,F1,k1", [(12, 100, 8, 125), (7, 333, 8, 25), (5, 1000, 8, 125), (6, 64, 3, 8), (4, 50, 11, 5)])
+def test_conv1_sumsq_vs_torch(R, T, F1, k1):
+    """sum (w1 (*) x - mu)^2 and its gradient, against autograd through F.conv1d in float64."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    g = torch.Generator().manual_seed(R * 31 + k1)
+    x = (torch.randn(R, T, generator=g) * 1.5 + 0.3).to(dev)
+    w = (torch.randn(F1, k1, generator=g) * 0.2).to(dev).requires_grad_(True)
+    pl = (k1 - 1) // 2
+    xd, wd = x.double().cpu(), w.detach().double().cpu().requires_grad_(True)
+    y = F.conv1d(F.pad(xd.unsqueeze(1), (pl, k1 - 1 - pl)), wd.unsqueeze(1))          # (R,F1,T)
+    mu = y.mean(dim=(0, 2))
+    m2_ref = ((y - mu.view(1, -1, 1)) ** 2).sum(dim=(0, 2))
+    cot = torch.randn(F1, generator=g).double()
+    (m2_ref * cot).sum().backward()
+    m2 = ops.conv1_sumsq(x, w, mu.detach().float().to(dev), pl)
+    (m2 * cot.float().to(dev)).sum().backward()
+    assert _rel(m2, m2_ref) < 2e-5
+    assert _rel(w.grad, wd.grad) < 1e-4        # (the reference grad includes d/dmu = 0 exactly: mu is the batch mean)
+
+
+@pytest.mark.parametrize("B,C,T,k", [(3, 64, 500, 25), (2, 64, 1000, 125), (2, 5, 37, 4), (1, 3, 16, 16)])
+def test_dwconv1d_vs_torch(B, C, T, k):
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    g = torch.Generator().manual_seed(T + k)
+    x = torch.randn(B, C, T, generator=g).to(dev).requires_grad_(True)
+    w = torch.randn(C, k, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(B, C, T, generator=g)
+    pl = (k - 1) // 2
+    y = ops.dwconv1d(x, w, pl)
+    (y * go.to(dev)).sum().backward()
+    xd, wd = x.detach().double().cpu().requires_grad_(True), w.detach().double().cpu().requires_grad_(True)
+    yr = F.conv1d(F.pad(xd, (pl, k - 1 - pl)), wd.unsqueeze(1), groups=C)
+    (yr * go.double()).sum().backward()
+    assert _rel(y, yr) < 1e-5 and _rel(x.grad, xd.grad) < 1e-5 and _rel(w.grad, wd.grad) < 2e-5
+
+
+def test_eegcnn_block_matches_reference_ops_in_eval_and_train():
+    """The algebraic restructuring of block 1/2 against the layer-by-layer evaluation of the same module (torch ops),
+    including BatchNorm running statistics."""
+    dev = _dev()
+    import copy
+    import speech_imagery_eeg_amd  # noqa
+    from models.eegcnn import EEGcnn
+    torch.manual_seed(0)
+    m = EEGcnn(Chans=20, kernLength1=31, kernLength2=8, F1=4, D=3, F2=12, P1=2, P2=5, dropoutRate=0.0).to(dev)
+    with torch.no_grad():
+        for bn in (m.block1_bn1, m.block1_bn2, m.block2_bn):
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    ref = copy.deepcopy(m)
+    x = torch.randn(6, 20, 200, device=dev) * 2 + 0.5
+    for mode in (True, False):
+        m.train(mode); ref.train(mode)
+        a = m(x)
+        b = ref._forward_reference_ops(x)
+        assert _rel(a, b) < 2e-4, f"train={mode}"
+        if mode:
+            ga = torch.autograd.grad(a.square().sum(), [p for p in m.parameters()])
+            gb = torch.autograd.grad(b.square().sum(), [p for p in ref.parameters()])
+            for (n, _), u, v in zip(m.named_parameters(), ga, gb):
+                sc = float(v.abs().max())
+                if sc < 1e-4 * float(max(t.abs().max() for t in gb)):
+                    continue                      # zero-gradient parameters (bias removed by the next BatchNorm)
+                assert float((u - v).abs().max()) < 2e-3 * sc, n
+            for k in m.state_dict():
+                assert _rel(m.state_dict()[k].float(), ref.state_dict()[k].float()) < 2e-4, k
