@@ -325,7 +325,7 @@ static int conv1_check(const char* who, const void* x, const void* w1, const voi
 }
 
 static int conv1_blocks(int rows, int* rows_per_block) {
-    int rpb = (rows + 4095) / 4096;                  // ~4096 blocks: fills 256 CUs with a short tail
+    int rpb = (rows + 2047) / 2048;                  // ~2048 blocks: fills 256 CUs with a short tail
     if (rpb < 1) rpb = 1;
     *rows_per_block = rpb;
     return (rows + rpb - 1) / rpb;

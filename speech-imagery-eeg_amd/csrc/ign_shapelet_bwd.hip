@@ -22,7 +22,33 @@ __global__ void __launch_bounds__(256) reduce_parts_kernel(const float* __restri
     out[i] = s;
 }
 
+// Many partials, few outputs (EEG-CNN statistics: 4096 partials of 8..1000 values): 16 outputs x 16 slices of the
+// partials per block; each slice is summed in ascending order and the 16 slice sums are combined in fixed order.
+__global__ void __launch_bounds__(256) reduce_parts_sliced_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                  int nparts, size_t n) {
+    __shared__ float sm[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + o;
+    const int per = (nparts + 15) / 16;
+    const int p0 = sl * per, p1 = min(nparts, p0 + per);
+    float s = 0.f;
+    if (i < n)
+        for (int p = p0; p < p1; ++p) s += part[(size_t)p * n + i];
+    sm[sl][o] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && (size_t)blockIdx.x * 16 + threadIdx.x < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sm[q][threadIdx.x];
+        out[(size_t)blockIdx.x * 16 + threadIdx.x] = t;
+    }
+}
+
 void ign_launch_reduce_parts(const float* part, float* out, int nparts, size_t n, hipStream_t s) {
+    if (nparts > 128) {
+        hipLaunchKernelGGL(reduce_parts_sliced_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, part, out, nparts, n);
+        return;
+    }
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(blocks), dim3(256), 0, s, part, out, nparts, n);
 }
