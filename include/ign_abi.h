@@ -56,10 +56,13 @@ int ign_instnorm_fwd(const float* x_btc, float* xn_bct, float* xt_bct, int B, in
  *   tstar    (B,K,C) int32  arg-max_t p  (RBF) / arg-min_t d (LTS); first index on ties (torch.argmax)
  *   zmu      (B,K,C,2)      {Z, mu}: RBF Z=sum_t exp(p_t), mu=sum_t softmax_t(p) p_t ;
  *                           LTS Z=sum_t exp(-(d_t-dmin)), mu=sum_t softmin_t(d) d_t      (for backward)
- *   d_save   (B,C,K,Tw)     every window distance, kept for the backward (NULL: not saved)              */
+ *   d_save   (B,C,K,Tw)     every window distance, kept for the backward (NULL: not saved)
+ *   xstat_save (B,C,Tw)     cosine / pearson only (else NULL): |x_win| resp. sqrt(sum (x_win-mean)^2), for the backward
+ * IGN_DIST_PEARS expects w_kcl already CENTRED over its last axis (w - mean_j w; the caller's autograd projects the
+ * gradient back), so that <x_win, w_c> equals the reference's centred numerator (Shapelet.py:11-19).               */
 int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const float* thr_kc,
                      float* p_out, float* dmin_out, int ld, int col0,
-                     int32_t* tstar, float* zmu, float* d_save,
+                     int32_t* tstar, float* zmu, float* d_save, float* xstat_save,
                      int B, int C, int T, int K, int L, int stride, float eps, int mode, void* stream);
 
 /* Backward of the above w.r.t. the shapelets (autograd of Shapelet.py:60-84 / :96-111; closed form in
@@ -72,6 +75,7 @@ size_t ign_shapelet_bwd_workspace_bytes(int B, int C, int T, int K, int L, int s
 int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const float* g_out, const float* p_out,
                      const float* dmin_out, int ld, int col0,
                      const int32_t* tstar, const float* zmu, const float* d_save,
+                     const float* xstat_save, const float* wnorm_kc /* (K,C) sqrt(sum_j w^2): cosine / pearson, else NULL */,
                      float* gw_kcl, void* workspace,
                      int B, int C, int T, int K, int L, int stride, float eps, int mode, void* stream);
 

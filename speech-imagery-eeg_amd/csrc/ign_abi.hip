@@ -84,16 +84,16 @@ extern "C" int ign_timing_read(const char* label, double* total_ms, long long* l
 extern "C" int ign_abi_version(void) { return IGN_ABI_VERSION; }
 extern "C" const char* ign_last_error(void) { return g_err; }
 
-extern shp_fwd_launch_t ign_fwd_table_p0[4][2][3];
-extern shp_fwd_launch_t ign_fwd_table_p1[4][2][3];
-extern shp_fwd_launch_t ign_fwd_table_p2[4][2][3];
-extern shp_fwd_launch_t ign_fwd_table_p3[4][2][3];
+extern shp_fwd_launch_t ign_fwd_table_p0[4][4][3];
+extern shp_fwd_launch_t ign_fwd_table_p1[4][4][3];
+extern shp_fwd_launch_t ign_fwd_table_p2[4][4][3];
+extern shp_fwd_launch_t ign_fwd_table_p3[4][4][3];
 
 shp_fwd_launch_t ign_get_fwd_launcher(int dist, int TT, int KT) {
-    if (dist < 0 || dist > 1 || TT < 1 || TT > 16) return nullptr;
+    if (dist < 0 || dist > 3 || TT < 1 || TT > 16) return nullptr;
     const int ki = KT == 1 ? 0 : KT == 2 ? 1 : KT == 5 ? 2 : -1;
     if (ki < 0) return nullptr;
-    shp_fwd_launch_t (*tabs[4])[2][3] = {ign_fwd_table_p0, ign_fwd_table_p1, ign_fwd_table_p2, ign_fwd_table_p3};
+    shp_fwd_launch_t (*tabs[4])[4][3] = {ign_fwd_table_p0, ign_fwd_table_p1, ign_fwd_table_p2, ign_fwd_table_p3};
     return tabs[(TT - 1) / 4][(TT - 1) % 4][dist][ki];
 }
 
@@ -103,10 +103,6 @@ static int split_mode(int mode, int* dist, int* gate, const char* who) {
     if ((mode & ~0x1f) != 0 || *dist > IGN_DIST_PEARS) {
         ign_set_error("%s: unknown mode 0x%x", who, mode);
         return IGN_E_ARG;
-    }
-    if (*dist != IGN_DIST_L1 && *dist != IGN_DIST_MSE) {
-        ign_set_error("%s: distance %d (cosine/pearson) is not implemented in this library version", who, *dist);
-        return IGN_E_UNSUP;
     }
     return 0;
 }
@@ -121,8 +117,9 @@ static int check_dims(const char* who, int B, int C, int T, int K, int L, int st
 
 // ------------------------------------------------------------------------------------------ forward
 extern "C" int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const float* thr_kc, float* p_out,
-                                float* dmin_out, int ld, int col0, int32_t* tstar, float* zmu, float* d_save, int B,
-                                int C, int T, int K, int L, int stride, float eps, int mode, void* stream) {
+                                float* dmin_out, int ld, int col0, int32_t* tstar, float* zmu, float* d_save,
+                                float* xstat_save, int B, int C, int T, int K, int L, int stride, float eps, int mode,
+                                void* stream) {
     static const char* who = "ign_shapelet_fwd";
     int dist, gate, rc;
     if ((rc = split_mode(mode, &dist, &gate, who))) return rc;
@@ -152,6 +149,7 @@ extern "C" int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const f
     ShpFwdArgs a;
     a.xn = xn_bct; a.w = w_kcl; a.thr = thr_kc; a.p_out = p_out; a.dmin_out = dmin_out; a.tstar = tstar; a.zmu = zmu;
     a.d = d_save;
+    a.xstat = (dist >= DIST_COS) ? xstat_save : nullptr;
     a.B = B; a.C = C; a.T = T; a.K = K; a.L = L; a.Tw = Tw; a.stride = stride; a.ld = ld; a.col0 = col0;
     a.npass = npass; a.xs_len = xs_len; a.gate = gate; a.eps = eps; a.invL = 1.0f / (float)L;
     const int nbg = (B + wpb - 1) / wpb;
@@ -251,8 +249,9 @@ extern "C" size_t ign_shapelet_bwd_workspace_bytes(int B, int C, int T, int K, i
 
 extern "C" int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const float* g_out, const float* p_out,
                                 const float* dmin_out, int ld, int col0, const int32_t* tstar, const float* zmu,
-                                const float* d_save, float* gw_kcl, void* workspace, int B, int C, int T, int K,
-                                int L, int stride, float eps, int mode, void* stream) {
+                                const float* d_save, const float* xstat_save, const float* wnorm_kc, float* gw_kcl,
+                                void* workspace, int B, int C, int T, int K, int L, int stride, float eps, int mode,
+                                void* stream) {
     static const char* who = "ign_shapelet_bwd";
     int dist, gate, rc;
     if ((rc = split_mode(mode, &dist, &gate, who))) return rc;
@@ -270,6 +269,10 @@ extern "C" int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const f
         ign_set_error("%s: row pitch ld=%d too small for col0=%d + K*C=%d", who, ld, col0, K * C);
         return IGN_E_ARG;
     }
+    if (dist >= DIST_COS && (!xstat_save || !wnorm_kc)) {
+        ign_set_error("%s: cosine / pearson need xstat_save (from the forward) and wnorm_kc", who);
+        return IGN_E_ARG;
+    }
     const int Tw = T - L + 1;
     BwdPlan p;
     if ((rc = plan_bwd(B, C, T, K, L, Tw, &p))) {
@@ -283,6 +286,8 @@ extern "C" int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const f
     }
     ShpBwdArgs a;
     a.xn = xn_bct; a.w = w_kcl; a.g = g_out; a.p = p_out; a.dmin = dmin_out; a.tstar = tstar; a.zmu = zmu; a.d = d_save;
+    a.xstat = xstat_save; a.wnorm = wnorm_kc;
+    a.xstat = xstat_save; a.wnorm = wnorm_kc;
     a.part = (float*)workspace;
     a.B = B; a.C = C; a.T = T; a.K = K; a.L = L; a.Tw = Tw; a.ld = ld; a.col0 = col0;
     a.nbs = p.nbs; a.kb = p.kb; a.cpk = p.cpk; a.tc = p.tc; a.xs_len = p.xs_len; a.gate = gate;

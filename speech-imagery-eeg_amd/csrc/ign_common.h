@@ -18,7 +18,7 @@ struct IgnScopedTimer {
     const char* label; hipStream_t stream; hipEvent_t e0, e1; bool on;
 };
 
-enum { DIST_L1 = 0, DIST_MSE = 1 };
+enum { DIST_L1 = 0, DIST_MSE = 1, DIST_COS = 2, DIST_PEARSON = 3 };
 enum { GATE_RBF = 0, GATE_LTS = 1 };
 
 // ---------------------------------------------------------------- forward
@@ -31,6 +31,7 @@ struct ShpFwdArgs {
     int32_t* tstar;       // (B,K,C)
     float* zmu;           // (B,K,C,2)
     float* d;             // (B,C,K,Tw) or null
+    float* xstat;         // (B,C,Tw) or null: ||x_win|| (cosine) / sqrt(sum (x_win - mean)^2) (pearson), saved for the backward
     int B, C, T, K, L, Tw, stride, ld, col0;
     int k0;               // first shapelet of this launch (blockIdx.y adds KT each)
     int npass;            // passes of 64*TT windows per row
@@ -53,6 +54,8 @@ struct ShpBwdArgs {
     const int32_t* tstar; // (B,K,C)
     const float* zmu;     // (B,K,C,2)
     const float* d;       // (B,C,K,Tw)
+    const float* xstat;   // (B,C,Tw)  window norms (cosine / pearson)
+    const float* wnorm;   // (K,C)     shapelet norms sqrt(sum_j w^2) (cosine / pearson)
     float* part;          // (nbs,K,C,L) partial sums over batch slices
     int B, C, T, K, L, Tw, ld, col0;
     int nbs;              // batch slices (gridDim.y)

@@ -64,6 +64,18 @@ __device__ __forceinline__ void bwd_mse_step(float (&acc)[JJ], const float (&wa)
 }
 
 template <int JJ>
+__device__ __forceinline__ void bwd_dot_step(float (&acc)[JJ], const float (&wa)[JJ], const float (&wb)[JJ],
+                                             const float (&A)[JJ]) {
+#pragma unroll
+    for (int t = 0; t < JJ; ++t)
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) {
+            const float xv = (t + jj) < JJ ? wa[(t + jj) % JJ] : wb[(t + jj) % JJ];
+            acc[jj] = fmaf(A[t], xv, acc[jj]);
+        }
+}
+
+template <int JJ>
 __device__ __forceinline__ void lds_load(float (&dst)[JJ], const float* p) {
 #pragma unroll
     for (int i = 0; i < JJ; i += 4) {
@@ -124,6 +136,8 @@ __global__ void __launch_bounds__(512, 2) shp_bwd_kernel(const ShpBwdArgs a) {
                     dmin = a.dmin[col];
                 }
                 const float* drow = a.d + (((size_t)b * a.C + c) * a.K + k) * a.Tw;
+                const float* xst = (DIST >= DIST_COS) ? a.xstat + ((size_t)b * a.C + c) * a.Tw : nullptr;
+                const float wn = (DIST >= DIST_COS) ? a.wnorm[(size_t)k * a.C + c] : 0.f;
                 float* Ak = As + k2 * a.tc;
                 float part = 0.f;
                 for (int tt = tid; tt < a.tc; tt += nthr) {
@@ -142,12 +156,25 @@ __global__ void __launch_bounds__(512, 2) shp_bwd_kernel(const ShpBwdArgs a) {
                             const float s = __expf(dmin - dv) * invZ;
                             dldd = gm * ((t == ts ? 1.f : 0.f) + s * (mu - dv));
                         }
-                        A = (DIST == DIST_L1) ? -dldd * a.invL : -2.f * dldd * a.invL;
+                        if (DIST == DIST_L1) {
+                            A = -dldd * a.invL;
+                            part += A;
+                        } else if (DIST == DIST_MSE) {
+                            A = -2.f * dldd * a.invL;
+                        } else if (DIST == DIST_COS) {
+                            // d = 1 - <x,w>/(max(|x|,e) max(|w|,e)):  dd/dw_j = -x_j/den + cos * w_j / |w|^2
+                            A = -dldd / (fmaxf(xst[t], 1e-8f) * fmaxf(wn, 1e-8f));
+                            if (wn >= 1e-8f) part += dldd * (1.f - dv) / (wn * wn);
+                        } else {
+                            // d = 1 - <x,wc>/(sx sw + e):  dd/dwc_j = -x_j/den + rho * sx * wc_j / (sw den)
+                            const float den = xst[t] * wn + 1e-8f;
+                            A = -dldd / den;
+                            if (wn > 0.f) part += dldd * (1.f - dv) * xst[t] / (wn * den);
+                        }
                     }
                     Ak[tt] = A;
-                    part += A;
                 }
-                if (DIST == DIST_L1) {
+                if (DIST != DIST_MSE) {
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
                     if (lane == 0) Sp[k2 * 8 + wave] = part;
@@ -155,7 +182,7 @@ __global__ void __launch_bounds__(512, 2) shp_bwd_kernel(const ShpBwdArgs a) {
             }
             __syncthreads();
 
-            if (DIST == DIST_L1)
+            if (DIST != DIST_MSE)
                 for (int wv = 0; wv < nwave; ++wv) ssum += Sp[kl * 8 + wv];
             const float* Ak = As + kl * a.tc;
             const float* xl = xs + jbase;
@@ -164,12 +191,14 @@ __global__ void __launch_bounds__(512, 2) shp_bwd_kernel(const ShpBwdArgs a) {
             for (int t = 0; t < a.tc; t += 2 * JJ) {         // tc is a multiple of 2*JJ: two ping-pong steps
                 lds_load<JJ>(Wb, xl + t + JJ);
                 lds_load<JJ>(A, Ak + t);
-                if (DIST == DIST_L1) bwd_l1_step<JJ>(acc, Wa, Wb, wreg, A);
-                else                 bwd_mse_step<JJ>(acc, Wa, Wb, wreg, A);
+                if (DIST == DIST_L1)       bwd_l1_step<JJ>(acc, Wa, Wb, wreg, A);
+                else if (DIST == DIST_MSE) bwd_mse_step<JJ>(acc, Wa, Wb, wreg, A);
+                else                       bwd_dot_step<JJ>(acc, Wa, Wb, A);
                 lds_load<JJ>(Wa, xl + t + 2 * JJ);
                 lds_load<JJ>(A, Ak + t + JJ);
-                if (DIST == DIST_L1) bwd_l1_step<JJ>(acc, Wb, Wa, wreg, A);
-                else                 bwd_mse_step<JJ>(acc, Wb, Wa, wreg, A);
+                if (DIST == DIST_L1)       bwd_l1_step<JJ>(acc, Wb, Wa, wreg, A);
+                else if (DIST == DIST_MSE) bwd_mse_step<JJ>(acc, Wb, Wa, wreg, A);
+                else                       bwd_dot_step<JJ>(acc, Wb, Wa, A);
             }
         }
     }
@@ -178,7 +207,9 @@ __global__ void __launch_bounds__(512, 2) shp_bwd_kernel(const ShpBwdArgs a) {
         float* out = a.part + (((size_t)bs * a.K + (kbase + kl)) * a.C + c) * a.L;
 #pragma unroll
         for (int jj = 0; jj < JJ; ++jj)
-            if (jbase + jj < a.L) out[jbase + jj] = (DIST == DIST_L1) ? 2.f * acc[jj] - ssum : acc[jj];
+            if (jbase + jj < a.L)
+                out[jbase + jj] = (DIST == DIST_L1) ? 2.f * acc[jj] - ssum
+                                : (DIST == DIST_MSE) ? acc[jj] : acc[jj] + wreg[jj] * ssum;
     }
 }
 

@@ -8,6 +8,12 @@ shp_bwd_launch_t ign_get_bwd_launcher(int dist, int JJ) {
     } else if (dist == DIST_MSE) {
         if (JJ == 4) return shp_bwd_launch<4, DIST_MSE>;
         if (JJ == 8) return shp_bwd_launch<8, DIST_MSE>;
+    } else if (dist == DIST_COS) {
+        if (JJ == 4) return shp_bwd_launch<4, DIST_COS>;
+        if (JJ == 8) return shp_bwd_launch<8, DIST_COS>;
+    } else if (dist == DIST_PEARSON) {
+        if (JJ == 4) return shp_bwd_launch<4, DIST_PEARSON>;
+        if (JJ == 8) return shp_bwd_launch<8, DIST_PEARSON>;
     }
     return nullptr;
 }

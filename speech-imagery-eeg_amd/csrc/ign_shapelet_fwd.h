@@ -73,6 +73,15 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
         float xw[TT + J - 1];
 #pragma unroll
         for (int i = 0; i < TT - 1; ++i) xw[i] = xl[i];
+        // cosine / pearson (Shapelet.py:64-69): the distance is 1 - <x_win, w> / (norms); the window norms are
+        // accumulated beside the dot products (1/KT extra work), the shapelet norms from the wave-uniform weights.
+        float xsq[DIST >= DIST_COS ? TT : 1], xsm[DIST == DIST_PEARSON ? TT : 1], wn2[DIST >= DIST_COS ? KT : 1];
+        if (DIST >= DIST_COS) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) { xsq[t] = 0.f; if (DIST == DIST_PEARSON) xsm[t] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < KT; ++k) wn2[k] = 0.f;
+        }
 
         int j0 = 0;
         for (; j0 + J <= L; j0 += J) {
@@ -83,11 +92,23 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
 #pragma unroll
                 for (int k = 0; k < KT; ++k) {
                     const float wv = wk[k * wks + j0 + jj];          // wave-uniform -> s_load / SGPR operand
+                    if (DIST >= DIST_COS) wn2[k] = fmaf(wv, wv, wn2[k]);
 #pragma unroll
                     for (int t = 0; t < TT; ++t) {
-                        const float df = xw[t + jj] - wv;
-                        if (DIST == DIST_L1) acc[k][t] += fabsf(df);
-                        else                 acc[k][t] = fmaf(df, df, acc[k][t]);
+                        if (DIST >= DIST_COS) {
+                            acc[k][t] = fmaf(xw[t + jj], wv, acc[k][t]);         // sliding dot product
+                        } else {
+                            const float df = xw[t + jj] - wv;
+                            if (DIST == DIST_L1) acc[k][t] += fabsf(df);
+                            else                 acc[k][t] = fmaf(df, df, acc[k][t]);
+                        }
+                    }
+                }
+                if (DIST >= DIST_COS) {
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) {
+                        xsq[t] = fmaf(xw[t + jj], xw[t + jj], xsq[t]);
+                        if (DIST == DIST_PEARSON) xsm[t] += xw[t + jj];
                     }
                 }
             }
@@ -99,11 +120,23 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const float wv = wk[k * wks + j0];
+                if (DIST >= DIST_COS) wn2[k] = fmaf(wv, wv, wn2[k]);
 #pragma unroll
                 for (int t = 0; t < TT; ++t) {
-                    const float df = xw[t] - wv;
-                    if (DIST == DIST_L1) acc[k][t] += fabsf(df);
-                    else                 acc[k][t] = fmaf(df, df, acc[k][t]);
+                    if (DIST >= DIST_COS) {
+                        acc[k][t] = fmaf(xw[t], wv, acc[k][t]);
+                    } else {
+                        const float df = xw[t] - wv;
+                        if (DIST == DIST_L1) acc[k][t] += fabsf(df);
+                        else                 acc[k][t] = fmaf(df, df, acc[k][t]);
+                    }
+                }
+            }
+            if (DIST >= DIST_COS) {
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    xsq[t] = fmaf(xw[t], xw[t], xsq[t]);
+                    if (DIST == DIST_PEARSON) xsm[t] += xw[t];
                 }
             }
 #pragma unroll
@@ -130,8 +163,23 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
         for (int k = 0; k < KT; ++k) {
             float* drow = a.d ? a.d + (((size_t)b * a.C + c) * a.K + (k0 + k)) * a.Tw : nullptr;
             float dv[TT];
+            if (DIST >= DIST_COS) {
+                // cosine:  d = 1 - dot / (max(|x|,1e-8) max(|w|,1e-8))              (F.cosine_similarity)
+                // pearson: d = 1 - dot_c / (sqrt(vx vw) + 1e-8), w already centred by the caller, vx = sum x^2 - (sum x)^2/L
+                const float wn = sqrtf(wn2[k]);
 #pragma unroll
-            for (int t = 0; t < TT; ++t) dv[t] = (t < nvalid) ? acc[k][t] * a.invL : 1e18f;
+                for (int t = 0; t < TT; ++t) {
+                    float xn;
+                    if (DIST == DIST_COS) xn = sqrtf(xsq[t]);
+                    else                  xn = sqrtf(fmaxf(xsq[t] - xsm[t] * xsm[t] * a.invL, 0.f));
+                    const float den = (DIST == DIST_COS) ? fmaxf(xn, 1e-8f) * fmaxf(wn, 1e-8f) : xn * wn + 1e-8f;
+                    dv[t] = (t < nvalid) ? 1.f - acc[k][t] / den : 1e18f;
+                    if (k == 0 && a.xstat && row_ok && t < nvalid) a.xstat[((size_t)b * a.C + c) * a.Tw + tl + t] = xn;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < TT; ++t) dv[t] = (t < nvalid) ? acc[k][t] * a.invL : 1e18f;
+            }
             if (a.gate == GATE_RBF) {
 #pragma unroll
                 for (int t = 0; t < TT; ++t) {

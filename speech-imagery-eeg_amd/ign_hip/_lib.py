@@ -20,7 +20,7 @@ SIGNATURES = {
     "ign_abi_version": (ci, []),
     "ign_last_error": (ctypes.c_char_p, []),
     "ign_instnorm_fwd": (ci, [vp, vp, vp, ci, ci, ci, cf, vp]),
-    "ign_shapelet_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),
+    "ign_shapelet_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),
     "ign_shapelet_bwd_workspace_bytes": (sz, [ci, ci, ci, ci, ci, ci, ci]),
     "ign_attn_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
     "ign_attn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
@@ -37,7 +37,7 @@ SIGNATURES = {
     "ign_dwconv1d_bwd_weight": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ign_timing_enable": (ci, [ci]),
     "ign_timing_read": (ci, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
-    "ign_shapelet_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),
+    "ign_shapelet_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),
 }
 
 

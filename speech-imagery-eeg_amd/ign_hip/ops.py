@@ -71,10 +71,12 @@ class ShapeletBankFn(torch.autograd.Function):
             tstar = torch.empty(B, K, C, device=xn.device, dtype=torch.int32)
             zmu = torch.empty(B, K, C, 2, device=xn.device, dtype=torch.float32)
             dsave = torch.empty(B, C, K, Tw, device=xn.device, dtype=torch.float32) if need_grad else None
+            xstat = torch.empty(B, C, Tw, device=xn.device, dtype=torch.float32) \
+                if (need_grad and (mode & 0xf) >= DIST_COS) else None
             _lib.check(L.ign_shapelet_fwd(_ptr(xn), _ptr(w), _ptr(thrs[g]), _ptr(P), _ptr(D), ld, col0,
-                                          _ptr(tstar), _ptr(zmu), _ptr(dsave), B, C, T, K, Lg, stride,
+                                          _ptr(tstar), _ptr(zmu), _ptr(dsave), _ptr(xstat), B, C, T, K, Lg, stride,
                                           float(eps), int(mode), _stream()), "ign_shapelet_fwd")
-            saved.append((tstar, zmu, dsave, col0, stride))
+            saved.append((tstar, zmu, dsave, col0, stride, xstat))
             col0 += K * C
         ctx.mark_non_differentiable(D)
         ctx.meta = (float(eps), int(mode), n_groups, saved, need_grad)
@@ -96,14 +98,15 @@ class ShapeletBankFn(torch.autograd.Function):
         grads_w, grads_t = [], []
         for g, w in enumerate(ws):
             K, _, Lg = w.shape
-            tstar, zmu, dsave, col0, stride = saved[g]
+            tstar, zmu, dsave, col0, stride, xstat = saved[g]
+            wnorm = w.square().sum(dim=-1).sqrt().contiguous() if (mode & 0xf) >= DIST_COS else None
             nbytes = L.ign_shapelet_bwd_workspace_bytes(B, C, T, K, Lg, stride, mode)
             if nbytes == 0:
                 raise _lib.IgnError(f"shapelet backward: no launch plan for K={K} L={Lg} stride={stride}")
             work = torch.empty(nbytes // 4, device=xn.device, dtype=torch.float32)
             gw = torch.empty_like(w)
             _lib.check(L.ign_shapelet_bwd(_ptr(xn), _ptr(w), _ptr(gP), _ptr(P), _ptr(D), ld, col0,
-                                          _ptr(tstar), _ptr(zmu), _ptr(dsave), _ptr(gw), _ptr(work),
+                                          _ptr(tstar), _ptr(zmu), _ptr(dsave), _ptr(xstat), _ptr(wnorm), _ptr(gw), _ptr(work),
                                           B, C, T, K, Lg, stride, eps, mode, _stream()), "ign_shapelet_bwd")
             grads_w.append(gw)
             if mode & GATE_LTS:       # dP/dthr = sigma'(thr - m) = P(1-P);  IGN/model/Shapelet.py:109
@@ -114,6 +117,10 @@ class ShapeletBankFn(torch.autograd.Function):
 
 def shapelet_bank(xn, weights, eps, mode=DIST_L1 | GATE_RBF, strides=None, thresholds=None):
     G = len(weights)
+    if (mode & 0xf) == DIST_PEARSON:
+        # pearson_corrcoef centres both operands (Shapelet.py:11-19).  <x - mean x, w_c> == <x, w_c> for a centred w_c,
+        # so the kernel gets the centred shapelets and autograd projects the gradient back through this subtraction.
+        weights = [w - w.mean(dim=-1, keepdim=True) for w in weights]
     strides = strides or [1] * G
     params = list(weights) + (list(thresholds) if (mode & GATE_LTS) else [])
     return ShapeletBankFn.apply(xn, eps, mode, tuple(strides), G, *params)

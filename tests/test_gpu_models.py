@@ -211,3 +211,31 @@ def test_head_linear_gate_and_flat_adam_vs_torch():
     for (n, p), q in zip(net1.named_parameters(), net2.parameters()):
         assert float((p - q).abs().max()) < 1e-5, n
     assert all(k in net1.state_dict() for k in net2.state_dict())
+
+
+@pytest.mark.parametrize("dfunc,mode", [("cosine", 2), ("pearson", 3)])
+def test_sbm_cosine_pearson_vs_oracle(dfunc, mode):
+    """distance_func='cosine' / 'pearson' through the whole SBM (IGN/model/Shapelet.py:64-69) against the CPU oracle."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models.Shapelet import ShapeBottleneckModel
+    from oracle import ign_oracle as O
+    cfg = make_cfg(distance_func=dfunc, enc_in=5, seq_len=120, num_class=3)
+    torch.manual_seed(0)
+    ref = O.OracleSBM(cfg, [3, 3, 3], [0.1, 0.3, 0.6])
+    m = ShapeBottleneckModel(cfg, [3, 3, 3], [0.1, 0.3, 0.6])
+    m.load_state_dict(ref.state_dict())
+    m.to(dev)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 120, 5, generator=g)
+    y = torch.arange(6) % 3
+    o_r, i_r = ref(x)
+    (F.cross_entropy(o_r, y) + i_r.loss.mean()).backward()
+    o, i = m(x.to(dev))
+    (F.cross_entropy(o, y.to(dev)) + i.loss.mean()).backward()
+    _close(o, o_r.detach().numpy(), 2e-4)
+    _close(i.p, i_r.p.detach().numpy())
+    _close(i.d, i_r.d.detach().numpy())
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        scale = max(float(q.grad.abs().max()), 1e-7)
+        assert float((p.grad.cpu() - q.grad).abs().max()) <= 3e-4 * scale + 1e-8, n

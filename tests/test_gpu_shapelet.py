@@ -64,7 +64,7 @@ def test_instance_norm_matches_oracle():
         assert torch.equal(xt.cpu(), x.permute(0, 2, 1).contiguous())
 
 
-@pytest.mark.parametrize("name,mode", [("l1", 0), ("mse", 1)])
+@pytest.mark.parametrize("name,mode", [("l1", 0), ("mse", 1), ("cos", 2), ("pearson", 3)])
 def test_shapelet_golden_small(name, mode):
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
@@ -120,6 +120,10 @@ def test_shapelet_bm_groups_one_bank():
     (5, 3, 200, 7, 33, 0),         # K = 5 + 2 tiles, odd L (tail loop)
     (2, 4, 1300, 3, 10, 0),        # Tw = 1291 > 1024: two passes, K = 2 + 1 tiles
     (3, 5, 300, 4, 50, 1),         # MSE
+    (3, 5, 300, 5, 50, 2),         # cosine
+    (2, 122, 1000, 5, 200, 2),     # cosine, CHISCO shape
+    (3, 5, 300, 7, 33, 3),         # pearson, K = 5 + 2 tiles, odd L
+    (2, 16, 1000, 5, 500, 3),      # pearson, long shapelets
     (3, 5, 120, 6, 3, 0),          # minimum shapelet length
     (2, 3, 50, 2, 50, 0),          # L == T: a single window
 ])
@@ -212,7 +216,8 @@ def test_abi_argument_errors():
     x = torch.zeros(16, device=dev)
     pp = ctypes.c_void_p(x.data_ptr())
     assert L.ign_instnorm_fwd(None, pp, None, 1, 4, 4, 1e-8, None) == -1001
-    assert L.ign_shapelet_fwd(pp, pp, None, pp, pp, 4, 0, pp, pp, None, 1, 2, 8, 2, 9, 1, 1.0, 0, None) == -1001  # L > T
-    assert L.ign_shapelet_fwd(pp, pp, None, pp, pp, 4, 0, pp, pp, None, 1, 2, 8, 2, 3, 1, 1.0, 2, None) == -1002  # cosine
-    assert b"cosine" in L.ign_last_error()
+    assert L.ign_shapelet_fwd(pp, pp, None, pp, pp, 4, 0, pp, pp, None, None, 1, 2, 8, 2, 9, 1, 1.0, 0, None) == -1001  # L > T
+    assert L.ign_shapelet_fwd(pp, pp, None, pp, pp, 4, 0, pp, pp, None, None, 1, 2, 8, 2, 3, 1, 1.0, 7, None) == -1001  # mode
+    assert b"unknown mode" in L.ign_last_error()
+    assert L.ign_shapelet_fwd(pp, pp, None, pp, pp, 4, 0, pp, pp, None, None, 1, 2, 8, 2, 3, 1, 1.0, 0x10, None) == -1001  # LTS, no thr
     assert L.ign_shapelet_bwd_workspace_bytes(1, 2, 8, 2, 3, 2, 0) == 0
