@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const float* __restrict
 // Block = 4 waves x 32 keys; loops over query tiles.  Per (32 queries x 32 keys): S = Q K^T, dP = dO V^T,
 // P = exp(S - lse), dS = P (dP - delta) scale, dV^T += dO^T P, dK^T += Q^T dS.
 template <int E>
-__global__ void __launch_bounds__(256) attn_bwd_dkdv_kernel(const AttnArgs a) {
+__global__ void __launch_bounds__(256, 2) attn_bwd_dkdv_kernel(const AttnArgs a) {
     constexpr int EH = E / 2, ED = (E + 31) / 32, PITCH = E + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;                                   // [ATT_KT][PITCH]
