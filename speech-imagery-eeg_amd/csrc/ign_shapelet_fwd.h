@@ -58,8 +58,6 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
     // Row statistics of this lane (merged across lanes at the end).  They are NOT kept in registers across
     // the distance loop: rows longer than 64*TT windows (npass > 1, not the case for any T <= 1024+L)
     // park them in LDS between passes, so the hot loop's register budget is acc + window only.
-    float r_best[KT], r_dmin[KT], r_Z[KT], r_M[KT];
-    int r_idx[KT];
     float* park = smem + (blockDim.x >> 6) * a.xs_len + threadIdx.x;    // [5*KT][blockDim.x], npass > 1 only
 
     for (int pass = 0; pass < a.npass; ++pass) {
@@ -143,24 +141,26 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
             for (int i = 0; i < TT - 1; ++i) xw[i] = xw[i + 1];
         }
 
-        // ---- per-pass epilogue: d = mean, gate statistics
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            if (pass == 0) {
-                r_best[k] = -INFINITY; r_dmin[k] = INFINITY; r_Z[k] = 0.f; r_M[k] = 0.f; r_idx[k] = 0x7fffffff;
-            } else {
-                r_best[k] = park[(5 * k + 0) * blockDim.x]; r_dmin[k] = park[(5 * k + 1) * blockDim.x];
-                r_Z[k] = park[(5 * k + 2) * blockDim.x];    r_M[k] = park[(5 * k + 3) * blockDim.x];
-                r_idx[k] = __float_as_int(park[(5 * k + 4) * blockDim.x]);
-            }
-        }
-        // Branch-free statistics.  Window positions past the end of the row (only in the last lanes) get d = +BIG:
+        // ---- per-pass epilogue, one shapelet at a time so only ONE set of row statistics is live (the 128-VGPR budget
+        // of 4 waves/SIMD is otherwise exceeded and the spills showed up as 1 GB/step of scratch writes in WRITE_SIZE):
+        // d = mean -> gate statistics -> coalesced store of d -> (last pass) merge of the 64 lanes and outputs.
+        // Branch-free statistics: window positions past the end of the row (only in the last lanes) get d = +BIG, so
         // p = exp(-(eps BIG)^2) = 0 and exp(-(BIG - m)) = 0 never win the arg-max / arg-min and add nothing to M; the
         // RBF soft-max weight exp(p) of such a slot is exactly 1, which is subtracted from Z afterwards.
         const int nvalid = min(TT, max(0, a.Tw - tl));
         const bool lds_store = (a.npass == 1) && a.d;          // x row no longer needed: reuse its LDS as a transpose buffer
+        const bool last_pass = pass + 1 == a.npass;
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
+            float rb, rd, rZ, rM;
+            int ri;
+            if (pass == 0) {
+                rb = -INFINITY; rd = INFINITY; rZ = 0.f; rM = 0.f; ri = 0x7fffffff;
+            } else {
+                rb = park[(5 * k + 0) * blockDim.x]; rd = park[(5 * k + 1) * blockDim.x];
+                rZ = park[(5 * k + 2) * blockDim.x]; rM = park[(5 * k + 3) * blockDim.x];
+                ri = __float_as_int(park[(5 * k + 4) * blockDim.x]);
+            }
             float* drow = a.d ? a.d + (((size_t)b * a.C + c) * a.K + (k0 + k)) * a.Tw : nullptr;
             float dv[TT];
             if (DIST >= DIST_COS) {
@@ -186,39 +186,37 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
                     const float u = a.eps * dv[t];
                     const float p = __expf(-(u * u));
                     const float e = __expf(p);
-                    r_Z[k] += e;
-                    r_M[k] = fmaf(e, p, r_M[k]);
-                    if (p > r_best[k]) { r_best[k] = p; r_idx[k] = tl + t; }
-                    r_dmin[k] = fminf(r_dmin[k], dv[t]);
+                    rZ += e;
+                    rM = fmaf(e, p, rM);
+                    if (p > rb) { rb = p; ri = tl + t; }
+                    rd = fminf(rd, dv[t]);
                     __builtin_amdgcn_sched_barrier(0);      // keep the inlined exp bodies from interleaving (VGPR pressure)
                 }
-                r_Z[k] -= (float)(TT - nvalid);
+                rZ -= (float)(TT - nvalid);
             } else {                                  // LTS: soft-min over d, stabilised by the running min
                 float pmin = dv[0];
 #pragma unroll
                 for (int t = 1; t < TT; ++t) pmin = fminf(pmin, dv[t]);
-                // r_best holds -(running min) so the arg-min tie rule is "first index"
-                const float mold = r_dmin[k];
+                // rb holds -(running min) so the arg-min tie rule is "first index"
+                const float mold = rd;
                 const float mnew = fminf(mold, pmin);
                 const float sc = (mold < INFINITY) ? __expf(mnew - mold) : 0.f;
-                r_Z[k] *= sc; r_M[k] *= sc;
+                rZ *= sc; rM *= sc;
                 if (mnew < 1e17f) {
 #pragma unroll
                     for (int t = 0; t < TT; ++t) {
                         const float e = __expf(mnew - dv[t]);
-                        r_Z[k] += e;
-                        r_M[k] = fmaf(e, dv[t], r_M[k]);
-                        if (-dv[t] > r_best[k]) { r_best[k] = -dv[t]; r_idx[k] = tl + t; }
+                        rZ += e;
+                        rM = fmaf(e, dv[t], rM);
+                        if (-dv[t] > rb) { rb = -dv[t]; ri = tl + t; }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    r_dmin[k] = mnew;
+                    rd = mnew;
                 }
             }
             if (drow) {
                 if (lds_store) {
-                    // lane-major registers -> time-major LDS -> coalesced 256-B global stores.  (Storing straight from the
-                    // registers makes every store instruction touch 64 lines 4 bytes at a time: PMC WRITE_SIZE was 1.64x
-                    // the bytes actually written.)
+                    // lane-major registers -> time-major LDS -> coalesced 256-B global stores
                     __syncthreads();
 #pragma unroll
                     for (int t = 0; t < TT; ++t) xs[lane * TT + t] = dv[t];
@@ -235,52 +233,46 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
                         if (t < nvalid) drow[tl + t] = dv[t];
                 }
             }
-        }
-        if (pass + 1 < a.npass) {
-#pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                park[(5 * k + 0) * blockDim.x] = r_best[k]; park[(5 * k + 1) * blockDim.x] = r_dmin[k];
-                park[(5 * k + 2) * blockDim.x] = r_Z[k];    park[(5 * k + 3) * blockDim.x] = r_M[k];
-                park[(5 * k + 4) * blockDim.x] = __int_as_float(r_idx[k]);
-            }
-        }
-    }
-
-    // ---- merge the 64 lanes of the row
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-        float best = r_best[k];
-        int idx = r_idx[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(idx, o, 64);
-            if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
-        }
-        const float dmin = wave_min(r_dmin[k]);
-        float Z = r_Z[k], M = r_M[k];
-        if (a.gate == GATE_LTS) {
-            const float sc = (r_dmin[k] < INFINITY) ? __expf(dmin - r_dmin[k]) : 0.f;
-            Z *= sc; M *= sc;
-        }
-        Z = wave_sum(Z);
-        M = wave_sum(M);
-        if (lane == 0 && row_ok) {
-            const int kk = k0 + k;
-            const size_t col = (size_t)b * a.ld + a.col0 + (size_t)kk * a.C + c;
-            const size_t sidx = ((size_t)b * a.K + kk) * a.C + c;
-            float pout;
-            if (a.gate == GATE_RBF) {
-                pout = best;                       // = p[t*] * (1 + s - s): Shapelet.py:81-82
+            if (!last_pass) {
+                park[(5 * k + 0) * blockDim.x] = rb; park[(5 * k + 1) * blockDim.x] = rd;
+                park[(5 * k + 2) * blockDim.x] = rZ; park[(5 * k + 3) * blockDim.x] = rM;
+                park[(5 * k + 4) * blockDim.x] = __int_as_float(ri);
             } else {
-                const float th = a.thr[(size_t)kk * a.C + c];
-                pout = 1.f / (1.f + __expf(-(th - dmin)));
+                // ---- merge the 64 lanes of the row
+                float best = rb;
+                int idx = ri;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ob = __shfl_xor(best, o, 64);
+                    const int oi = __shfl_xor(idx, o, 64);
+                    if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+                }
+                const float dmin = wave_min(rd);
+                float Z = rZ, M = rM;
+                if (a.gate == GATE_LTS) {
+                    const float sc = (rd < INFINITY) ? __expf(dmin - rd) : 0.f;
+                    Z *= sc; M *= sc;
+                }
+                Z = wave_sum(Z);
+                M = wave_sum(M);
+                if (lane == 0 && row_ok) {
+                    const int kk = k0 + k;
+                    const size_t col = (size_t)b * a.ld + a.col0 + (size_t)kk * a.C + c;
+                    const size_t sidx = ((size_t)b * a.K + kk) * a.C + c;
+                    float pout;
+                    if (a.gate == GATE_RBF) {
+                        pout = best;                       // = p[t*] * (1 + s - s): Shapelet.py:81-82
+                    } else {
+                        const float th = a.thr[(size_t)kk * a.C + c];
+                        pout = 1.f / (1.f + __expf(-(th - dmin)));
+                    }
+                    a.p_out[col] = pout;
+                    a.dmin_out[col] = dmin;
+                    a.tstar[sidx] = idx;
+                    a.zmu[2 * sidx] = Z;
+                    a.zmu[2 * sidx + 1] = M / Z;
+                }
             }
-            a.p_out[col] = pout;
-            a.dmin_out[col] = dmin;
-            a.tstar[sidx] = idx;
-            a.zmu[2 * sidx] = Z;
-            a.zmu[2 * sidx + 1] = M / Z;
         }
     }
 }
