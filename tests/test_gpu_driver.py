@@ -1,0 +1,104 @@
+"""GPU end-to-end checks of the drop-in driver (BASELINE config 0: UEA BasicMotions shape through run_uea.sh) on a
+generated BasicMotions-format fixture (the real archive cannot be fetched): the harness on the HIP models against the
+same harness on the CPU oracle, and the shell launcher itself."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+PKG = os.path.join(ROOT, "speech-imagery-eeg_amd")
+
+
+def _write_bm(tmp, n=24, C=6, T=100):
+    import speech_imagery_eeg_amd  # noqa
+    from data_provider.ts_reader import write_ts
+    d = os.path.join(tmp, "BasicMotions")
+    os.makedirs(d, exist_ok=True)
+    classes = ["badminton", "running", "standing", "walking"]
+    tt = np.arange(T)
+    for split, seed in (("TRAIN", 1), ("TEST", 2)):
+        rng = np.random.RandomState(seed)
+        X, y = [], []
+        for i in range(n):
+            k = i % 4
+            X.append(rng.randn(C, T) * 0.5 + np.sin(2 * np.pi * (k + 1) * tt / T)[None, :] * (1 + 0.2 * k))
+            y.append(classes[k])
+        write_ts(os.path.join(d, f"BasicMotions_{split}.ts"), X, y, "BasicMotions", classes)
+    return d
+
+
+def _args(tmp, model):
+    import run
+    return run.get_args(["--model", model, "--dnn_type", "FCN", "--data", "UEA", "--data_root", tmp, "--dataset",
+                         "BasicMotions", "--train_epochs", "3", "--batch_size", "8", "--seed", "0", "--amp",
+                         "--log_interval", "1", "--num_shapelet", "3", "--gating_value", "1"])
+
+
+@pytest.mark.parametrize("model", ["SBM", "InterpGN"])
+def test_harness_hip_vs_oracle(tmp_path, monkeypatch, capsys, model):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import speech_imagery_eeg_amd  # noqa
+    import run
+    from exp.experiment_classification import Experiment
+    from oracle import ign_oracle as O
+    _write_bm(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    run.set_seed(0)
+    e = Experiment(_args(str(tmp_path), model))
+    assert e.device.type == "cuda"
+    sd0 = {k: v.detach().cpu().clone() for k, v in e.model.state_dict().items()}
+
+    # same harness, CPU oracle models, same initial weights and the same (seeded) batch order
+    reg = dict(Experiment.model_dict)
+    reg.update(InterpGN=lambda cfg: O.OracleIGN(cfg),
+               SBM=lambda configs, num_shapelet, shapelet_len: O.OracleSBM(configs, num_shapelet, shapelet_len))
+    monkeypatch.setattr(Experiment, "model_dict", reg)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    os.makedirs(tmp_path / "cpu", exist_ok=True)
+    monkeypatch.chdir(tmp_path / "cpu")
+    run.set_seed(0)
+    ref = Experiment(_args(str(tmp_path), model))
+    assert ref.device.type == "cpu"
+    ref.model.load_state_dict(sd0)
+    monkeypatch.undo()
+
+    def first_epoch_loss(exp):
+        torch.manual_seed(123)                      # DataLoader shuffle order
+        exp.args.train_epochs = 1
+        exp.train()
+        return exp.validation()
+
+    monkeypatch.chdir(tmp_path)
+    lg, ag = first_epoch_loss(e)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    monkeypatch.chdir(tmp_path / "cpu")
+    lr, ar = first_epoch_loss(ref)
+    monkeypatch.undo()
+    assert abs(lg - lr) < 5e-3 * max(1.0, abs(lr)), (lg, lr)
+    loss, res, _ = e.test(result_dir=str(tmp_path / "result"))
+    assert res.preds.shape == (24,) and np.isfinite(loss)
+    assert os.path.exists(os.path.join(tmp_path, e.checkpoint_dir, "checkpoint.pth"))
+
+
+def test_run_uea_sh_launcher(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    data = tmp_path / "data"
+    _write_bm(str(data))
+    env = dict(os.environ, EPOCHS="2", SEEDS="0", DATA_ROOT=str(data))
+    work = tmp_path / "work"
+    os.makedirs(work)
+    for f in ("run.py", "run_uea.sh"):
+        os.symlink(os.path.join(PKG, f), work / f)
+    r = subprocess.run(["bash", "run_uea.sh", "BasicMotions"], cwd=work, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "accuracy:" in r.stdout
+    ck = work / "checkpoints" / "InterpGN" / "BasicMotions"
+    assert any("checkpoint.pth" in fs for _, _, fs in os.walk(ck)), r.stdout[-1000:]
