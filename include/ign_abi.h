@@ -115,6 +115,12 @@ int ign_gate_fwd(const float* sbm, const float* dnn, float* out, float* eta, int
 int ign_gate_bwd(const float* sbm, const float* dnn, const float* gout, const float* geta, float* gsbm, float* gdnn,
                  int B, int N, float gating_value, int use_gating_value, void* stream);
 
+/* Shapelet diversity regulariser of one length group, forward and gradient in one launch.
+ * Replaces IGN/model/Shapelet.py:223-230:  mean_{c,i,j} exp(-||w[i,c,:] - w[j,c,:] + eps||_2) (1 - delta_ij), eps = 1e-6.
+ * loss_part_c (C): per-channel partial sums (their sum is the group's loss); gw_kcl (K,C,L): d loss / d w.  K <= 16.  */
+int ign_diversity_fwd_bwd(const float* w_kcl, float* loss_part_c, float* gw_kcl, int K, int C, int L, float eps,
+                          void* stream);
+
 /* One Adam step over flat buffers (torch.optim.Adam semantics, no weight decay / amsgrad): replaces the per-tensor
  * optimizer.step() of IGN/exp/experiment_classification.py:338.  `step` is the 1-based step count.               */
 int ign_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,

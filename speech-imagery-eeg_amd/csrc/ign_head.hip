@@ -288,3 +288,84 @@ extern "C" int ign_adam_step(float* p, const float* g, float* m, float* v, long 
                        eps, (float)bc1, (float)sqrt(bc2));
     return ign_check_launch("adam_kernel");
 }
+
+// ------------------------------------------------------------------------------------------------ shapelet diversity
+// loss = mean_{c,i,j} exp(-|| w[i,c,:] - w[j,c,:] + 1e-6 ||_2) (1 - delta_ij)      IGN/model/Shapelet.py:223-230
+// (nn.PairwiseDistance(p=2): the eps is added to the DIFFERENCE, so d_ij != d_ji in the last bits -- both are kept).
+// One block per channel: pass 1 reduces the K*K squared distances into LDS, pass 2 forms the loss partial and the
+// gradient of the (unit-weighted) loss w.r.t. w.  Replaces ~25 tiny elementwise / reduction launches per group.
+constexpr int DIV_KMAX = 16;
+
+__global__ void __launch_bounds__(256) diversity_kernel(const float* __restrict__ w, float* __restrict__ loss_part,
+                                                        float* __restrict__ gw, int K, int C, int L, float eps) {
+    __shared__ float D2[DIV_KMAX][DIV_KMAX];        // D2[i][j] = sum_l (w_i - w_j + eps)^2
+    __shared__ float Ew[DIV_KMAX][DIV_KMAX];        // exp(-D_ij) / D_ij   (0 on the diagonal)
+    __shared__ float red[4];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t cs = (size_t)C * L;                 // stride between shapelets
+    const float* wc = w + (size_t)c * L;
+    for (int i = 0; i < K; ++i)
+        for (int j = i + 1; j < K; ++j) {
+            float a = 0.f, b = 0.f;
+            for (int l = tid; l < L; l += 256) {
+                const float dl = wc[i * cs + l] - wc[j * cs + l];
+                a = fmaf(dl + eps, dl + eps, a);
+                b = fmaf(eps - dl, eps - dl, b);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            __syncthreads();
+            if (lane == 0) red[wave] = a;
+            __syncthreads();
+            const float ta = red[0] + red[1] + red[2] + red[3];
+            __syncthreads();
+            if (lane == 0) red[wave] = b;
+            __syncthreads();
+            const float tb = red[0] + red[1] + red[2] + red[3];
+            if (tid == 0) { D2[i][j] = ta; D2[j][i] = tb; }
+        }
+    __syncthreads();
+    const float norm = 1.f / ((float)C * K * K);
+    if (tid < K * K) {
+        const int i = tid / K, j = tid % K;
+        float e = 0.f, ew = 0.f;
+        if (i != j) {
+            const float d = sqrtf(D2[i][j]);
+            e = expf(-d);
+            ew = e / d;
+        }
+        Ew[i][j] = ew;
+        D2[i][j] = e;                                // reuse as e_ij for the loss sum below
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) s += D2[i][j];
+        loss_part[c] = s * norm;
+    }
+    // d e_ij / d w_i[l] = -e_ij (dl + eps) / D_ij ;  d e_ji / d w_i[l] = +e_ji (eps - dl) / D_ji   (dl = w_i[l] - w_j[l])
+    for (int l = tid; l < L; l += 256)
+        for (int i = 0; i < K; ++i) {
+            const float wi = wc[i * cs + l];
+            float g = 0.f;
+            for (int j = 0; j < K; ++j)
+                if (j != i) {
+                    const float dl = wi - wc[j * cs + l];
+                    g += -Ew[i][j] * (dl + eps) + Ew[j][i] * (eps - dl);
+                }
+            gw[i * cs + (size_t)c * L + l] = g * norm;
+        }
+}
+
+extern "C" int ign_diversity_fwd_bwd(const float* w_kcl, float* loss_part_c, float* gw_kcl, int K, int C, int L, float eps,
+                                     void* stream) {
+    if (!w_kcl || !loss_part_c || !gw_kcl || K <= 0 || C <= 0 || L <= 0) {
+        ign_set_error("ign_diversity_fwd_bwd: null pointer or bad dimension (K=%d C=%d L=%d)", K, C, L);
+        return IGN_E_ARG;
+    }
+    if (K > DIV_KMAX) { ign_set_error("ign_diversity_fwd_bwd: K=%d > %d shapelets per group", K, DIV_KMAX); return IGN_E_UNSUP; }
+    IgnScopedTimer tm("diversity", (hipStream_t)stream);
+    hipLaunchKernelGGL(diversity_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, w_kcl, loss_part_c, gw_kcl, K, C, L, eps);
+    return ign_check_launch("diversity_kernel");
+}

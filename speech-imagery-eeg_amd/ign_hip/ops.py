@@ -326,3 +326,31 @@ class DwConv1dFn(torch.autograd.Function):
 
 def dwconv1d(x, w, pad_left):
     return DwConv1dFn.apply(x, w, pad_left)
+
+
+class DiversityFn(torch.autograd.Function):
+    """mean_{c,i,j} exp(-||w_i - w_j + 1e-6||) (1 - delta_ij) of one shapelet group (IGN/model/Shapelet.py:223-230);
+    the kernel produces the loss and its gradient together, backward only scales the saved gradient."""
+
+    @staticmethod
+    def forward(ctx, w):
+        _need_gpu("diversity", w)
+        w = w.contiguous()
+        K, C, L = w.shape
+        part = torch.empty(C, device=w.device, dtype=torch.float32)
+        gw = torch.empty_like(w)
+        _lib.check(_lib.lib().ign_diversity_fwd_bwd(_ptr(w), _ptr(part), _ptr(gw), K, C, L, 1e-6, _stream()),
+                   "ign_diversity_fwd_bwd")
+        ctx.save_for_backward(gw)
+        return part.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (gw,) = ctx.saved_tensors
+        return gw * g
+
+
+def diversity(w):
+    if not w.is_cuda or w.dtype != torch.float32 or w.shape[0] > 16:
+        return None
+    return DiversityFn.apply(w)

@@ -160,6 +160,10 @@ class ShapeBottleneckModel(nn.Module):
         """sum_g mean_{c,i,j} exp(-||w_i - w_j + 1e-6||_2) (1 - delta_ij)   (Shapelet.py:223-230)."""
         total = 0.
         for s in self.shapelets:
+            fused = ops.diversity(s.weights)            # one HIP launch per group (loss + gradient)
+            if fused is not None:
+                total = total + fused
+                continue
             sh = s.weights.permute(1, 0, 2)                                   # (C,K,L)
             dist = F.pairwise_distance(sh.unsqueeze(1), sh.unsqueeze(2), p=2)  # eps=1e-6 like nn.PairwiseDistance
             off_diag = 1.0 - torch.eye(sh.shape[1], device=dist.device, dtype=dist.dtype).unsqueeze(0)

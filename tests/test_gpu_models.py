@@ -239,3 +239,22 @@ def test_sbm_cosine_pearson_vs_oracle(dfunc, mode):
     for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
         scale = max(float(q.grad.abs().max()), 1e-7)
         assert float((p.grad.cpu() - q.grad).abs().max()) <= 3e-4 * scale + 1e-8, n
+
+
+def test_diversity_kernel_vs_torch():
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    torch.manual_seed(0)
+    for (K, C, L) in [(5, 122, 500), (10, 6, 5), (3, 7, 33), (1, 4, 9)]:
+        w = torch.randn(K, C, L, device=dev, requires_grad=True)
+        loss = ops.diversity(w)
+        (loss * 1.7).backward()
+        wd = w.detach().double().cpu().requires_grad_(True)
+        sh = wd.permute(1, 0, 2)
+        dist = F.pairwise_distance(sh.unsqueeze(1), sh.unsqueeze(2), p=2)
+        ref = (torch.exp(-dist) * (1.0 - torch.eye(K, dtype=torch.float64).unsqueeze(0))).mean()
+        (ref * 1.7).backward()
+        assert abs(loss.item() - ref.item()) <= 1e-5 * max(abs(ref.item()), 1e-3) + 1e-9, (K, C, L)
+        scale = float(wd.grad.abs().max())
+        assert float((w.grad.cpu().double() - wd.grad).abs().max()) <= 1e-4 * scale + 1e-12, (K, C, L)
