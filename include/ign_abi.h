@@ -148,6 +148,58 @@ size_t ign_dwconv1d_bwd_weight_workspace_bytes(int B, int C, int k);
 int ign_dwconv1d_bwd_weight(const float* x, const float* dy, float* dw, void* workspace, int B, int C, int T, int k,
                             int pad_left, void* stream);
 
+/* ---- FCN expert: channels-last 1-D convolution as an implicit GEMM on the fp32 matrix cores, BatchNorm + ReLU
+ * folded into the GEMM prologues / epilogues (csrc/ign_clconv.hip).  Replaces IGN/model/FullyConvNet.py:31-59
+ * (3 x [Conv1d -> BatchNorm1d -> ReLU] -> AdaptiveAvgPool1d) and its autograd.  Activations are (B, T, C) row-major
+ * (the loader's layout); a 'valid' convolution: Tout = Tin - k + 1.  All sums are fixed-order (deterministic).
+ *
+ * ign_clconv_pack_weights: w (Co,Ci,k) [torch Conv1d layout] -> wt_fwd (Co, k*Ci) with kk = j*Ci + ci, and (if not
+ *   NULL) wt_dgrad (Ci, k*Co) with kk = jj*Co + co holding w[co][ci][k-1-jj].
+ * ign_clconv_fwd: y[b,t,co] = bias[co] + sum_{j,ci} in[b,t+j,ci] w[co,ci,j], where in = x, or relu(pro_a[ci]*x + pro_b[ci])
+ *   when pro_a/pro_b are given (the BatchNorm affine + ReLU of the block below, applied while staging).
+ *   stat_part (ign_clconv_mtiles(B*Tout), 2, Co), nullable: per-tile sum_y and sum_y^2 for this block's BatchNorm.
+ * ign_clconv_dgrad: given dyp (B, Tout + 2(k-1), Co) = dL/dy zero-padded by k-1 rows on both sides of every sample,
+ *   computes dL/dz[b,t,ci] (z = this conv's input = relu(a_in*y_in + b_in)) and, in the epilogue, the ReLU-masked
+ *   g_in = dL/dz * [a_in*y_in + b_in > 0] (B,Tin,Ci) plus stat_part (ign_clconv_mtiles(B*Tin), 2, Ci) = per-tile
+ *   sum g_in and sum g_in*(y_in - mean_in)*invstd_in   (BatchNorm backward sums of the block below).
+ * ign_clconv_wgrad: dw[co,ci,j] = sum_{b,t} dy[b,t,co] in[b,t+j,ci]  (in as for fwd; dy rows are read from a buffer
+ *   padded by dy_pad rows per side).  Co % 4 == 0.  workspace: ign_clconv_wgrad_workspace_bytes().                  */
+long long ign_clconv_mtiles(long long M);
+int ign_clconv_pack_weights(const float* w_oik, float* wt_fwd, float* wt_dgrad, int Co, int Ci, int k, void* stream);
+int ign_clconv_fwd(const float* x, const float* wt_fwd, const float* bias, const float* pro_a, const float* pro_b,
+                   float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream);
+int ign_clconv_dgrad(const float* dyp, const float* wt_dgrad, const float* y_in, const float* a_in, const float* b_in,
+                     const float* mean_in, const float* invstd_in, float* g_in, float* stat_part,
+                     int B, int Tin, int Ci, int Co, int k, void* stream);
+size_t ign_clconv_wgrad_workspace_bytes(int B, int Tin, int Ci, int Co, int k);
+int ign_clconv_wgrad(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
+                     float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream);
+
+/* BatchNorm1d glue of the same expert (IGN/model/FullyConvNet.py:33,40,47; torch.nn.BatchNorm1d semantics: biased batch
+ * variance for normalisation, unbiased for running_var, momentum update).  C % 4 == 0, C <= 1024.
+ * finalize_fwd: partial sums (nparts, 2, C) over R rows -> a = gamma*invstd, b = beta - a*mean (so BN(y) = a*y + b),
+ *   mean, invstd; updates running_mean / running_var in place when they are not NULL.
+ * affine_eval: the same a, b, mean, invstd from the running statistics (module.eval()).
+ * relu_pool_fwd: pooled[b,c] = mean_t relu(a_c*y[b,t,c] + b_c)            (BatchNorm + ReLU + AdaptiveAvgPool1d(1)).
+ * relu_pool_bwd: g[b,t,c] = gpool[b,c]/T * [a_c*y + b_c > 0] and per-block partials (ign_bn_relu_pool_bwd_parts(B,T), 2, C)
+ *   of sum g and sum g*yhat.
+ * finalize_bwd: partials -> dbeta = sum g, dgamma = sum g*yhat.
+ * bwd_apply: dy = a*(g - (dbeta + yhat*dgamma)/R) [training] or a*g [eval], written into (B, pad + T + pad, C) with the
+ *   pad rows zeroed (the layout ign_clconv_dgrad / ign_clconv_wgrad read).                                          */
+int ign_bn_finalize_fwd(const float* part, int nparts, long long R, int C, const float* gamma, const float* beta,
+                        float eps, float momentum, float* running_mean, float* running_var,
+                        float* a, float* b, float* mean, float* invstd, void* stream);
+int ign_bn_affine_eval(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                       float eps, int C, float* a, float* b, float* mean, float* invstd, void* stream);
+int ign_bn_relu_pool_fwd(const float* y, const float* a, const float* b, float* pooled, int B, int T, int C, void* stream);
+long long ign_bn_relu_pool_bwd_parts(int B, int T);
+int ign_bn_relu_pool_bwd(const float* y, const float* gpool, const float* a, const float* b, const float* mean,
+                         const float* invstd, float* g, float* part, int B, int T, int C, void* stream);
+int ign_bn_finalize_bwd(const float* part, int nparts, int C, float* dbeta, float* dgamma, void* stream);
+int ign_bn_bwd_apply(const float* g, const float* y, const float* a, const float* mean, const float* invstd,
+                     const float* dbeta, const float* dgamma, float* dyp, int B, int T, int C, int pad, int training,
+                     void* stream);
+
 /* Per-kernel HIP-event timing (measurement only; off by default).  When enabled every kernel launch made by
  * this library is bracketed by hipEventRecord on the caller's stream.  ign_timing_read() waits for the recorded
  * events of `label` ("shp_fwd", "shp_bwd", "reduce_parts", "instnorm", "attn_fwd", "attn_bwd_dkdv", "attn_bwd_dq",

@@ -1,0 +1,776 @@
+// Channels-last 1-D convolution as an implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), with the
+// BatchNorm / ReLU glue of the FCN expert folded into the GEMM prologues and epilogues.
+//
+// Replaces IGN/model/FullyConvNet.py:31-50 (3 x [Conv1d -> BatchNorm1d -> ReLU]) and its autograd.
+//
+// Why a GEMM with no im2col: activations are (B, T, C) row-major -- the loader's own layout.  The im2col row of
+// output position (b, t) is x[b, t : t+k, :], i.e. k*C CONTIGUOUS floats starting at x[(b*T + t)*C].  So
+//     y[m][co] = sum_kk A[m][kk] * Wt[co][kk],   A[m][kk] = x[rowoff(m) + kk],   kk = j*C + ci,
+// is an NT GEMM whose A rows overlap in memory (row pitch C, row length k*C); nothing is gathered or copied.
+//   forward : A = previous activation (optionally relu(a_c*y + b_c) applied while staging: BatchNorm+ReLU of the
+//             previous block never touch HBM), epilogue adds the bias and emits per-channel sum / sum-of-squares
+//             partials for this block's BatchNorm;
+//   dgrad   : the same kernel on the zero-padded output gradient with the tap-reversed weights; its epilogue applies
+//             the ReLU mask of the layer below and emits that layer's BatchNorm-backward sums;
+//   wgrad   : TN GEMM dW[co][kk] = sum_m dy[m][co] * A[m][kk], split over row ranges, fixed-order reduction.
+// Tiles: 256-thread workgroups, 128x128 output tile, four waves in 2x2 each owning 64x64 = four 32x32 accumulators,
+// 16-deep K chunks double-buffered in LDS (40 KB): global -> registers -> LDS, one barrier per chunk.
+// The k index of a 32x32x2 step is permuted so that a lane's operand stream is 4 CONTIGUOUS floats (ds_read_b128):
+// step (u,e) of a chunk takes k = 8u + 4h + e from lane half h, for A and B alike, so the dot product is unchanged.
+#include "ign_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int acc_row16(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+constexpr int TM = 128, TN = 128, KC = 16;
+constexpr int NT_PITCH = KC + 4;             // floats per staged row (k contiguous); 20*i mod 64 is conflict-free for b128
+constexpr int TN_PITCH = 128 + 8;            // floats per staged reduction row (outputs contiguous)
+
+// logical GEMM row m -> float offset of its first element in a (samples, rows, row_pitch) buffer
+struct RowMap {
+    int rows_logical;        // rows per sample in the GEMM's row index space
+    int row0;                // first physical row of a sample that logical row 0 maps to (skips padding)
+    int row_pitch;           // floats between consecutive rows
+    long long sample_pitch;  // floats between samples
+};
+__device__ __forceinline__ long long row_off(const RowMap& rm, int m) {
+    const int s = m / rm.rows_logical;
+    const int r = m - s * rm.rows_logical;
+    return (long long)s * rm.sample_pitch + (long long)(rm.row0 + r) * rm.row_pitch;
+}
+
+template <int V> struct VecT;
+template <> struct VecT<1> { typedef float T; };
+template <> struct VecT<2> { typedef float2 T; };
+template <> struct VecT<4> { typedef float4 T; };
+
+template <int V>
+__device__ __forceinline__ void vload(float (&d)[V], const float* p) {
+    if (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p); d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; }
+    else if (V == 2) { const float2 t = *reinterpret_cast<const float2*>(p); d[0] = t.x; d[1] = t.y; }
+    else d[0] = *p;
+}
+template <int V>
+__device__ __forceinline__ void vstore(float* p, const float (&d)[V]) {
+    if (V == 4) *reinterpret_cast<float4*>(p) = make_float4(d[0], d[1], d[2], d[3]);
+    else if (V == 2) *reinterpret_cast<float2*>(p) = make_float2(d[0], d[1]);
+    else *p = d[0];
+}
+
+enum { EPI_BIAS_STATS = 0, EPI_MASK_STATS = 1 };
+
+struct GemmNTArgs {
+    const float* A; RowMap am; int K;          // A[m][kk] = A[row_off(m) + kk]
+    const float* Bt; int ldb;                  // Bt[n][kk]
+    float* C; int M, N;                        // dense (M, N)
+    const float* bias;                         // [N] or null
+    const float* pro_a; const float* pro_b; int pro_c;    // prologue: A <- relu(pro_a[c]*A + pro_b[c]), c = kk % pro_c
+    float* part;                               // (mtiles, 2, N) partial sums, or null
+    // EPI_MASK_STATS: g = acc * [ea*y + eb > 0]; partials of g and g*(y - mean)*invstd
+    const float* ey; const float* ea; const float* eb; const float* emean; const float* einv;
+    int mtiles, ntiles;
+};
+
+// ------------------------------------------------------------------------------------------------ NT GEMM
+template <int V, bool PRO, int EPI>
+__global__ void __launch_bounds__(256, 2) clconv_nt_kernel(const GemmNTArgs a) {
+    constexpr int VPR = KC / V;                // vectors per staged row
+    constexpr int RPP = 256 / VPR;             // rows per staging pass
+    constexpr int NPASS = TM / RPP;            // passes per tile (8 / V)
+    __shared__ __attribute__((aligned(16))) float smem[2][(TM + TN) * NT_PITCH];
+
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2); give each XCD a contiguous run of
+    // logical tiles so the n-tiles of one m-tile (same A rows) and neighbouring m-tiles (overlapping rows) meet there.
+    const int nwg = a.mtiles * a.ntiles;
+    int lid = blockIdx.x;
+    {
+        const int per = nwg / 8;
+        if (lid < per * 8) lid = (lid & 7) * per + (lid >> 3);
+    }
+    const int mt = lid / a.ntiles, nt = lid - mt * a.ntiles;
+    const int m0 = mt * TM, n0 = nt * TN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // staging coordinates: vector q of rows (r + p*RPP)
+    const int sq = tid % VPR, sr = tid / VPR;
+    const float* arow[NPASS];
+    const float* brow[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int m = min(m0 + sr + p * RPP, a.M - 1);        // tail rows shadow the last valid row (masked at the store)
+        const int n = min(n0 + sr + p * RPP, a.N - 1);
+        arow[p] = a.A + row_off(a.am, m) + sq * V;
+        brow[p] = a.Bt + (long long)n * a.ldb + sq * V;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[NPASS][V], rb[NPASS][V];
+    const int nchunk = (a.K + KC - 1) / KC;
+
+    // The prologue (BatchNorm affine + ReLU of the block below) is applied when the registers are written to LDS, i.e.
+    // AFTER the MFMAs of the current chunk: applying it at the load would make the wave wait for the load first.
+    float pa[V], pb[V];
+    bool pro_ok = false;
+    auto gload = [&](int c) {
+        const int kk = c * KC + sq * V;
+        const bool ok = kk < a.K;               // V divides K: a vector is entirely inside or outside
+        if (PRO) {
+            pro_ok = ok;
+            if (ok) {
+                const int ch = kk % a.pro_c;
+                vload<V>(pa, a.pro_a + ch);
+                vload<V>(pb, a.pro_b + ch);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            if (ok) {
+                vload<V>(ra[p], arow[p] + c * KC);
+                vload<V>(rb[p], brow[p] + c * KC);
+            } else {
+#pragma unroll
+                for (int v = 0; v < V; ++v) { ra[p][v] = 0.f; rb[p][v] = 0.f; }
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* As = smem[buf];
+        float* Bs = As + TM * NT_PITCH;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            if (PRO && pro_ok) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) ra[p][v] = fmaxf(fmaf(pa[v], ra[p][v], pb[v]), 0.f);
+            }
+            vstore<V>(As + (sr + p * RPP) * NT_PITCH + sq * V, ra[p]);
+            vstore<V>(Bs + (sr + p * RPP) * NT_PITCH + sq * V, rb[p]);
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload(c + 1);
+        const float* As = smem[buf] + (wm * 64 + l31) * NT_PITCH + 4 * h;
+        const float* Bs = smem[buf] + TM * NT_PITCH + (wn * 64 + l31) * NT_PITCH + 4 * h;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float4 a0 = *reinterpret_cast<const float4*>(As + 8 * u);
+            const float4 a1 = *reinterpret_cast<const float4*>(As + 32 * NT_PITCH + 8 * u);
+            const float4 b0 = *reinterpret_cast<const float4*>(Bs + 8 * u);
+            const float4 b1 = *reinterpret_cast<const float4*>(Bs + 32 * NT_PITCH + 8 * u);
+#define IGN_STEP(e)                                   \
+            acc[0][0] = MFMA32(a0.e, b0.e, acc[0][0]); \
+            acc[0][1] = MFMA32(a0.e, b1.e, acc[0][1]); \
+            acc[1][0] = MFMA32(a1.e, b0.e, acc[1][0]); \
+            acc[1][1] = MFMA32(a1.e, b1.e, acc[1][1]);
+            IGN_STEP(x) IGN_STEP(y) IGN_STEP(z) IGN_STEP(w)
+#undef IGN_STEP
+        }
+        if (c + 1 < nchunk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  Lane (l31, h) of accumulator (i, j) holds column n = n0 + wn*64 + j*32 + l31 and the 16 rows
+    // m0 + wm*64 + i*32 + acc_row16(r, h).
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        const bool n_ok = n < a.N;
+        const int nc = n_ok ? n : a.N - 1;
+        const float bv = (EPI == EPI_BIAS_STATS && a.bias) ? a.bias[nc] : 0.f;
+        float ea = 0.f, eb = 0.f, em = 0.f, ei = 0.f;
+        if (EPI == EPI_MASK_STATS) { ea = a.ea[nc]; eb = a.eb[nc]; em = a.emean[nc]; ei = a.einv[nc]; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + acc_row16(r, h);
+                const bool ok = n_ok && m < a.M;
+                float v = acc[i][j][r];
+                if (EPI == EPI_BIAS_STATS) {
+                    v += bv;
+                    if (ok) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+                } else {
+                    const float yv = ok ? a.ey[(long long)m * a.N + n] : 0.f;
+                    v = (fmaf(ea, yv, eb) > 0.f) ? v : 0.f;
+                    if (ok) { s1[j] += v; s2[j] = fmaf(v, (yv - em) * ei, s2[j]); }
+                }
+                if (ok) a.C[(long long)m * a.N + n] = v;
+            }
+        }
+    }
+    if (a.part) {
+        // combine the lane halves, then the two waves that share these columns, in a fixed order
+        float* red = smem[0];                  // [2 (wm)][2 (stat)][128 (col)]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32, 64);
+            s2[j] += __shfl_xor(s2[j], 32, 64);
+            if (h == 0) {
+                const int col = wn * 64 + j * 32 + l31;
+                red[(wm * 2 + 0) * TN + col] = s1[j];
+                red[(wm * 2 + 1) * TN + col] = s2[j];
+            }
+        }
+        __syncthreads();
+        if (tid < TN && n0 + tid < a.N) {
+            a.part[((long long)mt * 2 + 0) * a.N + n0 + tid] = red[0 * TN + tid] + red[2 * TN + tid];
+            a.part[((long long)mt * 2 + 1) * a.N + n0 + tid] = red[1 * TN + tid] + red[3 * TN + tid];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ TN GEMM (wgrad)
+struct GemmTNArgs {
+    const float* P; RowMap pm; int NP;         // P[m][co], co < NP (dense row of NP floats at row_off(pm, m))
+    const float* Q; RowMap qm; int NQ;         // Q[m][kk] = Q[row_off(qm, m) + kk], kk < NQ
+    const float* pro_a; const float* pro_b; int pro_c;    // Q <- relu(pro_a[c]*Q + pro_b[c]), c = kk % pro_c
+    float* part;                               // (nsplit, NP, NQ) partial products
+    int M, nsplit, ptiles, qtiles;
+};
+
+// Row-pair permutation: lane i of operand block b reads output index 2*i + b, so one ds_read_b64 feeds both 32-wide
+// blocks of the wave tile; accumulator (i, j) row rho <-> co = 64*wm + 2*rho + i, lane column c <-> kk = 64*wn + 2*c + j.
+template <int VQ, bool PRO>
+__global__ void __launch_bounds__(256, 2) clconv_tn_kernel(const GemmTNArgs a) {
+    constexpr int QVPR = 128 / VQ;             // Q vectors per staged row
+    constexpr int QRPP = 256 / QVPR;           // Q rows per pass
+    constexpr int QNPASS = KC / QRPP;          // (VQ=4: 2, VQ=2: 4, VQ=1: 8)
+    __shared__ __attribute__((aligned(16))) float smem[2][2 * KC * TN_PITCH];
+
+    const int tile = blockIdx.x;
+    const int pt = tile / a.qtiles, qt = tile - pt * a.qtiles;
+    const int p0 = pt * 128, q0 = qt * 128;
+    const int split = blockIdx.y;
+    const int rows_per = ((a.M + a.nsplit - 1) / a.nsplit + KC - 1) / KC * KC;
+    const int m_begin = split * rows_per;
+    const int m_end = min(a.M, m_begin + rows_per);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // P staging: float4 c4 of rows r, r+8  (NP is a multiple of 4: checked by the launcher)
+    const int pc = (tid & 31) * 4, pr = tid >> 5;
+    const bool p_ok = p0 + pc < a.NP;
+    // Q staging: vector qv of rows qr + i*QRPP
+    const int qc = (tid % QVPR) * VQ, qr = tid / QVPR;
+    const bool q_ok = q0 + qc < a.NQ;
+    float qa[VQ], qb[VQ];
+    if (PRO && q_ok) {
+        const int ch = (q0 + qc) % a.pro_c;
+        vload<VQ>(qa, a.pro_a + ch);
+        vload<VQ>(qb, a.pro_b + ch);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float rp[2][4], rq[QNPASS][VQ];
+    bool rq_ok[QNPASS];
+    auto gload = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mb + pr + 8 * i;
+            if (p_ok && m < m_end) vload<4>(rp[i], a.P + row_off(a.pm, m) + p0 + pc);
+            else { rp[i][0] = rp[i][1] = rp[i][2] = rp[i][3] = 0.f; }
+        }
+#pragma unroll
+        for (int i = 0; i < QNPASS; ++i) {
+            const int m = mb + qr + QRPP * i;
+            if (q_ok && m < m_end) {
+                vload<VQ>(rq[i], a.Q + row_off(a.qm, m) + q0 + qc);
+                rq_ok[i] = true;
+            } else {
+#pragma unroll
+                for (int v = 0; v < VQ; ++v) rq[i][v] = 0.f;
+                rq_ok[i] = false;
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* Ps = smem[buf];
+        float* Qs = Ps + KC * TN_PITCH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) vstore<4>(Ps + (pr + 8 * i) * TN_PITCH + pc, rp[i]);
+#pragma unroll
+        for (int i = 0; i < QNPASS; ++i) {
+            if (PRO && rq_ok[i]) {              // applied after the MFMAs of the current chunk (see the NT kernel)
+#pragma unroll
+                for (int v = 0; v < VQ; ++v) rq[i][v] = fmaxf(fmaf(qa[v], rq[i][v], qb[v]), 0.f);
+            }
+            vstore<VQ>(Qs + (qr + QRPP * i) * TN_PITCH + qc, rq[i]);
+        }
+    };
+
+    if (m_begin < m_end) {
+        gload(m_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int mb = m_begin; mb < m_end; mb += KC, buf ^= 1) {
+        if (mb + KC < m_end) gload(mb + KC);
+        const float* Ps = smem[buf] + h * TN_PITCH + wm * 64 + 2 * l31;
+        const float* Qs = smem[buf] + KC * TN_PITCH + h * TN_PITCH + wn * 64 + 2 * l31;
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            const float2 pv = *reinterpret_cast<const float2*>(Ps + 2 * s * TN_PITCH);
+            const float2 qv = *reinterpret_cast<const float2*>(Qs + 2 * s * TN_PITCH);
+            acc[0][0] = MFMA32(pv.x, qv.x, acc[0][0]);
+            acc[0][1] = MFMA32(pv.x, qv.y, acc[0][1]);
+            acc[1][0] = MFMA32(pv.y, qv.x, acc[1][0]);
+            acc[1][1] = MFMA32(pv.y, qv.y, acc[1][1]);
+        }
+        if (mb + KC < m_end) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = a.part + (long long)split * a.NP * a.NQ;
+    const int kk = q0 + wn * 64 + 2 * l31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = p0 + wm * 64 + 2 * acc_row16(r, h) + i;
+            if (co < a.NP) {
+                float* o = out + (long long)co * a.NQ + kk;
+                if (!(a.NQ & 1) && kk + 1 < a.NQ) {
+                    *reinterpret_cast<float2*>(o) = make_float2(acc[i][0][r], acc[i][1][r]);
+                } else {                       // odd row pitch: the pair is not 8-byte aligned
+                    if (kk < a.NQ) o[0] = acc[i][0][r];
+                    if (kk + 1 < a.NQ) o[1] = acc[i][1][r];
+                }
+            }
+        }
+}
+
+// dW[co][ci][j] = sum_s part[s][co][j*Ci + ci]   (s ascending: bitwise reproducible); torch (Co, Ci, k) layout
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit,
+                                                           int Co, int Ci, int k) {
+    const long long n = (long long)Co * Ci * k;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // index in (Co, k, Ci) order: coalesced reads
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < nsplit; ++p) s += part[(long long)p * n + i];
+    const int ci = (int)(i % Ci);
+    const long long t = i / Ci;
+    const int j = (int)(t % k);
+    const long long co = t / k;
+    dw[(co * Ci + ci) * k + j] = s;
+}
+
+// Wt[co][j*Ci + ci] = W[co][ci][j];   Wd[ci][jj*Co + co] = W[co][ci][k-1-jj]
+__global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                           float* __restrict__ wd, int Co, int Ci, int k) {
+    const long long n = (long long)Co * Ci * k;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int j = (int)(i % k);
+    const long long t = i / k;
+    const int ci = (int)(t % Ci);
+    const long long co = t / Ci;
+    const float v = w[i];
+    wt[(co * k + j) * Ci + ci] = v;
+    if (wd) wd[((long long)ci * k + (k - 1 - j)) * Co + co] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm glue
+// forward finalize: mean, biased var -> a = gamma*invstd, b = beta - a*mean; running stats (unbiased var).
+// part is (nparts, 2, C): per-tile sum and sum of squares, combined in double in tile order.
+__global__ void bn_finalize_fwd_kernel(const float* __restrict__ part, int nparts, long long R, int C,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                       float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ a,
+                                       float* __restrict__ b, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sl = threadIdx.x >> 6;                     // 4 slices of the partials per channel
+    __shared__ double sh[2][4][64];
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        const int per = (nparts + 3) / 4;
+        const int i0 = sl * per, i1 = min(nparts, i0 + per);
+        for (int i = i0; i < i1; ++i) { s += (double)part[((size_t)i * 2 + 0) * C + c]; q += (double)part[((size_t)i * 2 + 1) * C + c]; }
+    }
+    sh[0][sl][threadIdx.x & 63] = s;
+    sh[1][sl][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    s = sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x] + sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x];
+    q = sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x] + sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x];
+    const double m = s / (double)R;
+    double var = q / (double)R - m * m;
+    if (var < 0.0) var = 0.0;
+    const float inv = (float)(1.0 / sqrt(var + (double)eps));
+    const float av = gamma[c] * inv;
+    a[c] = av;
+    b[c] = beta[c] - av * (float)m;
+    mean_out[c] = (float)m;
+    invstd_out[c] = inv;
+    if (run_mean) {
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+        const double unb = (R > 1) ? var * (double)R / (double)(R - 1) : var;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void bn_affine_eval_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int C,
+                                      float* __restrict__ a, float* __restrict__ b, float* __restrict__ mean_out,
+                                      float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float inv = 1.f / sqrtf(run_var[c] + eps);
+    const float av = gamma[c] * inv;
+    a[c] = av;
+    b[c] = beta[c] - av * run_mean[c];
+    mean_out[c] = run_mean[c];
+    invstd_out[c] = inv;
+}
+
+__global__ void bn_finalize_bwd_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dbeta,
+                                       float* __restrict__ dgamma) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sl = threadIdx.x >> 6;
+    __shared__ double sh[2][4][64];
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        const int per = (nparts + 3) / 4;
+        const int i0 = sl * per, i1 = min(nparts, i0 + per);
+        for (int i = i0; i < i1; ++i) { s += (double)part[((size_t)i * 2 + 0) * C + c]; q += (double)part[((size_t)i * 2 + 1) * C + c]; }
+    }
+    sh[0][sl][threadIdx.x & 63] = s;
+    sh[1][sl][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    dbeta[c] = (float)(sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x] + sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
+    dgamma[c] = (float)(sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x] + sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
+}
+
+// Global average pool of relu(a*y + b) over time:  pooled[b][c] = (1/T) sum_t max(a_c*y[b,t,c] + b_c, 0).
+// One block per sample; thread <-> (row lane, 4 channels); the row lanes are combined through LDS in fixed order.
+__global__ void __launch_bounds__(256) bn_relu_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ a,
+                                                               const float* __restrict__ b, float* __restrict__ pooled, int T,
+                                                               int C) {
+    extern __shared__ float sm[];                         // [rif][C]
+    const int c4 = C / 4, rif = 256 / c4;
+    const int col = (threadIdx.x % c4) * 4, rofs = threadIdx.x / c4;
+    const float* yb = y + (size_t)blockIdx.x * T * C;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rofs < rif) {
+        const float4 av = *reinterpret_cast<const float4*>(a + col), bv = *reinterpret_cast<const float4*>(b + col);
+        for (int t = rofs; t < T; t += rif) {
+            const float4 yv = *reinterpret_cast<const float4*>(yb + (size_t)t * C + col);
+            s[0] += fmaxf(fmaf(av.x, yv.x, bv.x), 0.f);
+            s[1] += fmaxf(fmaf(av.y, yv.y, bv.y), 0.f);
+            s[2] += fmaxf(fmaf(av.z, yv.z, bv.z), 0.f);
+            s[3] += fmaxf(fmaf(av.w, yv.w, bv.w), 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sm[rofs * C + col + q] = s[q];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float u = 0.f;
+        for (int q = 0; q < rif; ++q) u += sm[q * C + c];
+        pooled[(size_t)blockIdx.x * C + c] = u / (float)T;
+    }
+}
+
+// Backward of the pool through ReLU: g[b,t,c] = (gpool[b,c]/T) * [a*y + b > 0]; per-block partials of sum g and
+// sum g*yhat (BatchNorm backward).  Grid (ceil(T / rows_per_block), B).
+constexpr int POOL_ROWS = 128;
+__global__ void __launch_bounds__(256) bn_relu_pool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gpool,
+                                                               const float* __restrict__ a, const float* __restrict__ b,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               float* __restrict__ g, float* __restrict__ part, int T, int C) {
+    extern __shared__ float sm[];                         // [2][rif][C]
+    const int c4 = C / 4, rif = 256 / c4;
+    const int col = (threadIdx.x % c4) * 4, rofs = threadIdx.x / c4;
+    const int bi = blockIdx.y;
+    const int t0 = blockIdx.x * POOL_ROWS, t1 = min(T, t0 + POOL_ROWS);
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rofs < rif) {
+        float av[4], bv[4], mv[4], iv[4], gp[4];
+        vload<4>(av, a + col); vload<4>(bv, b + col); vload<4>(mv, mean + col); vload<4>(iv, invstd + col);
+        vload<4>(gp, gpool + (size_t)bi * C + col);
+        const float invT = 1.f / (float)T;
+        for (int t = t0 + rofs; t < t1; t += rif) {
+            const size_t off = ((size_t)bi * T + t) * C + col;
+            float yy[4], gg[4];
+            vload<4>(yy, y + off);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                gg[q] = (fmaf(av[q], yy[q], bv[q]) > 0.f) ? gp[q] * invT : 0.f;
+                s0[q] += gg[q];
+                s1[q] = fmaf(gg[q], (yy[q] - mv[q]) * iv[q], s1[q]);
+            }
+            vstore<4>(g + off, gg);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sm[rofs * C + col + q] = s0[q]; sm[(rif + rofs) * C + col + q] = s1[q]; }
+    }
+    __syncthreads();
+    const size_t pi = (size_t)bi * gridDim.x + blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float u = 0.f, v = 0.f;
+        for (int q = 0; q < rif; ++q) { u += sm[q * C + c]; v += sm[(rif + q) * C + c]; }
+        part[(pi * 2 + 0) * C + c] = u;
+        part[(pi * 2 + 1) * C + c] = v;
+    }
+}
+
+// dy = a * (g - [training] (dbeta + yhat*dgamma)/R) written into a per-sample zero-padded buffer
+// (B, pad + T + pad, C); the pad rows are zeroed here.  One thread per float4.
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                           const float* __restrict__ a, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ dbeta,
+                                                           const float* __restrict__ dgamma, float* __restrict__ dyp, int T, int C,
+                                                           int pad, long long n4, float invR, int training) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = C / 4;
+    const int col = (int)(i % c4) * 4;
+    const long long row = i / c4;                         // padded row index over all samples
+    const int Tp = T + 2 * pad;
+    const long long bi = row / Tp;
+    const int tp = (int)(row - bi * Tp);
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tp >= pad && tp < pad + T) {
+        const size_t off = ((size_t)bi * T + (tp - pad)) * C + col;
+        float gg[4], yy[4];
+        vload<4>(gg, g + off);
+        if (training) vload<4>(yy, y + off);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = col + q;
+            float t = gg[q];
+            if (training) t -= (dbeta[c] + (yy[q] - mean[c]) * invstd[c] * dgamma[c]) * invR;
+            out[q] = a[c] * t;
+        }
+    }
+    vstore<4>(dyp + i * 4, out);
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static int vec_width(int c) { return (c % 4 == 0) ? 4 : (c % 2 == 0) ? 2 : 1; }
+
+template <int EPI>
+static int launch_nt(const GemmNTArgs& a, int V, bool pro, hipStream_t s) {
+    const dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(256);
+#define IGN_NT(VV, PP) hipLaunchKernelGGL((clconv_nt_kernel<VV, PP, EPI>), grid, block, 0, s, a)
+    if (V == 4) { if (pro) IGN_NT(4, true); else IGN_NT(4, false); }
+    else if (V == 2) { if (pro) IGN_NT(2, true); else IGN_NT(2, false); }
+    else { if (pro) IGN_NT(1, true); else IGN_NT(1, false); }
+#undef IGN_NT
+    return ign_check_launch("clconv_nt_kernel");
+}
+
+extern "C" long long ign_clconv_mtiles(long long M) { return (M + TM - 1) / TM; }
+
+extern "C" int ign_clconv_pack_weights(const float* w_oik, float* wt_fwd, float* wt_dgrad, int Co, int Ci, int k, void* stream) {
+    if (!w_oik || !wt_fwd || Co <= 0 || Ci <= 0 || k <= 0) {
+        ign_set_error("ign_clconv_pack_weights: bad argument (Co=%d Ci=%d k=%d)", Co, Ci, k);
+        return IGN_E_ARG;
+    }
+    const long long n = (long long)Co * Ci * k;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oik, wt_fwd,
+                       wt_dgrad, Co, Ci, k);
+    return ign_check_launch("pack_weights_kernel");
+}
+
+extern "C" int ign_clconv_fwd(const float* x, const float* wt, const float* bias, const float* pro_a, const float* pro_b,
+                              float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream) {
+    static const char* who = "ign_clconv_fwd";
+    const int Tout = Tin - k + 1;
+    if (!x || !wt || !y || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || ((pro_a == nullptr) != (pro_b == nullptr))) {
+        ign_set_error("%s: bad argument (B=%d Tin=%d Ci=%d Co=%d k=%d)", who, B, Tin, Ci, Co, k);
+        return IGN_E_ARG;
+    }
+    const long long M = (long long)B * Tout;
+    if (M > 0x7fffffffLL / 2) { ign_set_error("%s: B*Tout = %lld rows exceed the 2^30 row index space", who, M); return IGN_E_TOOBIG; }
+    GemmNTArgs a{};
+    a.A = x; a.am = RowMap{Tout, 0, Ci, (long long)Tin * Ci}; a.K = k * Ci;
+    a.Bt = wt; a.ldb = k * Ci; a.C = y; a.M = (int)M; a.N = Co; a.bias = bias;
+    a.pro_a = pro_a; a.pro_b = pro_b; a.pro_c = Ci; a.part = stat_part;
+    a.mtiles = (int)((M + TM - 1) / TM); a.ntiles = (Co + TN - 1) / TN;
+    IgnScopedTimer tm("clconv_fwd", (hipStream_t)stream);
+    return launch_nt<EPI_BIAS_STATS>(a, vec_width(Ci), pro_a != nullptr, (hipStream_t)stream);
+}
+
+extern "C" int ign_clconv_dgrad(const float* dyp, const float* wt_dgrad, const float* y_in, const float* a_in, const float* b_in,
+                                const float* mean_in, const float* invstd_in, float* g_in, float* stat_part, int B, int Tin,
+                                int Ci, int Co, int k, void* stream) {
+    static const char* who = "ign_clconv_dgrad";
+    const int Tout = Tin - k + 1;
+    if (!dyp || !wt_dgrad || !y_in || !a_in || !b_in || !mean_in || !invstd_in || !g_in || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 ||
+        Tout <= 0) {
+        ign_set_error("%s: bad argument (B=%d Tin=%d Ci=%d Co=%d k=%d)", who, B, Tin, Ci, Co, k);
+        return IGN_E_ARG;
+    }
+    const long long M = (long long)B * Tin;
+    if (M > 0x7fffffffLL / 2) { ign_set_error("%s: B*Tin = %lld rows exceed the 2^30 row index space", who, M); return IGN_E_TOOBIG; }
+    GemmNTArgs a{};
+    // logical row (b, t) reads padded rows t .. t+k-1 of sample b: dz[b,t,ci] = sum_{jj,co} dyp[b,t+jj,co] W[co,ci,k-1-jj]
+    a.A = dyp; a.am = RowMap{Tin, 0, Co, (long long)(Tout + 2 * (k - 1)) * Co}; a.K = k * Co;
+    a.Bt = wt_dgrad; a.ldb = k * Co; a.C = g_in; a.M = (int)M; a.N = Ci;
+    a.part = stat_part; a.ey = y_in; a.ea = a_in; a.eb = b_in; a.emean = mean_in; a.einv = invstd_in;
+    a.mtiles = (int)((M + TM - 1) / TM); a.ntiles = (Ci + TN - 1) / TN;
+    IgnScopedTimer tm("clconv_dgrad", (hipStream_t)stream);
+    return launch_nt<EPI_MASK_STATS>(a, vec_width(Co), false, (hipStream_t)stream);
+}
+
+static int wgrad_splits(long long M, int tiles) {
+    long long s = (1024 + tiles - 1) / tiles;             // ~4 workgroups per CU in flight
+    const long long max_s = (M + 8 * KC - 1) / (8 * KC);  // at least 8 chunks per split
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+extern "C" size_t ign_clconv_wgrad_workspace_bytes(int B, int Tin, int Ci, int Co, int k) {
+    const int Tout = Tin - k + 1;
+    if (B <= 0 || Tout <= 0 || Ci <= 0 || Co <= 0) return 0;
+    const int tiles = ((Co + 127) / 128) * ((k * Ci + 127) / 128);
+    return (size_t)wgrad_splits((long long)B * Tout, tiles) * Co * k * Ci * sizeof(float);
+}
+
+extern "C" int ign_clconv_wgrad(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
+                                float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream) {
+    static const char* who = "ign_clconv_wgrad";
+    const int Tout = Tin - k + 1;
+    if (!dyp || !x || !dw_oik || !workspace || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || dy_pad < 0 ||
+        ((pro_a == nullptr) != (pro_b == nullptr))) {
+        ign_set_error("%s: bad argument (B=%d Tin=%d Ci=%d Co=%d k=%d pad=%d)", who, B, Tin, Ci, Co, k, dy_pad);
+        return IGN_E_ARG;
+    }
+    if (Co % 4) { ign_set_error("%s: Co=%d must be a multiple of 4", who, Co); return IGN_E_UNSUP; }
+    const long long M = (long long)B * Tout;
+    if (M > 0x7fffffffLL / 2) { ign_set_error("%s: B*Tout = %lld rows exceed the 2^30 row index space", who, M); return IGN_E_TOOBIG; }
+    hipStream_t s = (hipStream_t)stream;
+    GemmTNArgs a{};
+    a.P = dyp; a.pm = RowMap{Tout, dy_pad, Co, (long long)(Tout + 2 * dy_pad) * Co}; a.NP = Co;
+    a.Q = x; a.qm = RowMap{Tout, 0, Ci, (long long)Tin * Ci}; a.NQ = k * Ci;
+    a.pro_a = pro_a; a.pro_b = pro_b; a.pro_c = Ci;
+    a.part = (float*)workspace; a.M = (int)M;
+    a.ptiles = (Co + 127) / 128; a.qtiles = (k * Ci + 127) / 128;
+    a.nsplit = wgrad_splits(M, a.ptiles * a.qtiles);
+    const dim3 grid((unsigned)(a.ptiles * a.qtiles), (unsigned)a.nsplit), block(256);
+    const int V = vec_width(Ci);
+    const bool pro = pro_a != nullptr;
+    {
+        IgnScopedTimer tm("clconv_wgrad", s);
+#define IGN_TN(VV, PP) hipLaunchKernelGGL((clconv_tn_kernel<VV, PP>), grid, block, 0, s, a)
+        if (V == 4) { if (pro) IGN_TN(4, true); else IGN_TN(4, false); }
+        else if (V == 2) { if (pro) IGN_TN(2, true); else IGN_TN(2, false); }
+        else { if (pro) IGN_TN(1, true); else IGN_TN(1, false); }
+#undef IGN_TN
+    }
+    int rc;
+    if ((rc = ign_check_launch("clconv_tn_kernel"))) return rc;
+    const long long n = (long long)Co * Ci * k;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace, dw_oik,
+                       a.nsplit, Co, Ci, k);
+    return ign_check_launch("wgrad_reduce_kernel");
+}
+
+static int bn_check(const char* who, long long R, int C) {
+    if (R <= 0 || C <= 0 || (C & 3) || C > 1024) {
+        ign_set_error("%s: need R > 0 and 4 <= C <= 1024 with C %% 4 == 0 (R=%lld C=%d)", who, R, C);
+        return IGN_E_ARG;
+    }
+    return 0;
+}
+
+extern "C" int ign_bn_finalize_fwd(const float* part, int nparts, long long R, int C, const float* gamma, const float* beta,
+                                   float eps, float momentum, float* running_mean, float* running_var, float* a, float* b,
+                                   float* mean, float* invstd, void* stream) {
+    if (!part || nparts <= 0 || R <= 0 || C <= 0 || !gamma || !beta || !a || !b || !mean || !invstd) {
+        ign_set_error("ign_bn_finalize_fwd: bad argument");
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, nparts, R, C, gamma, beta,
+                       eps, momentum, running_mean, running_var, a, b, mean, invstd);
+    return ign_check_launch("bn_finalize_fwd_kernel");
+}
+
+extern "C" int ign_bn_affine_eval(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                                  float eps, int C, float* a, float* b, float* mean, float* invstd, void* stream) {
+    if (!running_mean || !running_var || !gamma || !beta || C <= 0 || !a || !b || !mean || !invstd) {
+        ign_set_error("ign_bn_affine_eval: bad argument");
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(bn_affine_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, running_mean, running_var,
+                       gamma, beta, eps, C, a, b, mean, invstd);
+    return ign_check_launch("bn_affine_eval_kernel");
+}
+
+extern "C" int ign_bn_finalize_bwd(const float* part, int nparts, int C, float* dbeta, float* dgamma, void* stream) {
+    if (!part || nparts <= 0 || C <= 0 || !dbeta || !dgamma) {
+        ign_set_error("ign_bn_finalize_bwd: bad argument");
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, nparts, C, dbeta, dgamma);
+    return ign_check_launch("bn_finalize_bwd_kernel");
+}
+
+extern "C" int ign_bn_relu_pool_fwd(const float* y, const float* a, const float* b, float* pooled, int B, int T, int C,
+                                    void* stream) {
+    int rc;
+    if ((rc = bn_check("ign_bn_relu_pool_fwd", (long long)B * T, C))) return rc;
+    if (!y || !a || !b || !pooled) { ign_set_error("ign_bn_relu_pool_fwd: null pointer"); return IGN_E_ARG; }
+    const int rif = 256 / (C / 4);
+    IgnScopedTimer tm("bn_relu_pool_fwd", (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(B), dim3(256), (size_t)rif * C * 4, (hipStream_t)stream, y, a, b, pooled, T, C);
+    return ign_check_launch("bn_relu_pool_fwd_kernel");
+}
+
+extern "C" long long ign_bn_relu_pool_bwd_parts(int B, int T) { return (long long)B * ((T + POOL_ROWS - 1) / POOL_ROWS); }
+
+extern "C" int ign_bn_relu_pool_bwd(const float* y, const float* gpool, const float* a, const float* b, const float* mean,
+                                    const float* invstd, float* g, float* part, int B, int T, int C, void* stream) {
+    int rc;
+    if ((rc = bn_check("ign_bn_relu_pool_bwd", (long long)B * T, C))) return rc;
+    if (!y || !gpool || !a || !b || !mean || !invstd || !g || !part) { ign_set_error("ign_bn_relu_pool_bwd: null pointer"); return IGN_E_ARG; }
+    const int rif = 256 / (C / 4);
+    IgnScopedTimer tm("bn_relu_pool_bwd", (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_relu_pool_bwd_kernel, dim3((T + POOL_ROWS - 1) / POOL_ROWS, B), dim3(256), (size_t)2 * rif * C * 4,
+                       (hipStream_t)stream, y, gpool, a, b, mean, invstd, g, part, T, C);
+    return ign_check_launch("bn_relu_pool_bwd_kernel");
+}
+
+extern "C" int ign_bn_bwd_apply(const float* g, const float* y, const float* a, const float* mean, const float* invstd,
+                                const float* dbeta, const float* dgamma, float* dyp, int B, int T, int C, int pad, int training,
+                                void* stream) {
+    int rc;
+    if ((rc = bn_check("ign_bn_bwd_apply", (long long)B * T, C))) return rc;
+    if (!g || !a || !dyp || pad < 0 || (training && (!y || !mean || !invstd || !dbeta || !dgamma))) {
+        ign_set_error("ign_bn_bwd_apply: null pointer / negative pad");
+        return IGN_E_ARG;
+    }
+    const long long n4 = (long long)B * (T + 2 * pad) * (C / 4);
+    IgnScopedTimer tm("bn_bwd_apply", (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, y, a, mean,
+                       invstd, dbeta, dgamma, dyp, T, C, pad, n4, 1.0f / (float)((long long)B * T), training);
+    return ign_check_launch("bn_bwd_apply_kernel");
+}

@@ -36,6 +36,19 @@ SIGNATURES = {
     "ign_dwconv1d_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "ign_dwconv1d_bwd_weight_workspace_bytes": (sz, [ci, ci, ci]),
     "ign_dwconv1d_bwd_weight": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ign_clconv_mtiles": (ll, [ll]),
+    "ign_clconv_pack_weights": (ci, [vp, vp, vp, ci, ci, ci, vp]),
+    "ign_clconv_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ign_clconv_dgrad": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ign_clconv_wgrad_workspace_bytes": (sz, [ci, ci, ci, ci, ci]),
+    "ign_clconv_wgrad": (ci, [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ign_bn_finalize_fwd": (ci, [vp, ci, ll, ci, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp, vp]),
+    "ign_bn_affine_eval": (ci, [vp, vp, vp, vp, cf, ci, vp, vp, vp, vp, vp]),
+    "ign_bn_relu_pool_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, vp]),
+    "ign_bn_relu_pool_bwd_parts": (ll, [ci, ci]),
+    "ign_bn_relu_pool_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
+    "ign_bn_finalize_bwd": (ci, [vp, ci, ci, vp, vp, vp]),
+    "ign_bn_bwd_apply": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ign_timing_enable": (ci, [ci]),
     "ign_timing_read": (ci, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
     "ign_shapelet_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),

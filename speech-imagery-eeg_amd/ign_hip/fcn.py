@@ -1,0 +1,177 @@
+"""The FCN expert's convolution stack as ONE autograd node over the channels-last implicit-GEMM kernels
+(include/ign_abi.h: ign_clconv_*, ign_bn_*; csrc/ign_clconv.hip).
+
+Replaces ``block1 -> block2 -> block3 -> AdaptiveAvgPool1d`` of IGN/model/FullyConvNet.py:31-57.  What reaches HBM per
+block is only the raw convolution output y_l (needed by the backward anyway): BatchNorm's statistics come out of the
+GEMM epilogue, its affine + ReLU are applied while the NEXT GEMM stages its operand, and the last block's
+BatchNorm + ReLU + average pool is one reduction pass.  Backward mirrors it: the data-gradient GEMM applies the ReLU
+mask of the block below and emits that block's BatchNorm-backward sums; one elementwise pass per block turns them
+into dL/dy (written zero-padded, the layout the GEMMs read); the weight-gradient GEMM recomputes relu(bn(y)) on the
+fly.  torch supplies memory and the autograd plumbing only.  There is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+DEBUG = None       # set to a dict to capture the backward intermediates (tests/diag_fcn.py)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class BnState:
+    """Non-tensor carrier for one block's BatchNorm1d buffers and mode (torch.nn.BatchNorm semantics: batch statistics
+    when training or when no running statistics are tracked; the running buffers are updated in place by
+    ign_bn_finalize_fwd only in training mode)."""
+
+    def __init__(self, bn):
+        self.eps = float(bn.eps)
+        self.use_batch_stats = bn.training or not bn.track_running_stats
+        self.running_mean = self.running_var = None
+        self.momentum = 0.0
+        if bn.track_running_stats:
+            self.running_mean, self.running_var = bn.running_mean, bn.running_var
+            if bn.training:
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked.add_(1)
+                self.momentum = float(bn.momentum) if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        self.update_running = bn.training and bn.track_running_stats
+
+
+class FcnBodyFn(torch.autograd.Function):
+    """forward(x (B,T,C), states, w1, b1, gamma1, beta1, w2, ..., beta3) -> pooled (B, C3)."""
+
+    @staticmethod
+    def forward(ctx, x, states, *params):
+        L = _lib.lib()
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise _lib.IgnError(f"fcn_body: needs a float32 GPU tensor, got {x.dtype} on {x.device} (no CPU fallback)")
+        x = x.contiguous()
+        B = x.shape[0]
+        nl = len(params) // 4
+        dev = x.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        need_grad = any(ctx.needs_input_grad[2:])
+        inputs, affine, wds, shapes = [x], [], [], []
+        pa = pb = None
+        for l in range(nl):
+            w, b, gamma, beta = (p.contiguous() for p in params[4 * l:4 * l + 4])
+            Co, Ci, k = w.shape
+            h = inputs[-1]
+            Tin = h.shape[1]
+            Tout = Tin - k + 1
+            if h.shape[2] != Ci or Tout <= 0 or Co % 4:
+                raise _lib.IgnError(f"fcn_body block {l + 1}: input {tuple(h.shape)} vs weight {tuple(w.shape)}")
+            wt = torch.empty(Co, k * Ci, **f32)
+            wd = torch.empty(Ci, k * Co, **f32) if (l > 0 and need_grad) else None
+            _lib.check(L.ign_clconv_pack_weights(_ptr(w), _ptr(wt), _ptr(wd), Co, Ci, k, _stream()), "ign_clconv_pack_weights")
+            st = states[l]
+            y = torch.empty(B, Tout, Co, **f32)
+            nparts = int(L.ign_clconv_mtiles(B * Tout))
+            part = torch.empty(nparts, 2, Co, **f32) if st.use_batch_stats else None
+            _lib.check(L.ign_clconv_fwd(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part), B, Tin, Ci, Co, k,
+                                        _stream()), "ign_clconv_fwd")
+            a, bb, mean, invstd = (torch.empty(Co, **f32) for _ in range(4))
+            if st.use_batch_stats:
+                _lib.check(L.ign_bn_finalize_fwd(_ptr(part), nparts, B * Tout, Co, _ptr(gamma), _ptr(beta), st.eps, st.momentum,
+                                                 _ptr(st.running_mean if st.update_running else None),
+                                                 _ptr(st.running_var if st.update_running else None), _ptr(a), _ptr(bb), _ptr(mean),
+                                                 _ptr(invstd), _stream()), "ign_bn_finalize_fwd")
+            else:
+                _lib.check(L.ign_bn_affine_eval(_ptr(st.running_mean), _ptr(st.running_var), _ptr(gamma), _ptr(beta), st.eps, Co,
+                                                _ptr(a), _ptr(bb), _ptr(mean), _ptr(invstd), _stream()), "ign_bn_affine_eval")
+            inputs.append(y)
+            affine.append((a, bb, mean, invstd))
+            wds.append(wd)
+            shapes.append((Co, Ci, k, Tin, Tout))
+            pa, pb = a, bb
+        y_last = inputs[-1]
+        Cl, Tl = y_last.shape[2], y_last.shape[1]
+        pooled = torch.empty(B, Cl, **f32)
+        _lib.check(L.ign_bn_relu_pool_fwd(_ptr(y_last), _ptr(pa), _ptr(pb), _ptr(pooled), B, Tl, Cl, _stream()),
+                   "ign_bn_relu_pool_fwd")
+        ctx.saved = (inputs, affine, wds, shapes, [st.use_batch_stats for st in states]) if need_grad else None
+        return pooled
+
+    @staticmethod
+    def backward(ctx, gpool):
+        if ctx.saved is None:
+            raise _lib.IgnError("fcn_body backward called but the forward ran without parameter gradients enabled")
+        if ctx.needs_input_grad[0]:
+            raise _lib.IgnError("fcn_body: gradient w.r.t. the input series is not implemented (inputs are data)")
+        L = _lib.lib()
+        inputs, affine, wds, shapes, batch_stats = ctx.saved
+        nl = len(shapes)
+        B = inputs[0].shape[0]
+        dev = gpool.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        gpool = gpool.contiguous()
+        grads = [None] * (4 * nl)
+
+        # last block: pool -> ReLU mask -> BatchNorm-backward sums
+        Co, Ci, k, Tin, Tout = shapes[-1]
+        a, bb, mean, invstd = affine[-1]
+        y = inputs[-1]
+        g = torch.empty_like(y)
+        nparts = int(L.ign_bn_relu_pool_bwd_parts(B, Tout))
+        part = torch.empty(nparts, 2, Co, **f32)
+        _lib.check(L.ign_bn_relu_pool_bwd(_ptr(y), _ptr(gpool), _ptr(a), _ptr(bb), _ptr(mean), _ptr(invstd), _ptr(g), _ptr(part),
+                                          B, Tout, Co, _stream()), "ign_bn_relu_pool_bwd")
+        for l in range(nl - 1, -1, -1):
+            Co, Ci, k, Tin, Tout = shapes[l]
+            a, bb, mean, invstd = affine[l]
+            y = inputs[l + 1]
+            dbeta, dgamma = torch.empty(Co, **f32), torch.empty(Co, **f32)
+            _lib.check(L.ign_bn_finalize_bwd(_ptr(part), nparts, Co, _ptr(dbeta), _ptr(dgamma), _stream()), "ign_bn_finalize_bwd")
+            pad = (k - 1) if l > 0 else 0
+            dyp = torch.empty(B, Tout + 2 * pad, Co, **f32)
+            training = 1 if batch_stats[l] else 0
+            _lib.check(L.ign_bn_bwd_apply(_ptr(g), _ptr(y), _ptr(a), _ptr(mean), _ptr(invstd), _ptr(dbeta), _ptr(dgamma), _ptr(dyp),
+                                          B, Tout, Co, pad, training, _stream()), "ign_bn_bwd_apply")
+            if DEBUG is not None:
+                DEBUG[f"g{l}"], DEBUG[f"dyp{l}"], DEBUG[f"dbeta{l}"], DEBUG[f"dgamma{l}"] = g.clone(), dyp.clone(), dbeta.clone(), dgamma.clone()
+            del g
+            # weight gradient; the operand below is relu(bn(y_{l-1})) recomputed on the fly (raw x for the first block)
+            pa, pb = (affine[l - 1][0], affine[l - 1][1]) if l > 0 else (None, None)
+            ws = torch.empty(int(L.ign_clconv_wgrad_workspace_bytes(B, Tin, Ci, Co, k)) // 4, **f32)
+            dw = torch.empty(Co, Ci, k, **f32)
+            _lib.check(L.ign_clconv_wgrad(_ptr(dyp), pad, _ptr(inputs[l]), _ptr(pa), _ptr(pb), _ptr(dw), _ptr(ws), B, Tin, Ci, Co, k,
+                                          _stream()), "ign_clconv_wgrad")
+            del ws
+            grads[4 * l + 0] = dw
+            # The bias in front of a batch-statistics BatchNorm has an identically zero gradient (the batch mean removes
+            # it); with running statistics it is the column sum of dL/dy.
+            grads[4 * l + 1] = torch.zeros(Co, **f32) if training else dyp.sum(dim=(0, 1))
+            grads[4 * l + 2] = dgamma
+            grads[4 * l + 3] = dbeta
+            if l > 0:
+                pa_, pb_, pm_, pi_ = affine[l - 1]
+                g = torch.empty(B, Tin, Ci, **f32)
+                nparts = int(L.ign_clconv_mtiles(B * Tin))
+                part = torch.empty(nparts, 2, Ci, **f32)
+                _lib.check(L.ign_clconv_dgrad(_ptr(dyp), _ptr(wds[l]), _ptr(inputs[l]), _ptr(pa_), _ptr(pb_), _ptr(pm_), _ptr(pi_),
+                                              _ptr(g), _ptr(part), B, Tin, Ci, Co, k, _stream()), "ign_clconv_dgrad")
+            del dyp
+        ctx.saved = None
+        return (None, None, *grads)
+
+
+def fcn_body(x, blocks):
+    """x (B,T,C) float32 on the GPU; blocks = [(conv1d, batchnorm1d), ...] -> pooled (B, C_last)."""
+    states = [BnState(bn) for _, bn in blocks]
+    params = []
+    for conv, bn in blocks:
+        if conv.bias is None or bn.weight is None or bn.bias is None:
+            raise _lib.IgnError("fcn_body: Conv1d needs a bias and BatchNorm1d needs affine parameters")
+        if conv.stride != (1,) or conv.padding != (0,) or conv.dilation != (1,) or conv.groups != 1:
+            raise _lib.IgnError("fcn_body: only stride-1, unpadded, undilated, ungrouped Conv1d is implemented")
+        params += [conv.weight, conv.bias, bn.weight, bn.bias]
+    return FcnBodyFn.apply(x, states, *params)

@@ -13,7 +13,12 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ign_hip import ops
+import os
+
+from ign_hip import fcn, ops
+
+# IGN_FCN_MIOPEN=1 routes the convolutions through torch's MIOpen backend instead (A/B measurements only)
+_USE_CLCONV = os.environ.get("IGN_FCN_MIOPEN", "0") != "1"
 
 
 class FullyConvNetwork(nn.Module):
@@ -38,9 +43,13 @@ class FullyConvNetwork(nn.Module):
 
     def forward(self, x, x_mark_enc=None, x_dec=None, x_mark_dec=None, mask=None, x_bct=None):
         if x.is_cuda and not torch.is_autocast_enabled():
-            h = x.permute(0, 2, 1).unsqueeze(2)                  # (B,C,1,T) view, channels-last strides, no copy
-            h = self._block(self.block3, self._block(self.block2, self._block(self.block1, h)))
-            pooled = h.mean(dim=(2, 3))
+            if _USE_CLCONV:
+                # x (B,T,C) is already the channels-last operand of the implicit GEMM: no transpose, no im2col
+                pooled = fcn.fcn_body(x, [(b[0], b[1]) for b in (self.block1, self.block2, self.block3)])
+            else:
+                h = x.permute(0, 2, 1).unsqueeze(2)              # (B,C,1,T) view, channels-last strides, no copy
+                h = self._block(self.block3, self._block(self.block2, self._block(self.block1, h)))
+                pooled = h.mean(dim=(2, 3))
         else:
             h = x_bct if x_bct is not None else x.permute(0, 2, 1)
             h = self.block3(self.block2(self.block1(h)))

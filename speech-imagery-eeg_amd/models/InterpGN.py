@@ -1,4 +1,6 @@
 """Interpretability-gated mixture of the SBM expert and a deep expert (IGN/model/InterpGN.py:13-66)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -26,6 +28,9 @@ dnn_dict = {
 }
 
 
+_SIDE_STREAMS = {}          # device -> HIP stream the deep expert runs on (see InterpGN._experts)
+
+
 def gini_gate(sbm_out, deep_out, gating_value=None):
     """eta = (N * sum softmax(sbm)^2 - 1) / (N - 1); out = eta*sbm + (1-eta)*dnn   (InterpGN.py:44-52).
     At test time ``gating_value`` snaps eta to 1 where it exceeds the threshold."""
@@ -45,9 +50,31 @@ class InterpGN(nn.Module):
         self.sbm = ShapeBottleneckModel(configs=configs, num_shapelet=num_shapelet, shapelet_len=shapelet_len)
         self.deep_model = dnn_dict[configs.dnn_type](configs)
 
-    def forward(self, x, x_mark_enc=None, x_dec=None, x_mark_dec=None, mask=None, gating_value=None):
+    # The two experts are independent until the gate and load different pipes of a CU: the shapelet kernels are
+    # fp32-VALU bound, the deep expert's convolutions / GEMMs MFMA bound, and a CDNA4 SIMD issues both at once
+    # (MI355X_MICROARCH.md, "Wave scheduling").  Running them on two HIP streams lets the matrix work hide under the
+    # vector work; autograd replays each backward node on its forward stream, so the backward overlaps the same way.
+    expert_streams = os.environ.get("IGN_EXPERT_STREAMS", "1") != "0"
+
+    def _experts(self, x, x_mark_enc, x_dec, x_mark_dec, mask):
+        if not (self.expert_streams and x.is_cuda):
+            sbm_out, info = self.sbm(x)
+            return sbm_out, info, self.deep_model(x, x_mark_enc, x_dec, x_mark_dec, mask)
+        main = torch.cuda.current_stream(x.device)
+        side = _SIDE_STREAMS.get(x.device)
+        if side is None:
+            side = _SIDE_STREAMS[x.device] = torch.cuda.Stream(x.device, priority=int(os.environ.get('IGN_SIDE_PRIO', '-1')))
+        side.wait_stream(main)                      # x and the parameters are ready
+        with torch.cuda.stream(side):
+            deep_out = self.deep_model(x, x_mark_enc, x_dec, x_mark_dec, mask)
+        x.record_stream(side)
         sbm_out, info = self.sbm(x)
-        deep_out = self.deep_model(x, x_mark_enc, x_dec, x_mark_dec, mask)
+        main.wait_stream(side)
+        deep_out.record_stream(main)
+        return sbm_out, info, deep_out
+
+    def forward(self, x, x_mark_enc=None, x_dec=None, x_mark_dec=None, mask=None, gating_value=None):
+        sbm_out, info, deep_out = self._experts(x, x_mark_enc, x_dec, x_mark_dec, mask)
         if torch.is_autocast_enabled():
             out, eta = gini_gate(sbm_out, deep_out, gating_value)
         else:

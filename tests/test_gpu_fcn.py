@@ -1,0 +1,254 @@
+"""GPU parity of the FCN expert's hand-written convolution stack (csrc/ign_clconv.hip through the C ABI):
+implicit-GEMM Conv1d forward / data gradient / weight gradient with the BatchNorm + ReLU prologues and epilogues,
+against a float64 torch reference of IGN/model/FullyConvNet.py:31-59 on the CPU.  Tolerance 1e-4 (north_star)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from conftest import make_cfg
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _s():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("B,T,Ci,Co,k,pro", [
+    (4, 100, 6, 128, 8, False),      # BasicMotions first block: float2 staging, K = 48
+    (3, 40, 3, 128, 3, False),       # odd channel count: scalar staging, K = 9 (one ragged chunk)
+    (2, 50, 7, 64, 2, False),        # N < tile, odd K
+    (2, 1000, 122, 128, 8, False),   # CHISCO first block
+    (2, 993, 128, 256, 5, True),     # second block with the BatchNorm+ReLU prologue, two n-tiles
+    (3, 77, 256, 128, 3, True),      # third block, ragged m-tiles
+    (5, 9, 128, 256, 3, True),       # seq_len <= 10 kernels
+])
+def test_clconv_fwd_matches_conv1d(B, T, Ci, Co, k, pro):
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B * 1000 + T + Ci + k)
+    x = torch.randn(B, T, Ci, generator=g)
+    w = torch.randn(Co, Ci, k, generator=g) / (Ci * k) ** 0.5
+    bias = torch.randn(Co, generator=g)
+    pa = (torch.rand(Ci, generator=g) + 0.5) if pro else None
+    pb = torch.randn(Ci, generator=g) * 0.3 if pro else None
+    xin = torch.relu(x.double() * pa.double() + pb.double()) if pro else x.double()
+    ref = F.conv1d(xin.permute(0, 2, 1), w.double(), bias.double()).permute(0, 2, 1)      # (B,Tout,Co)
+    Tout = T - k + 1
+    xd, wd_, bd = x.to(dev), w.to(dev), bias.to(dev)
+    pad, pbd = (pa.to(dev), pb.to(dev)) if pro else (None, None)
+    wt = torch.empty(Co, k * Ci, device=dev)
+    _lib.check(L.ign_clconv_pack_weights(_p(wd_), _p(wt), None, Co, Ci, k, _s()), "pack")
+    y = torch.full((B, Tout, Co), float("nan"), device=dev)
+    nparts = int(L.ign_clconv_mtiles(B * Tout))
+    part = torch.full((nparts, 2, Co), float("nan"), device=dev)
+    _lib.check(L.ign_clconv_fwd(_p(xd), _p(wt), _p(bd), _p(pad), _p(pbd), _p(y), _p(part), B, T, Ci, Co, k, _s()), "fwd")
+    assert _rel(y, ref) < TOL
+    # the BatchNorm statistics partials of the epilogue
+    s1 = part[:, 0].double().sum(0).cpu()
+    s2 = part[:, 1].double().sum(0).cpu()
+    assert float((s1 - ref.sum((0, 1))).abs().max() / ref.abs().sum((0, 1)).max()) < TOL
+    assert float((s2 - ref.square().sum((0, 1))).abs().max() / ref.square().sum((0, 1)).max()) < TOL
+
+
+def _ref_blocks(cfg_in, widths, ks, seed):
+    torch.manual_seed(seed)
+    blocks, ci = [], cfg_in
+    for co, k in zip(widths, ks):
+        blocks.append(nn.Sequential(nn.Conv1d(ci, co, k), nn.BatchNorm1d(co), nn.ReLU()))
+        ci = co
+    for b in blocks:                    # non-trivial affine / running state
+        with torch.no_grad():
+            b[1].weight.uniform_(0.5, 1.5)
+            b[1].bias.normal_(0, 0.3)
+            b[1].running_mean.normal_(0, 0.2)
+            b[1].running_var.uniform_(0.5, 2.0)
+    return nn.Sequential(*blocks)
+
+
+@pytest.mark.parametrize("B,T,C,widths,ks,training", [
+    (8, 100, 6, (128, 256, 128), (8, 5, 3), True),       # BasicMotions
+    (8, 100, 6, (128, 256, 128), (8, 5, 3), False),      # eval: running statistics
+    (4, 37, 3, (64, 128, 64), (3, 3, 2), True),          # odd channels, ragged tiles, short kernels
+    (2, 1000, 122, (128, 256, 128), (8, 5, 3), True),    # CHISCO shape (small batch)
+    (3, 61, 9, (128, 256, 128), (8, 5, 3), False),
+])
+def test_fcn_body_forward_backward(B, T, C, widths, ks, training):
+    dev = _dev()
+    import copy
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import fcn
+    ref = _ref_blocks(C, widths, ks, seed=B + T + C).double().train(training)
+    mod = copy.deepcopy(ref).float().to(dev).train(training)
+    g = torch.Generator().manual_seed(11 * T + C)
+    x = torch.randn(B, T, C, generator=g)
+    gp = torch.randn(B, widths[-1], generator=g)
+
+    # float64 reference, keeping the BatchNorm outputs: an element whose pre-activation is ~0 sits on the ReLU kink, where
+    # fp32 rounding may legitimately pick the other side than float64 (one such element moves a B=2 gradient by ~1e-2).
+    h = x.double().permute(0, 2, 1)
+    near = []
+    for blk in ref:
+        n = blk[1](blk[0](h))
+        near.append(int((n.abs() < 1e-5).sum()))
+        h = blk[2](n)
+    pooled_ref = h.mean(-1)
+    (pooled_ref * gp.double()).sum().backward()
+
+    pooled = fcn.fcn_body(x.to(dev), [(b[0], b[1]) for b in mod])
+    (pooled * gp.to(dev)).sum().backward()
+    assert _rel(pooled, pooled_ref) < TOL
+    top_kink = max([l for l, c in enumerate(near) if c] or [-1])      # blocks <= top_kink see the kink elements
+    for (n, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        if training and n.endswith("0.bias"):
+            # true gradient is zero (batch statistics remove the bias); both sides hold at most rounding noise
+            assert float(p.grad.abs().max()) <= 1e-4 * max(1.0, float(q.grad.abs().max())), n
+            continue
+        tol = 2 * TOL if int(n.split(".")[0]) > top_kink else 5e-2
+        assert _rel(p.grad, q.grad) < tol, (n, near)
+    for (n, p), (_, q) in zip(mod.named_buffers(), ref.named_buffers()):
+        if p.dtype.is_floating_point:
+            assert _rel(p, q) < TOL, n
+        else:
+            assert int(p) == int(q), n
+
+
+def _away_from_kink(y, a, b, margin=1e-3):
+    """Move pre-activations that are within `margin` of the ReLU kink away from it (keeps the test well-conditioned)."""
+    pre = y * a + b
+    bad = pre.abs() < margin
+    return torch.where(bad, y + 4 * margin / a, y)
+
+
+@pytest.mark.parametrize("B,Tin,Ci,Co,k", [(2, 989, 256, 128, 3), (2, 993, 128, 256, 5), (3, 50, 64, 128, 3), (1, 9, 128, 256, 2)])
+def test_clconv_dgrad_and_wgrad_kernels(B, Tin, Ci, Co, k):
+    """ign_clconv_dgrad (ReLU mask + BatchNorm-backward sums in the epilogue) and ign_clconv_wgrad (prologue recomputes
+    relu(bn(y))) against float64 autograd of the same maths, with pre-activations kept off the ReLU kink."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(Tin + Ci + k)
+    Tout = Tin - k + 1
+    a = torch.rand(Ci, generator=g) + 0.5
+    b = torch.randn(Ci, generator=g) * 0.3
+    mean = torch.randn(Ci, generator=g) * 0.2
+    invstd = torch.rand(Ci, generator=g) + 0.5
+    y_in = _away_from_kink(torch.randn(B, Tin, Ci, generator=g), a, b)
+    w = torch.randn(Co, Ci, k, generator=g) / (Ci * k) ** 0.5
+    dy = torch.randn(B, Tout, Co, generator=g)
+
+    yd = y_in.double().requires_grad_(True)
+    pre = yd * a.double() + b.double()
+    z = torch.relu(pre)
+    pre.retain_grad()
+    wdbl = w.double().requires_grad_(True)
+    out = F.conv1d(z.permute(0, 2, 1), wdbl).permute(0, 2, 1)
+    (out * dy.double()).sum().backward()
+    g_ref = pre.grad                                          # dL/dz masked by the ReLU
+    yhat = (y_in.double() - mean.double()) * invstd.double()
+    s1_ref, s2_ref = g_ref.sum((0, 1)), (g_ref * yhat).sum((0, 1))
+
+    pad = k - 1
+    dyp = torch.zeros(B, Tout + 2 * pad, Co)
+    dyp[:, pad:pad + Tout] = dy
+    to = lambda t: t.contiguous().to(dev)
+    dypd, yind, ad, bd, md, isd, wd_ = to(dyp), to(y_in), to(a), to(b), to(mean), to(invstd), to(w)
+    wt = torch.empty(Co, k * Ci, device=dev)
+    wdg = torch.empty(Ci, k * Co, device=dev)
+    _lib.check(L.ign_clconv_pack_weights(_p(wd_), _p(wt), _p(wdg), Co, Ci, k, _s()), "pack")
+    gin = torch.full((B, Tin, Ci), float("nan"), device=dev)
+    nparts = int(L.ign_clconv_mtiles(B * Tin))
+    part = torch.full((nparts, 2, Ci), float("nan"), device=dev)
+    _lib.check(L.ign_clconv_dgrad(_p(dypd), _p(wdg), _p(yind), _p(ad), _p(bd), _p(md), _p(isd), _p(gin), _p(part),
+                                  B, Tin, Ci, Co, k, _s()), "dgrad")
+    assert _rel(gin, g_ref) < TOL
+    assert _rel(part[:, 0].double().sum(0), s1_ref) < TOL and _rel(part[:, 1].double().sum(0), s2_ref) < TOL
+
+    ws = torch.empty(int(L.ign_clconv_wgrad_workspace_bytes(B, Tin, Ci, Co, k)) // 4, device=dev)
+    dw = torch.full((Co, Ci, k), float("nan"), device=dev)
+    _lib.check(L.ign_clconv_wgrad(_p(dypd), pad, _p(yind), _p(ad), _p(bd), _p(dw), _p(ws), B, Tin, Ci, Co, k, _s()), "wgrad")
+    assert _rel(dw, wdbl.grad) < TOL
+
+
+def test_fcn_body_is_deterministic_and_matches_full_batch_shape():
+    """Bitwise reproducibility at the benchmark shape (fixed-order reductions everywhere: no float atomics), plus a
+    size-independent property: the pooled feature of a sample does not depend on which other samples share the batch
+    when the statistics are frozen (eval mode)."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import fcn
+    mod = _ref_blocks(122, (128, 256, 128), (8, 5, 3), seed=5).to(dev).train()
+    x = torch.randn(16, 1000, 122, generator=torch.Generator().manual_seed(3)).to(dev)
+    blocks = [(b[0], b[1]) for b in mod]
+    outs, grads = [], []
+    for _ in range(2):
+        mod.zero_grad(set_to_none=True)
+        p = fcn.fcn_body(x, blocks)
+        p.square().sum().backward()
+        outs.append(p.detach().clone())
+        grads.append([q.grad.clone() for q in mod.parameters()])
+    assert torch.equal(outs[0], outs[1])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+    mod.eval()
+    with torch.no_grad():
+        full = fcn.fcn_body(x, blocks)
+        half = fcn.fcn_body(x[5:9].contiguous(), blocks)
+    assert _rel(half, full[5:9]) < 1e-6
+
+
+def test_fcn_model_refuses_nothing_it_supports_and_matches_miopen_path():
+    """The drop-in FullyConvNetwork on the new kernels vs the same module on torch's own GPU convolutions."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    import models.FullyConvNet as M
+    cfg = make_cfg(enc_in=6, seq_len=100, num_class=4)
+    torch.manual_seed(0)
+    net = M.FullyConvNetwork(cfg).to(dev).train()
+    x = torch.randn(8, 100, 6, generator=torch.Generator().manual_seed(1)).to(dev)
+    y = torch.arange(8, device=dev) % 4
+    res = {}
+    for flag in (True, False):
+        M._USE_CLCONV = flag
+        try:
+            net.zero_grad(set_to_none=True)
+            sd = {k: v.clone() for k, v in net.state_dict().items()}
+            out = net(x)
+            F.cross_entropy(out, y).backward()
+            res[flag] = (out.detach().clone(), [p.grad.clone() for p in net.parameters()],
+                         {k: v.clone() for k, v in net.state_dict().items()})
+            net.load_state_dict(sd)
+        finally:
+            M._USE_CLCONV = True
+    assert _rel(res[True][0], res[False][0]) < TOL
+    for (n, _), a, b in zip(net.named_parameters(), res[True][1], res[False][1]):
+        if n.endswith("0.bias") and "fc" not in n:
+            continue
+        assert _rel(a, b) < 5 * TOL, n
+    for k in res[True][2]:
+        if "running" in k:
+            assert _rel(res[True][2][k], res[False][2][k]) < TOL, k
