@@ -397,27 +397,44 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm glue
+// Sum of the per-tile partials (nparts, 2, C) for 32 channels per block: 32 slices of the partials are summed in
+// parallel (ascending inside a slice), then the 32 slice sums are combined in fixed order in double.
+__device__ __forceinline__ void bn_sum_partials(const float* __restrict__ part, int nparts, int C, double* s_out, double* q_out) {
+    __shared__ double sh[2][32][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        const int per = (nparts + 31) / 32;
+        const int i0 = sl * per, i1 = min(nparts, i0 + per);
+        float fs = 0.f, fq = 0.f;              // <= 64 addends of like magnitude per slice in fp32, slices combined in double
+        int n = 0;
+        for (int i = i0; i < i1; ++i) {
+            fs += part[((size_t)i * 2 + 0) * C + c];
+            fq += part[((size_t)i * 2 + 1) * C + c];
+            if (++n == 64) { s += (double)fs; q += (double)fq; fs = fq = 0.f; n = 0; }
+        }
+        s += (double)fs; q += (double)fq;
+    }
+    sh[0][sl][cl] = s;
+    sh[1][sl][cl] = q;
+    __syncthreads();
+    s = q = 0.0;
+    if (sl == 0) {
+        for (int k = 0; k < 32; ++k) { s += sh[0][k][cl]; q += sh[1][k][cl]; }
+    }
+    *s_out = s; *q_out = q;
+}
+
 // forward finalize: mean, biased var -> a = gamma*invstd, b = beta - a*mean; running stats (unbiased var).
-// part is (nparts, 2, C): per-tile sum and sum of squares, combined in double in tile order.
-__global__ void bn_finalize_fwd_kernel(const float* __restrict__ part, int nparts, long long R, int C,
+__global__ void __launch_bounds__(1024) bn_finalize_fwd_kernel(const float* __restrict__ part, int nparts, long long R, int C,
                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                        float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ a,
                                        float* __restrict__ b, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int sl = threadIdx.x >> 6;                     // 4 slices of the partials per channel
-    __shared__ double sh[2][4][64];
-    double s = 0.0, q = 0.0;
-    if (c < C) {
-        const int per = (nparts + 3) / 4;
-        const int i0 = sl * per, i1 = min(nparts, i0 + per);
-        for (int i = i0; i < i1; ++i) { s += (double)part[((size_t)i * 2 + 0) * C + c]; q += (double)part[((size_t)i * 2 + 1) * C + c]; }
-    }
-    sh[0][sl][threadIdx.x & 63] = s;
-    sh[1][sl][threadIdx.x & 63] = q;
-    __syncthreads();
-    if (sl != 0 || c >= C) return;
-    s = sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x] + sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x];
-    q = sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x] + sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x];
+    double s, q;
+    bn_sum_partials(part, nparts, C, &s, &q);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) != 0 || c >= C) return;
     const double m = s / (double)R;
     double var = q / (double)R - m * m;
     if (var < 0.0) var = 0.0;
@@ -448,23 +465,14 @@ __global__ void bn_affine_eval_kernel(const float* __restrict__ run_mean, const 
     invstd_out[c] = inv;
 }
 
-__global__ void bn_finalize_bwd_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dbeta,
-                                       float* __restrict__ dgamma) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int sl = threadIdx.x >> 6;
-    __shared__ double sh[2][4][64];
-    double s = 0.0, q = 0.0;
-    if (c < C) {
-        const int per = (nparts + 3) / 4;
-        const int i0 = sl * per, i1 = min(nparts, i0 + per);
-        for (int i = i0; i < i1; ++i) { s += (double)part[((size_t)i * 2 + 0) * C + c]; q += (double)part[((size_t)i * 2 + 1) * C + c]; }
-    }
-    sh[0][sl][threadIdx.x & 63] = s;
-    sh[1][sl][threadIdx.x & 63] = q;
-    __syncthreads();
-    if (sl != 0 || c >= C) return;
-    dbeta[c] = (float)(sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x] + sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
-    dgamma[c] = (float)(sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x] + sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
+__global__ void __launch_bounds__(1024) bn_finalize_bwd_kernel(const float* __restrict__ part, int nparts, int C,
+                                                               float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    double s, q;
+    bn_sum_partials(part, nparts, C, &s, &q);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) != 0 || c >= C) return;
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
 }
 
 // Global average pool of relu(a*y + b) over time:  pooled[b][c] = (1/T) sum_t max(a_c*y[b,t,c] + b_c, 0).
@@ -540,36 +548,49 @@ __global__ void __launch_bounds__(256) bn_relu_pool_bwd_kernel(const float* __re
     }
 }
 
-// dy = a * (g - [training] (dbeta + yhat*dgamma)/R) written into a per-sample zero-padded buffer
-// (B, pad + T + pad, C); the pad rows are zeroed here.  One thread per float4.
+// dy = a * (g - [training] (dbeta + yhat*dgamma)/R) = a*g + c1*y + c0 written into a per-sample zero-padded buffer
+// (B, pad + T + pad, C); the pad rows are zeroed here.  Thread <-> (row lane, 4 channels): the three per-channel
+// coefficients are formed once per thread, then the block walks APPLY_ROWS padded rows.
+constexpr int APPLY_ROWS = 64;
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                                            const float* __restrict__ a, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ dbeta,
                                                            const float* __restrict__ dgamma, float* __restrict__ dyp, int T, int C,
-                                                           int pad, long long n4, float invR, int training) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const int c4 = C / 4;
-    const int col = (int)(i % c4) * 4;
-    const long long row = i / c4;                         // padded row index over all samples
-    const int Tp = T + 2 * pad;
-    const long long bi = row / Tp;
-    const int tp = (int)(row - bi * Tp);
-    float out[4] = {0.f, 0.f, 0.f, 0.f};
-    if (tp >= pad && tp < pad + T) {
-        const size_t off = ((size_t)bi * T + (tp - pad)) * C + col;
-        float gg[4], yy[4];
-        vload<4>(gg, g + off);
-        if (training) vload<4>(yy, y + off);
+                                                           int pad, long long rows_padded, float invR, int training) {
+    const int c4 = C / 4, rif = 256 / c4;
+    const int col = (threadIdx.x % c4) * 4, rofs = threadIdx.x / c4;
+    if (rofs >= rif) return;
+    float ca[4], c1[4], c0[4];
+    vload<4>(ca, a + col);
+    if (training) {
+        float mv[4], iv[4], db[4], dg[4];
+        vload<4>(mv, mean + col); vload<4>(iv, invstd + col); vload<4>(db, dbeta + col); vload<4>(dg, dgamma + col);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int c = col + q;
-            float t = gg[q];
-            if (training) t -= (dbeta[c] + (yy[q] - mean[c]) * invstd[c] * dgamma[c]) * invR;
-            out[q] = a[c] * t;
+            c1[q] = -ca[q] * iv[q] * dg[q] * invR;
+            c0[q] = -ca[q] * (db[q] - mv[q] * iv[q] * dg[q]) * invR;
         }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c1[q] = c0[q] = 0.f;
     }
-    vstore<4>(dyp + i * 4, out);
+    const int Tp = T + 2 * pad;
+    const long long r0 = (long long)blockIdx.x * APPLY_ROWS;
+    const long long r1 = min(rows_padded, r0 + APPLY_ROWS);
+    for (long long row = r0 + rofs; row < r1; row += rif) {
+        const long long bi = row / Tp;
+        const int tp = (int)(row - bi * Tp);
+        float out[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tp >= pad && tp < pad + T) {
+            const size_t off = ((size_t)bi * T + (tp - pad)) * C + col;
+            float gg[4], yy[4] = {0.f, 0.f, 0.f, 0.f};
+            vload<4>(gg, g + off);
+            if (training) vload<4>(yy, y + off);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[q] = fmaf(ca[q], gg[q], fmaf(c1[q], yy[q], c0[q]));
+        }
+        vstore<4>(dyp + (size_t)row * C + col, out);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -709,7 +730,7 @@ extern "C" int ign_bn_finalize_fwd(const float* part, int nparts, long long R, i
         ign_set_error("ign_bn_finalize_fwd: bad argument");
         return IGN_E_ARG;
     }
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, nparts, R, C, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, nparts, R, C, gamma, beta,
                        eps, momentum, running_mean, running_var, a, b, mean, invstd);
     return ign_check_launch("bn_finalize_fwd_kernel");
 }
@@ -730,7 +751,7 @@ extern "C" int ign_bn_finalize_bwd(const float* part, int nparts, int C, float* 
         ign_set_error("ign_bn_finalize_bwd: bad argument");
         return IGN_E_ARG;
     }
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, nparts, C, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, nparts, C, dbeta, dgamma);
     return ign_check_launch("bn_finalize_bwd_kernel");
 }
 
@@ -768,9 +789,9 @@ extern "C" int ign_bn_bwd_apply(const float* g, const float* y, const float* a, 
         ign_set_error("ign_bn_bwd_apply: null pointer / negative pad");
         return IGN_E_ARG;
     }
-    const long long n4 = (long long)B * (T + 2 * pad) * (C / 4);
+    const long long rows = (long long)B * (T + 2 * pad);
     IgnScopedTimer tm("bn_bwd_apply", (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, y, a, mean,
-                       invstd, dbeta, dgamma, dyp, T, C, pad, n4, 1.0f / (float)((long long)B * T), training);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((rows + APPLY_ROWS - 1) / APPLY_ROWS)), dim3(256), 0, (hipStream_t)stream,
+                       g, y, a, mean, invstd, dbeta, dgamma, dyp, T, C, pad, rows, 1.0f / (float)((long long)B * T), training);
     return ign_check_launch("bn_bwd_apply_kernel");
 }
