@@ -5,8 +5,8 @@
   python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A step = one optimizer step of the training hot path (IGN/exp/experiment_classification.py:313-343) on one
-batch per rank: instance norm -> shapelet bank (HIP) -> SBM head + FCN expert -> gini gate -> 3-term loss ->
-backward (HIP shapelet backward) -> gradient all-reduce over RCCL (N>1) -> Adam.  Inputs are resident in HBM
+batch per rank: instance norm -> shapelet bank (HIP) -> SBM head || FCN expert (implicit-GEMM conv kernels, second HIP
+stream) -> gini gate -> 3-term loss -> backward (HIP shapelet / conv backward) -> gradient all-reduce over RCCL (N>1) -> Adam.  Inputs are resident in HBM
 before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--iso-steps", type=int, default=8, help="steps of the serial (one-stream) pass that measures isolated "
+                    "kernel durations for the roofline object")
     ap.add_argument("--cpu-sample", type=int, default=4, help="samples for the CPU baseline step (0 = skip)")
     ap.add_argument("--config", choices=["ign", "eegcnn", "transformer"], default="ign",
                     help="ign = BASELINE.json's headline (config 1 / 5); eegcnn / transformer = the baselines of "
@@ -191,6 +193,27 @@ def main():
     fwd_ms, fwd_n = _lib.timing_read("shp_fwd")
     bwd_ms, bwd_n = _lib.timing_read("shp_bwd")
 
+    # Kernel durations free of co-running kernels: in the timed region the two experts of IGN run on two HIP streams, so
+    # a kernel's event bracket also contains the time it shared the CUs with the other expert.  A short serial pass
+    # (same step, one stream) right after the timed region gives the isolated durations the roofline fractions refer to.
+    iso = {}
+    if args.config == "ign":
+        from models.InterpGN import InterpGN as _IGN
+        was = _IGN.expert_streams
+        _IGN.expert_streams = False
+        try:
+            step(0)
+            torch.cuda.synchronize()
+            _lib.timing_enable(True)                 # resets the registry
+            for i in range(args.iso_steps):
+                step(args.warmup + i)
+            torch.cuda.synchronize()
+            for lab in ("shp_fwd", "shp_bwd", "clconv_fwd", "clconv_dgrad", "clconv_wgrad"):
+                ms, n = _lib.timing_read(lab)
+                iso[lab] = (ms / max(1, args.iso_steps), n // max(1, args.iso_steps))
+        finally:
+            _IGN.expert_streams = was
+
     attn = {k: _lib.timing_read(k) for k in ("attn_fwd", "attn_bwd_dkdv", "attn_bwd_dq")} if args.config != "ign" else {}
     if rank == 0:
         res = {
@@ -222,9 +245,29 @@ def main():
             res["roofline"] = {"bound": "valu", "kernel": "shp_bwd_kernel", "achieved": bwd_tflops,
                                "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": bwd_tflops / PEAK_FP32_VALU_TFLOPS,
                                "traffic": traffic, "ms_per_step": bwd_ms / max(1, args.steps), "launches": bwd_n,
+                               "note": "timed region = two HIP streams (SBM expert || FCN expert): these brackets include "
+                                       "time shared with the other expert's kernels; 'isolated' = the same kernels in a "
+                                       "serial pass of --iso-steps steps right after the timed region",
                                "fwd_kernel": {"kernel": "shp_fwd_kernel", "achieved": fwd_tflops,
                                               "frac": fwd_tflops / PEAK_FP32_VALU_TFLOPS,
                                               "ms_per_step": fwd_ms / max(1, args.steps), "launches": fwd_n}}
+            if iso:
+                def _tf(flops, ms):
+                    return flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                fcn_f = 2.0 * B * (993 * 128 * 976 + 989 * 256 * 640 + 987 * 128 * 768)
+                fcn_d = 2.0 * B * (993 * 128 * 1280 + 989 * 256 * 384)                          # data gradients of blocks 3, 2
+                res["roofline"]["isolated"] = {
+                    "shp_bwd_kernel": {"ms_per_step": iso["shp_bwd"][0], "achieved": _tf(f_bwd, iso["shp_bwd"][0]),
+                                       "frac": _tf(f_bwd, iso["shp_bwd"][0]) / PEAK_FP32_VALU_TFLOPS},
+                    "shp_fwd_kernel": {"ms_per_step": iso["shp_fwd"][0], "achieved": _tf(f_fwd, iso["shp_fwd"][0]),
+                                       "frac": _tf(f_fwd, iso["shp_fwd"][0]) / PEAK_FP32_VALU_TFLOPS},
+                    "clconv_fwd (mfma)": {"ms_per_step": iso["clconv_fwd"][0], "achieved": _tf(fcn_f, iso["clconv_fwd"][0]),
+                                          "frac": _tf(fcn_f, iso["clconv_fwd"][0]) / 157.3},
+                    "clconv_dgrad (mfma)": {"ms_per_step": iso["clconv_dgrad"][0], "achieved": _tf(fcn_d, iso["clconv_dgrad"][0]),
+                                            "frac": _tf(fcn_d, iso["clconv_dgrad"][0]) / 157.3},
+                    "clconv_wgrad (mfma)": {"ms_per_step": iso["clconv_wgrad"][0], "achieved": _tf(fcn_f, iso["clconv_wgrad"][0]),
+                                            "frac": _tf(fcn_f, iso["clconv_wgrad"][0]) / 157.3},
+                    "steps": args.iso_steps}
         else:
             # attention core: fwd 4*B*H*L*S*E flop per layer (QK^T + PV); the two backward kernels execute 7 products
             # (S and dP are recomputed for dQ) but the ALGORITHMIC count is 5 products = 2.5x forward.

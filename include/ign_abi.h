@@ -171,6 +171,20 @@ int ign_clconv_fwd(const float* x, const float* wt_fwd, const float* bias, const
 int ign_clconv_dgrad(const float* dyp, const float* wt_dgrad, const float* y_in, const float* a_in, const float* b_in,
                      const float* mean_in, const float* invstd_in, float* g_in, float* stat_part,
                      int B, int Tin, int Ci, int Co, int k, void* stream);
+/* Split-bf16 ("x6") variants of fwd / dgrad: the same maths at fp32 rounding-level accuracy on the bf16 matrix cores.
+ * gfx950 executes fp32-input MFMA at the fp32 vector rate; here every fp32 operand is split exactly into three bf16 terms
+ * and the six partial products of weight >= 2^-16 are accumulated in fp32 (v_mfma_f32_32x32x16_bf16): 2.7x the fp32-MFMA
+ * throughput, error vs float64 at the level of fp32 accumulation (tests/test_gpu_fcn.py).  The weights arrive pre-split:
+ * ign_clconv_pack_weights_x3 writes wt3_fwd (3, Co, Kp) and (if not NULL) wt3_dgrad (3, Ci, Kp') as bf16 planes with row
+ * pitch Kp = ign_clconv_kpad(k*Ci) resp. Kp' = ign_clconv_kpad(k*Co) (zero tail).  Activations stay fp32 in HBM and are split
+ * while they are staged into LDS.                                                                                      */
+int ign_clconv_kpad(int K);
+int ign_clconv_pack_weights_x3(const float* w_oik, void* wt3_fwd, void* wt3_dgrad, int Co, int Ci, int k, void* stream);
+int ign_clconv_fwd_x6(const float* x, const void* wt3_fwd, const float* bias, const float* pro_a, const float* pro_b,
+                      float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream);
+int ign_clconv_dgrad_x6(const float* dyp, const void* wt3_dgrad, const float* y_in, const float* a_in, const float* b_in,
+                        const float* mean_in, const float* invstd_in, float* g_in, float* stat_part,
+                        int B, int Tin, int Ci, int Co, int k, void* stream);
 size_t ign_clconv_wgrad_workspace_bytes(int B, int Tin, int Ci, int Co, int k);
 int ign_clconv_wgrad(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
                      float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream);

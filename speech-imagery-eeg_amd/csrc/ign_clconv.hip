@@ -71,7 +71,66 @@ struct GemmNTArgs {
     // EPI_MASK_STATS: g = acc * [ea*y + eb > 0]; partials of g and g*(y - mean)*invstd
     const float* ey; const float* ea; const float* eb; const float* emean; const float* einv;
     int mtiles, ntiles;
+    const unsigned short* B3; int Kp;          // split-bf16 kernels: Bt as 3 bf16 planes (3, N, Kp), Kp = K rounded up to 8
 };
+
+// ---- epilogue shared by the fp32 and the split-bf16 kernels.  Lane (l31, h) of accumulator (i, j) holds column
+// n = n0 + wn*64 + j*32 + l31 and the 16 rows m0 + wm*64 + i*32 + acc_row16(r, h).  `red` is >= 512 floats of LDS that no
+// wave still reads.
+template <int EPI>
+__device__ __forceinline__ void nt_epilogue(const GemmNTArgs& a, const f32x16 (&acc)[2][2], float* red, int mt, int m0, int n0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        const bool n_ok = n < a.N;
+        const int nc = n_ok ? n : a.N - 1;
+        const float bv = (EPI == EPI_BIAS_STATS && a.bias) ? a.bias[nc] : 0.f;
+        float ea = 0.f, eb = 0.f, em = 0.f, ei = 0.f;
+        if (EPI == EPI_MASK_STATS) { ea = a.ea[nc]; eb = a.eb[nc]; em = a.emean[nc]; ei = a.einv[nc]; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + acc_row16(r, h);
+                const bool ok = n_ok && m < a.M;
+                float v = acc[i][j][r];
+                if (EPI == EPI_BIAS_STATS) {
+                    v += bv;
+                    if (ok) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+                } else {
+                    const float yv = ok ? a.ey[(long long)m * a.N + n] : 0.f;
+                    v = (fmaf(ea, yv, eb) > 0.f) ? v : 0.f;
+                    if (ok) { s1[j] += v; s2[j] = fmaf(v, (yv - em) * ei, s2[j]); }
+                }
+                if (ok) a.C[(long long)m * a.N + n] = v;
+            }
+        }
+    }
+    if (a.part) {
+        // combine the lane halves, then the two waves that share these columns, in a fixed order
+        // red: [2 (wm)][2 (stat)][128 (col)]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32, 64);
+            s2[j] += __shfl_xor(s2[j], 32, 64);
+            if (h == 0) {
+                const int col = wn * 64 + j * 32 + l31;
+                red[(wm * 2 + 0) * TN + col] = s1[j];
+                red[(wm * 2 + 1) * TN + col] = s2[j];
+            }
+        }
+        __syncthreads();
+        if (tid < TN && n0 + tid < a.N) {
+            a.part[((long long)mt * 2 + 0) * a.N + n0 + tid] = red[0 * TN + tid] + red[2 * TN + tid];
+            a.part[((long long)mt * 2 + 1) * a.N + n0 + tid] = red[1 * TN + tid] + red[3 * TN + tid];
+        }
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------ NT GEMM
 template <int V, bool PRO, int EPI>
@@ -185,55 +244,172 @@ __global__ void __launch_bounds__(256, 2) clconv_nt_kernel(const GemmNTArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue.  Lane (l31, h) of accumulator (i, j) holds column n = n0 + wn*64 + j*32 + l31 and the 16 rows
-    // m0 + wm*64 + i*32 + acc_row16(r, h).
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + l31;
-        const bool n_ok = n < a.N;
-        const int nc = n_ok ? n : a.N - 1;
-        const float bv = (EPI == EPI_BIAS_STATS && a.bias) ? a.bias[nc] : 0.f;
-        float ea = 0.f, eb = 0.f, em = 0.f, ei = 0.f;
-        if (EPI == EPI_MASK_STATS) { ea = a.ea[nc]; eb = a.eb[nc]; em = a.emean[nc]; ei = a.einv[nc]; }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + acc_row16(r, h);
-                const bool ok = n_ok && m < a.M;
-                float v = acc[i][j][r];
-                if (EPI == EPI_BIAS_STATS) {
-                    v += bv;
-                    if (ok) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
-                } else {
-                    const float yv = ok ? a.ey[(long long)m * a.N + n] : 0.f;
-                    v = (fmaf(ea, yv, eb) > 0.f) ? v : 0.f;
-                    if (ok) { s1[j] += v; s2[j] = fmaf(v, (yv - em) * ei, s2[j]); }
-                }
-                if (ok) a.C[(long long)m * a.N + n] = v;
-            }
-        }
+    nt_epilogue<EPI>(a, acc, smem[0], mt, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------ NT GEMM, split bf16
+// fp32-accurate product on the bf16 matrix cores.  gfx950 runs v_mfma_f32_32x32x2_f32 at the fp32 VECTOR rate
+// (64 FLOP/clk/SIMD, 157 TFLOP/s) -- the real matrix throughput is behind the 16-bit inputs (1024 FLOP/clk/SIMD).
+// Each fp32 operand is split exactly into three bf16 terms x = x0 + x1 + x2 (8 significant bits each, round-to-nearest;
+// the residuals are exact fp32 subtractions) and the product keeps the six terms of weight >= 2^-16,
+//     a*b ~= a0*b0 + (a0*b1 + a1*b0) + (a0*b2 + a1*b1 + a2*b0),        dropped: O(2^-24 |a b|),
+// every partial product exact (8 x 8 bits) and accumulated in fp32 by v_mfma_f32_32x32x16_bf16: 6 MFMAs of 16x the
+// rate = 2.7x the fp32-MFMA throughput at fp32 rounding-level error (measured against float64 in tests/test_gpu_fcn.py).
+// The activation operand is split while it is staged (after the BatchNorm+ReLU prologue); the weights arrive pre-split
+// (ign_clconv_pack_weights_x3).  LDS: 6 planes of [128 rows][16 k + 8 pad] bf16 per stage, double-buffered (72 KB).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int X6_PITCH = KC + 8;             // bf16 per staged row: 48 B, 12*i mod 64 dwords is conflict-free for b128 reads
+constexpr int X6_PLANE = TM * X6_PITCH;      // bf16 per plane per stage
+constexpr int X6_STAGE = 6 * X6_PLANE;       // A planes 0..2, B planes 3..5
+constexpr size_t X6_LDS_BYTES = (size_t)2 * X6_STAGE * sizeof(unsigned short);
+
+__device__ __forceinline__ void split3(float v, __bf16& x0, __bf16& x1, __bf16& x2) {
+    x0 = (__bf16)v;
+    float r = v - (float)x0;
+    x1 = (__bf16)r;
+    r -= (float)x1;
+    x2 = (__bf16)r;
+}
+
+template <int V, bool PRO, int EPI>
+__global__ void __launch_bounds__(256, 2) clconv_nt_x6_kernel(const GemmNTArgs a) {
+    constexpr int VPR = KC / V, RPP = 256 / VPR, NPASS = TM / RPP;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    __bf16* smem = reinterpret_cast<__bf16*>(smem16);
+
+    const int nwg = a.mtiles * a.ntiles;
+    int lid = blockIdx.x;
+    {
+        const int per = nwg / 8;
+        if (lid < per * 8) lid = (lid & 7) * per + (lid >> 3);
     }
-    if (a.part) {
-        // combine the lane halves, then the two waves that share these columns, in a fixed order
-        float* red = smem[0];                  // [2 (wm)][2 (stat)][128 (col)]
+    const int mt = lid / a.ntiles, nt = lid - mt * a.ntiles;
+    const int m0 = mt * TM, n0 = nt * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    const int sq = tid % VPR, sr = tid / VPR;
+    const float* arow[NPASS];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            s1[j] += __shfl_xor(s1[j], 32, 64);
-            s2[j] += __shfl_xor(s2[j], 32, 64);
-            if (h == 0) {
-                const int col = wn * 64 + j * 32 + l31;
-                red[(wm * 2 + 0) * TN + col] = s1[j];
-                red[(wm * 2 + 1) * TN + col] = s2[j];
+    for (int p = 0; p < NPASS; ++p) arow[p] = a.A + row_off(a.am, min(m0 + sr + p * RPP, a.M - 1)) + sq * V;
+    // B planes: thread <-> (row tid/2, 8-element half tid&1)
+    const int brw = tid >> 1, bh = tid & 1;
+    const unsigned short* bsrc = a.B3 + (size_t)min(n0 + brw, a.N - 1) * a.Kp + 8 * bh;
+    const size_t bplane = (size_t)a.N * a.Kp;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[NPASS][V];
+    uint4 rb[3];
+    float pa[V], pb[V];
+    bool a_ok = false;
+    const int nchunk = (a.K + KC - 1) / KC;
+
+    auto gload = [&](int c) {
+        const int kk = c * KC + sq * V;
+        a_ok = kk < a.K;
+        if (PRO && a_ok) {
+            const int ch = kk % a.pro_c;
+            vload<V>(pa, a.pro_a + ch);
+            vload<V>(pb, a.pro_b + ch);
+        }
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            if (a_ok) vload<V>(ra[p], arow[p] + c * KC);
+            else {
+#pragma unroll
+                for (int v = 0; v < V; ++v) ra[p][v] = 0.f;
             }
         }
+        const bool b_ok = c * KC + 8 * bh < a.Kp;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            rb[pl] = b_ok ? *reinterpret_cast<const uint4*>(bsrc + pl * bplane + c * KC) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto lstore = [&](int buf) {
+        __bf16* st = smem + buf * X6_STAGE;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            __bf16 x0[V], x1[V], x2[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                float t = ra[p][v];
+                if (PRO && a_ok) t = fmaxf(fmaf(pa[v], t, pb[v]), 0.f);
+                split3(t, x0[v], x1[v], x2[v]);
+            }
+            __bf16* d = st + (sr + p * RPP) * X6_PITCH + sq * V;
+#pragma unroll
+            for (int v = 0; v < V; ++v) { d[v] = x0[v]; d[X6_PLANE + v] = x1[v]; d[2 * X6_PLANE + v] = x2[v]; }
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<uint4*>(st + (3 + pl) * X6_PLANE + brw * X6_PITCH + 8 * bh) = rb[pl];
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload(c + 1);
+        const __bf16* As = smem + buf * X6_STAGE + (wm * 64 + l31) * X6_PITCH + 8 * h;
+        const __bf16* Bs = smem + buf * X6_STAGE + 3 * X6_PLANE + (wn * 64 + l31) * X6_PITCH + 8 * h;
+        bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                af[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * X6_PLANE + i * 32 * X6_PITCH);
+                bf[i][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * X6_PLANE + i * 32 * X6_PITCH);
+            }
+#define IGN_X6(pa_, pb_)                                                                                   \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[0][pb_], acc[0][0], 0, 0, 0);   \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[1][pb_], acc[0][1], 0, 0, 0);   \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[0][pb_], acc[1][0], 0, 0, 0);   \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[1][pb_], acc[1][1], 0, 0, 0);
+        IGN_X6(2, 0) IGN_X6(0, 2) IGN_X6(1, 1) IGN_X6(1, 0) IGN_X6(0, 1) IGN_X6(0, 0)     // small terms first
+#undef IGN_X6
+        if (c + 1 < nchunk) lstore(buf ^ 1);
         __syncthreads();
-        if (tid < TN && n0 + tid < a.N) {
-            a.part[((long long)mt * 2 + 0) * a.N + n0 + tid] = red[0 * TN + tid] + red[2 * TN + tid];
-            a.part[((long long)mt * 2 + 1) * a.N + n0 + tid] = red[1 * TN + tid] + red[3 * TN + tid];
-        }
     }
+    nt_epilogue<EPI>(a, acc, reinterpret_cast<float*>(smem16), mt, m0, n0);
+}
+
+// Wt3[p][co][j*Ci + ci] = split_p(W[co][ci][j]) (row pitch Kp, zero tail);  Wd3[p][ci][jj*Co + co] = split_p(W[co][ci][k-1-jj])
+__global__ void __launch_bounds__(256) pack_weights_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wt3,
+                                                              unsigned short* __restrict__ wd3, int Co, int Ci, int k, int Kpf,
+                                                              int Kpd) {
+    const long long nf = (long long)Co * Kpf, nd = wd3 ? (long long)Ci * Kpd : 0;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f;
+    __bf16* dst;
+    long long plane;
+    if (i < nf) {
+        const int kk = (int)(i % Kpf);
+        const long long co = i / Kpf;
+        if (kk < k * Ci) { const int j = kk / Ci, ci = kk - j * Ci; v = w[(co * Ci + ci) * k + j]; }
+        dst = reinterpret_cast<__bf16*>(wt3) + i;
+        plane = nf;
+    } else if (i < nf + nd) {
+        const long long e = i - nf;
+        const int kk = (int)(e % Kpd);
+        const long long ci = e / Kpd;
+        if (kk < k * Co) { const int jj = kk / Co, co = kk - jj * Co; v = w[((long long)co * Ci + ci) * k + (k - 1 - jj)]; }
+        dst = reinterpret_cast<__bf16*>(wd3) + e;
+        plane = nd;
+    } else {
+        return;
+    }
+    __bf16 x0, x1, x2;
+    split3(v, x0, x1, x2);
+    dst[0] = x0; dst[plane] = x1; dst[2 * plane] = x2;
 }
 
 // ------------------------------------------------------------------------------------------------ TN GEMM (wgrad)
@@ -607,6 +783,40 @@ static int launch_nt(const GemmNTArgs& a, int V, bool pro, hipStream_t s) {
     return ign_check_launch("clconv_nt_kernel");
 }
 
+template <int EPI>
+static int launch_nt_x6(const GemmNTArgs& a, int V, bool pro, hipStream_t s) {
+    const dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(256);
+#define IGN_X6L(VV, PP)                                                                                                        \
+    do {                                                                                                                       \
+        static bool once = false;                                                                                              \
+        if (!once) {                                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_nt_x6_kernel<VV, PP, EPI>),                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES);                          \
+            once = true;                                                                                                       \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((clconv_nt_x6_kernel<VV, PP, EPI>), grid, block, X6_LDS_BYTES, s, a);                                \
+    } while (0)
+    if (V == 4) { if (pro) IGN_X6L(4, true); else IGN_X6L(4, false); }
+    else if (V == 2) { if (pro) IGN_X6L(2, true); else IGN_X6L(2, false); }
+    else { if (pro) IGN_X6L(1, true); else IGN_X6L(1, false); }
+#undef IGN_X6L
+    return ign_check_launch("clconv_nt_x6_kernel");
+}
+
+extern "C" int ign_clconv_kpad(int K) { return (K + 7) / 8 * 8; }
+
+extern "C" int ign_clconv_pack_weights_x3(const float* w_oik, void* wt3_fwd, void* wt3_dgrad, int Co, int Ci, int k, void* stream) {
+    if (!w_oik || !wt3_fwd || Co <= 0 || Ci <= 0 || k <= 0) {
+        ign_set_error("ign_clconv_pack_weights_x3: bad argument (Co=%d Ci=%d k=%d)", Co, Ci, k);
+        return IGN_E_ARG;
+    }
+    const int Kpf = ign_clconv_kpad(k * Ci), Kpd = ign_clconv_kpad(k * Co);
+    const long long n = (long long)Co * Kpf + (wt3_dgrad ? (long long)Ci * Kpd : 0);
+    hipLaunchKernelGGL(pack_weights_x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oik,
+                       (unsigned short*)wt3_fwd, (unsigned short*)wt3_dgrad, Co, Ci, k, Kpf, Kpd);
+    return ign_check_launch("pack_weights_x3_kernel");
+}
+
 extern "C" long long ign_clconv_mtiles(long long M) { return (M + TM - 1) / TM; }
 
 extern "C" int ign_clconv_pack_weights(const float* w_oik, float* wt_fwd, float* wt_dgrad, int Co, int Ci, int k, void* stream) {
@@ -620,9 +830,8 @@ extern "C" int ign_clconv_pack_weights(const float* w_oik, float* wt_fwd, float*
     return ign_check_launch("pack_weights_kernel");
 }
 
-extern "C" int ign_clconv_fwd(const float* x, const float* wt, const float* bias, const float* pro_a, const float* pro_b,
-                              float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream) {
-    static const char* who = "ign_clconv_fwd";
+static int clconv_fwd_impl(const char* who, bool x6, const float* x, const void* wt, const float* bias, const float* pro_a,
+                           const float* pro_b, float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream) {
     const int Tout = Tin - k + 1;
     if (!x || !wt || !y || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || ((pro_a == nullptr) != (pro_b == nullptr))) {
         ign_set_error("%s: bad argument (B=%d Tin=%d Ci=%d Co=%d k=%d)", who, B, Tin, Ci, Co, k);
@@ -632,17 +841,28 @@ extern "C" int ign_clconv_fwd(const float* x, const float* wt, const float* bias
     if (M > 0x7fffffffLL / 2) { ign_set_error("%s: B*Tout = %lld rows exceed the 2^30 row index space", who, M); return IGN_E_TOOBIG; }
     GemmNTArgs a{};
     a.A = x; a.am = RowMap{Tout, 0, Ci, (long long)Tin * Ci}; a.K = k * Ci;
-    a.Bt = wt; a.ldb = k * Ci; a.C = y; a.M = (int)M; a.N = Co; a.bias = bias;
+    a.Bt = x6 ? nullptr : (const float*)wt; a.ldb = k * Ci; a.C = y; a.M = (int)M; a.N = Co; a.bias = bias;
+    a.B3 = x6 ? (const unsigned short*)wt : nullptr; a.Kp = ign_clconv_kpad(k * Ci);
     a.pro_a = pro_a; a.pro_b = pro_b; a.pro_c = Ci; a.part = stat_part;
     a.mtiles = (int)((M + TM - 1) / TM); a.ntiles = (Co + TN - 1) / TN;
     IgnScopedTimer tm("clconv_fwd", (hipStream_t)stream);
+    if (x6) return launch_nt_x6<EPI_BIAS_STATS>(a, vec_width(Ci), pro_a != nullptr, (hipStream_t)stream);
     return launch_nt<EPI_BIAS_STATS>(a, vec_width(Ci), pro_a != nullptr, (hipStream_t)stream);
 }
 
-extern "C" int ign_clconv_dgrad(const float* dyp, const float* wt_dgrad, const float* y_in, const float* a_in, const float* b_in,
-                                const float* mean_in, const float* invstd_in, float* g_in, float* stat_part, int B, int Tin,
-                                int Ci, int Co, int k, void* stream) {
-    static const char* who = "ign_clconv_dgrad";
+extern "C" int ign_clconv_fwd(const float* x, const float* wt, const float* bias, const float* pro_a, const float* pro_b,
+                              float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream) {
+    return clconv_fwd_impl("ign_clconv_fwd", false, x, wt, bias, pro_a, pro_b, y, stat_part, B, Tin, Ci, Co, k, stream);
+}
+
+extern "C" int ign_clconv_fwd_x6(const float* x, const void* wt3, const float* bias, const float* pro_a, const float* pro_b,
+                                 float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream) {
+    return clconv_fwd_impl("ign_clconv_fwd_x6", true, x, wt3, bias, pro_a, pro_b, y, stat_part, B, Tin, Ci, Co, k, stream);
+}
+
+static int clconv_dgrad_impl(const char* who, bool x6, const float* dyp, const void* wt_dgrad, const float* y_in, const float* a_in,
+                             const float* b_in, const float* mean_in, const float* invstd_in, float* g_in, float* stat_part, int B,
+                             int Tin, int Ci, int Co, int k, void* stream) {
     const int Tout = Tin - k + 1;
     if (!dyp || !wt_dgrad || !y_in || !a_in || !b_in || !mean_in || !invstd_in || !g_in || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 ||
         Tout <= 0) {
@@ -654,11 +874,27 @@ extern "C" int ign_clconv_dgrad(const float* dyp, const float* wt_dgrad, const f
     GemmNTArgs a{};
     // logical row (b, t) reads padded rows t .. t+k-1 of sample b: dz[b,t,ci] = sum_{jj,co} dyp[b,t+jj,co] W[co,ci,k-1-jj]
     a.A = dyp; a.am = RowMap{Tin, 0, Co, (long long)(Tout + 2 * (k - 1)) * Co}; a.K = k * Co;
-    a.Bt = wt_dgrad; a.ldb = k * Co; a.C = g_in; a.M = (int)M; a.N = Ci;
+    a.Bt = x6 ? nullptr : (const float*)wt_dgrad; a.ldb = k * Co; a.C = g_in; a.M = (int)M; a.N = Ci;
+    a.B3 = x6 ? (const unsigned short*)wt_dgrad : nullptr; a.Kp = ign_clconv_kpad(k * Co);
     a.part = stat_part; a.ey = y_in; a.ea = a_in; a.eb = b_in; a.emean = mean_in; a.einv = invstd_in;
     a.mtiles = (int)((M + TM - 1) / TM); a.ntiles = (Ci + TN - 1) / TN;
     IgnScopedTimer tm("clconv_dgrad", (hipStream_t)stream);
+    if (x6) return launch_nt_x6<EPI_MASK_STATS>(a, vec_width(Co), false, (hipStream_t)stream);
     return launch_nt<EPI_MASK_STATS>(a, vec_width(Co), false, (hipStream_t)stream);
+}
+
+extern "C" int ign_clconv_dgrad(const float* dyp, const float* wt_dgrad, const float* y_in, const float* a_in, const float* b_in,
+                                const float* mean_in, const float* invstd_in, float* g_in, float* stat_part, int B, int Tin,
+                                int Ci, int Co, int k, void* stream) {
+    return clconv_dgrad_impl("ign_clconv_dgrad", false, dyp, wt_dgrad, y_in, a_in, b_in, mean_in, invstd_in, g_in, stat_part, B, Tin,
+                             Ci, Co, k, stream);
+}
+
+extern "C" int ign_clconv_dgrad_x6(const float* dyp, const void* wt3_dgrad, const float* y_in, const float* a_in, const float* b_in,
+                                   const float* mean_in, const float* invstd_in, float* g_in, float* stat_part, int B, int Tin,
+                                   int Ci, int Co, int k, void* stream) {
+    return clconv_dgrad_impl("ign_clconv_dgrad_x6", true, dyp, wt3_dgrad, y_in, a_in, b_in, mean_in, invstd_in, g_in, stat_part, B,
+                             Tin, Ci, Co, k, stream);
 }
 
 static int wgrad_splits(long long M, int tiles) {

@@ -10,12 +10,15 @@ into dL/dy (written zero-padded, the layout the GEMMs read); the weight-gradient
 fly.  torch supplies memory and the autograd plumbing only.  There is no CPU path.
 """
 import ctypes
+import os
 
 import torch
 
 from . import _lib
 
 
+# "f32": v_mfma_f32_32x32x2_f32; "bf16x6": the split-bf16 product on the bf16 matrix cores (fp32 rounding-level accuracy)
+CONV_MATH = os.environ.get("IGN_CONV_MATH", "f32")
 DEBUG = None       # set to a dict to capture the backward intermediates (tests/diag_fcn.py)
 
 
@@ -60,6 +63,7 @@ class FcnBodyFn(torch.autograd.Function):
         dev = x.device
         f32 = dict(device=dev, dtype=torch.float32)
         need_grad = any(ctx.needs_input_grad[2:])
+        x6 = CONV_MATH == "bf16x6"
         inputs, affine, wds, shapes = [x], [], [], []
         pa = pb = None
         for l in range(nl):
@@ -70,15 +74,23 @@ class FcnBodyFn(torch.autograd.Function):
             Tout = Tin - k + 1
             if h.shape[2] != Ci or Tout <= 0 or Co % 4:
                 raise _lib.IgnError(f"fcn_body block {l + 1}: input {tuple(h.shape)} vs weight {tuple(w.shape)}")
-            wt = torch.empty(Co, k * Ci, **f32)
-            wd = torch.empty(Ci, k * Co, **f32) if (l > 0 and need_grad) else None
-            _lib.check(L.ign_clconv_pack_weights(_ptr(w), _ptr(wt), _ptr(wd), Co, Ci, k, _stream()), "ign_clconv_pack_weights")
             st = states[l]
             y = torch.empty(B, Tout, Co, **f32)
             nparts = int(L.ign_clconv_mtiles(B * Tout))
             part = torch.empty(nparts, 2, Co, **f32) if st.use_batch_stats else None
-            _lib.check(L.ign_clconv_fwd(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part), B, Tin, Ci, Co, k,
-                                        _stream()), "ign_clconv_fwd")
+            want_wd = l > 0 and need_grad
+            if x6:
+                wt = torch.empty(3, Co, int(L.ign_clconv_kpad(k * Ci)), device=dev, dtype=torch.bfloat16)
+                wd = torch.empty(3, Ci, int(L.ign_clconv_kpad(k * Co)), device=dev, dtype=torch.bfloat16) if want_wd else None
+                _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt), _ptr(wd), Co, Ci, k, _stream()), "ign_clconv_pack_weights_x3")
+                _lib.check(L.ign_clconv_fwd_x6(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part), B, Tin, Ci, Co, k,
+                                               _stream()), "ign_clconv_fwd_x6")
+            else:
+                wt = torch.empty(Co, k * Ci, **f32)
+                wd = torch.empty(Ci, k * Co, **f32) if want_wd else None
+                _lib.check(L.ign_clconv_pack_weights(_ptr(w), _ptr(wt), _ptr(wd), Co, Ci, k, _stream()), "ign_clconv_pack_weights")
+                _lib.check(L.ign_clconv_fwd(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part), B, Tin, Ci, Co, k,
+                                            _stream()), "ign_clconv_fwd")
             a, bb, mean, invstd = (torch.empty(Co, **f32) for _ in range(4))
             if st.use_batch_stats:
                 _lib.check(L.ign_bn_finalize_fwd(_ptr(part), nparts, B * Tout, Co, _ptr(gamma), _ptr(beta), st.eps, st.momentum,
@@ -98,7 +110,7 @@ class FcnBodyFn(torch.autograd.Function):
         pooled = torch.empty(B, Cl, **f32)
         _lib.check(L.ign_bn_relu_pool_fwd(_ptr(y_last), _ptr(pa), _ptr(pb), _ptr(pooled), B, Tl, Cl, _stream()),
                    "ign_bn_relu_pool_fwd")
-        ctx.saved = (inputs, affine, wds, shapes, [st.use_batch_stats for st in states]) if need_grad else None
+        ctx.saved = (inputs, affine, wds, shapes, [st.use_batch_stats for st in states], x6) if need_grad else None
         return pooled
 
     @staticmethod
@@ -108,7 +120,7 @@ class FcnBodyFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise _lib.IgnError("fcn_body: gradient w.r.t. the input series is not implemented (inputs are data)")
         L = _lib.lib()
-        inputs, affine, wds, shapes, batch_stats = ctx.saved
+        inputs, affine, wds, shapes, batch_stats, x6 = ctx.saved
         nl = len(shapes)
         B = inputs[0].shape[0]
         dev = gpool.device
@@ -157,7 +169,8 @@ class FcnBodyFn(torch.autograd.Function):
                 g = torch.empty(B, Tin, Ci, **f32)
                 nparts = int(L.ign_clconv_mtiles(B * Tin))
                 part = torch.empty(nparts, 2, Ci, **f32)
-                _lib.check(L.ign_clconv_dgrad(_ptr(dyp), _ptr(wds[l]), _ptr(inputs[l]), _ptr(pa_), _ptr(pb_), _ptr(pm_), _ptr(pi_),
+                dgrad = L.ign_clconv_dgrad_x6 if x6 else L.ign_clconv_dgrad
+                _lib.check(dgrad(_ptr(dyp), _ptr(wds[l]), _ptr(inputs[l]), _ptr(pa_), _ptr(pb_), _ptr(pm_), _ptr(pi_),
                                               _ptr(g), _ptr(part), B, Tin, Ci, Co, k, _stream()), "ign_clconv_dgrad")
             del dyp
         ctx.saved = None

@@ -44,7 +44,8 @@ def _s():
     (3, 77, 256, 128, 3, True),      # third block, ragged m-tiles
     (5, 9, 128, 256, 3, True),       # seq_len <= 10 kernels
 ])
-def test_clconv_fwd_matches_conv1d(B, T, Ci, Co, k, pro):
+@pytest.mark.parametrize("math", ["f32", "bf16x6"])
+def test_clconv_fwd_matches_conv1d(B, T, Ci, Co, k, pro, math):
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
     from ign_hip import _lib
@@ -60,13 +61,18 @@ def test_clconv_fwd_matches_conv1d(B, T, Ci, Co, k, pro):
     Tout = T - k + 1
     xd, wd_, bd = x.to(dev), w.to(dev), bias.to(dev)
     pad, pbd = (pa.to(dev), pb.to(dev)) if pro else (None, None)
-    wt = torch.empty(Co, k * Ci, device=dev)
-    _lib.check(L.ign_clconv_pack_weights(_p(wd_), _p(wt), None, Co, Ci, k, _s()), "pack")
     y = torch.full((B, Tout, Co), float("nan"), device=dev)
     nparts = int(L.ign_clconv_mtiles(B * Tout))
     part = torch.full((nparts, 2, Co), float("nan"), device=dev)
-    _lib.check(L.ign_clconv_fwd(_p(xd), _p(wt), _p(bd), _p(pad), _p(pbd), _p(y), _p(part), B, T, Ci, Co, k, _s()), "fwd")
-    assert _rel(y, ref) < TOL
+    if math == "f32":
+        wt = torch.empty(Co, k * Ci, device=dev)
+        _lib.check(L.ign_clconv_pack_weights(_p(wd_), _p(wt), None, Co, Ci, k, _s()), "pack")
+        _lib.check(L.ign_clconv_fwd(_p(xd), _p(wt), _p(bd), _p(pad), _p(pbd), _p(y), _p(part), B, T, Ci, Co, k, _s()), "fwd")
+    else:       # split-bf16 product on the bf16 matrix cores: must be as accurate as the fp32 kernel
+        wt = torch.empty(3, Co, int(L.ign_clconv_kpad(k * Ci)), device=dev, dtype=torch.bfloat16)
+        _lib.check(L.ign_clconv_pack_weights_x3(_p(wd_), _p(wt), None, Co, Ci, k, _s()), "pack_x3")
+        _lib.check(L.ign_clconv_fwd_x6(_p(xd), _p(wt), _p(bd), _p(pad), _p(pbd), _p(y), _p(part), B, T, Ci, Co, k, _s()), "fwd_x6")
+    assert _rel(y, ref) < 3e-6, "fp32 rounding level (K <= 1280 terms)"
     # the BatchNorm statistics partials of the epilogue
     s1 = part[:, 0].double().sum(0).cpu()
     s2 = part[:, 1].double().sum(0).cpu()
@@ -96,11 +102,13 @@ def _ref_blocks(cfg_in, widths, ks, seed):
     (2, 1000, 122, (128, 256, 128), (8, 5, 3), True),    # CHISCO shape (small batch)
     (3, 61, 9, (128, 256, 128), (8, 5, 3), False),
 ])
-def test_fcn_body_forward_backward(B, T, C, widths, ks, training):
+@pytest.mark.parametrize("math", ["f32", "bf16x6"])
+def test_fcn_body_forward_backward(B, T, C, widths, ks, training, math, monkeypatch):
     dev = _dev()
     import copy
     import speech_imagery_eeg_amd  # noqa
     from ign_hip import fcn
+    monkeypatch.setattr(fcn, "CONV_MATH", math)
     ref = _ref_blocks(C, widths, ks, seed=B + T + C).double().train(training)
     mod = copy.deepcopy(ref).float().to(dev).train(training)
     g = torch.Generator().manual_seed(11 * T + C)
@@ -144,7 +152,8 @@ def _away_from_kink(y, a, b, margin=1e-3):
 
 
 @pytest.mark.parametrize("B,Tin,Ci,Co,k", [(2, 989, 256, 128, 3), (2, 993, 128, 256, 5), (3, 50, 64, 128, 3), (1, 9, 128, 256, 2)])
-def test_clconv_dgrad_and_wgrad_kernels(B, Tin, Ci, Co, k):
+@pytest.mark.parametrize("math", ["f32", "bf16x6"])
+def test_clconv_dgrad_and_wgrad_kernels(B, Tin, Ci, Co, k, math):
     """ign_clconv_dgrad (ReLU mask + BatchNorm-backward sums in the epilogue) and ign_clconv_wgrad (prologue recomputes
     relu(bn(y))) against float64 autograd of the same maths, with pre-activations kept off the ReLU kink."""
     dev = _dev()
@@ -183,9 +192,16 @@ def test_clconv_dgrad_and_wgrad_kernels(B, Tin, Ci, Co, k):
     gin = torch.full((B, Tin, Ci), float("nan"), device=dev)
     nparts = int(L.ign_clconv_mtiles(B * Tin))
     part = torch.full((nparts, 2, Ci), float("nan"), device=dev)
-    _lib.check(L.ign_clconv_dgrad(_p(dypd), _p(wdg), _p(yind), _p(ad), _p(bd), _p(md), _p(isd), _p(gin), _p(part),
-                                  B, Tin, Ci, Co, k, _s()), "dgrad")
-    assert _rel(gin, g_ref) < TOL
+    if math == "f32":
+        _lib.check(L.ign_clconv_dgrad(_p(dypd), _p(wdg), _p(yind), _p(ad), _p(bd), _p(md), _p(isd), _p(gin), _p(part),
+                                      B, Tin, Ci, Co, k, _s()), "dgrad")
+    else:
+        wt3 = torch.empty(3, Co, int(L.ign_clconv_kpad(k * Ci)), device=dev, dtype=torch.bfloat16)
+        wd3 = torch.empty(3, Ci, int(L.ign_clconv_kpad(k * Co)), device=dev, dtype=torch.bfloat16)
+        _lib.check(L.ign_clconv_pack_weights_x3(_p(wd_), _p(wt3), _p(wd3), Co, Ci, k, _s()), "pack_x3")
+        _lib.check(L.ign_clconv_dgrad_x6(_p(dypd), _p(wd3), _p(yind), _p(ad), _p(bd), _p(md), _p(isd), _p(gin), _p(part),
+                                         B, Tin, Ci, Co, k, _s()), "dgrad_x6")
+    assert _rel(gin, g_ref) < 3e-6
     assert _rel(part[:, 0].double().sum(0), s1_ref) < TOL and _rel(part[:, 1].double().sum(0), s2_ref) < TOL
 
     ws = torch.empty(int(L.ign_clconv_wgrad_workspace_bytes(B, Tin, Ci, Co, k)) // 4, device=dev)
