@@ -240,8 +240,13 @@ def main():
                 traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["shp_bwd_kernel"]["bytes_per_step"]
             except Exception:
                 pass
+            from ign_hip import fcn as _fcn
             res["config"] = dict(common, workload="Synthetic CHISCO-shape EEG (122ch x 1000, 3-class) IGN(FCN expert), "
-                                 "driver-default groups K=5 x L{100,200,300,500}, Adam lr 5e-3, fp32")
+                                 "driver-default groups K=5 x L{100,200,300,500}, Adam lr 5e-3, fp32",
+                                 conv_math=_fcn.CONV_MATH + (" (fp32 operands split exactly into 3 bf16 terms, 6 partial products "
+                                                            "accumulated in fp32; <= 3e-6 vs float64, same as the fp32-MFMA "
+                                                            "kernel; IGN_CONV_MATH=f32 selects that one)"
+                                                            if _fcn.CONV_MATH == "bf16x6" else ""))
             res["roofline"] = {"bound": "valu", "kernel": "shp_bwd_kernel", "achieved": bwd_tflops,
                                "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": bwd_tflops / PEAK_FP32_VALU_TFLOPS,
                                "traffic": traffic, "ms_per_step": bwd_ms / max(1, args.steps), "launches": bwd_n,

@@ -76,40 +76,61 @@ struct GemmNTArgs {
 
 // ---- epilogue shared by the fp32 and the split-bf16 kernels.  Lane (l31, h) of accumulator (i, j) holds column
 // n = n0 + wn*64 + j*32 + l31 and the 16 rows m0 + wm*64 + i*32 + acc_row16(r, h).  `red` is >= 512 floats of LDS that no
-// wave still reads.
-template <int EPI>
-__device__ __forceinline__ void nt_epilogue(const GemmNTArgs& a, const f32x16 (&acc)[2][2], float* red, int mt, int m0, int n0) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// wave still reads.  FULL = the whole 128x128 tile is inside the output: no per-element masks, and the 16 y values an
+// accumulator needs (EPI_MASK_STATS) are fetched as 16 independent loads before any of them is used.
+template <int EPI, bool FULL>
+__device__ __forceinline__ void nt_epilogue_body(const GemmNTArgs& a, const f32x16 (&acc)[2][2], float (&s1)[2], float (&s2)[2],
+                                                 int m0, int n0, int m_lim) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave & 1, wn = wave >> 1;
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + l31;
-        const bool n_ok = n < a.N;
+        const bool n_ok = FULL || n < a.N;
         const int nc = n_ok ? n : a.N - 1;
         const float bv = (EPI == EPI_BIAS_STATS && a.bias) ? a.bias[nc] : 0.f;
         float ea = 0.f, eb = 0.f, em = 0.f, ei = 0.f;
         if (EPI == EPI_MASK_STATS) { ea = a.ea[nc]; eb = a.eb[nc]; em = a.emean[nc]; ei = a.einv[nc]; }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            const int mb = m0 + wm * 64 + i * 32;
+            float yv[16];
+            if (EPI == EPI_MASK_STATS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + acc_row16(r, h);
+                    const int mc = FULL ? m : min(m, m_lim - 1);
+                    yv[r] = a.ey[(long long)mc * a.N + nc];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + acc_row16(r, h);
-                const bool ok = n_ok && m < a.M;
+                const int m = mb + acc_row16(r, h);
+                const bool ok = FULL || (n_ok && m < m_lim);
                 float v = acc[i][j][r];
                 if (EPI == EPI_BIAS_STATS) {
                     v += bv;
                     if (ok) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
                 } else {
-                    const float yv = ok ? a.ey[(long long)m * a.N + n] : 0.f;
-                    v = (fmaf(ea, yv, eb) > 0.f) ? v : 0.f;
-                    if (ok) { s1[j] += v; s2[j] = fmaf(v, (yv - em) * ei, s2[j]); }
+                    v = (fmaf(ea, yv[r], eb) > 0.f) ? v : 0.f;
+                    if (ok) { s1[j] += v; s2[j] = fmaf(v, (yv[r] - em) * ei, s2[j]); }
                 }
                 if (ok) a.C[(long long)m * a.N + n] = v;
             }
         }
     }
+}
+
+template <int EPI>
+__device__ __forceinline__ void nt_epilogue(const GemmNTArgs& a, const f32x16 (&acc)[2][2], float* red, int mt, int m0, int n0,
+                                            int m_lim) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    if (m0 + TM <= m_lim && n0 + TN <= a.N) nt_epilogue_body<EPI, true>(a, acc, s1, s2, m0, n0, m_lim);
+    else nt_epilogue_body<EPI, false>(a, acc, s1, s2, m0, n0, m_lim);
     if (a.part) {
         // combine the lane halves, then the two waves that share these columns, in a fixed order
         // red: [2 (wm)][2 (stat)][128 (col)]
@@ -130,7 +151,6 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs& a, const f32x16 (&
         }
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------ NT GEMM
 template <int V, bool PRO, int EPI>
@@ -244,7 +264,7 @@ __global__ void __launch_bounds__(256, 2) clconv_nt_kernel(const GemmNTArgs a) {
         __syncthreads();
     }
 
-    nt_epilogue<EPI>(a, acc, smem[0], mt, m0, n0);
+    nt_epilogue<EPI>(a, acc, smem[0], mt, m0, n0, a.M);
 }
 
 // ------------------------------------------------------------------------------------------------ NT GEMM, split bf16
@@ -256,12 +276,10 @@ __global__ void __launch_bounds__(256, 2) clconv_nt_kernel(const GemmNTArgs a) {
 // every partial product exact (8 x 8 bits) and accumulated in fp32 by v_mfma_f32_32x32x16_bf16: 6 MFMAs of 16x the
 // rate = 2.7x the fp32-MFMA throughput at fp32 rounding-level error (measured against float64 in tests/test_gpu_fcn.py).
 // The activation operand is split while it is staged (after the BatchNorm+ReLU prologue); the weights arrive pre-split
-// (ign_clconv_pack_weights_x3).  LDS: 6 planes of [128 rows][16 k + 8 pad] bf16 per stage, double-buffered (72 KB).
+// (ign_clconv_pack_weights_x3).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int X6_PITCH = KC + 8;             // bf16 per staged row: 48 B, 12*i mod 64 dwords is conflict-free for b128 reads
 constexpr int X6_PLANE = TM * X6_PITCH;      // bf16 per plane per stage
-constexpr int X6_STAGE = 6 * X6_PLANE;       // A planes 0..2, B planes 3..5
-constexpr size_t X6_LDS_BYTES = (size_t)2 * X6_STAGE * sizeof(unsigned short);
 
 __device__ __forceinline__ void split3(float v, __bf16& x0, __bf16& x1, __bf16& x2) {
     x0 = (__bf16)v;
@@ -271,11 +289,34 @@ __device__ __forceinline__ void split3(float v, __bf16& x0, __bf16& x1, __bf16& 
     x2 = (__bf16)r;
 }
 
+// ---- split-bf16 convolution with tap reuse.  The im2col rows of 128 consecutive output positions of one sample overlap:
+// together they are the (128 + k - 1)-row span of the input.  Per 16-channel chunk that span is loaded, passed through the
+// prologue and split ONCE, and all k taps run from it with the MFMA row operand shifted by one LDS row per tap -- the plain
+// GEMM form above loads and splits every activation k times.  Weights: bf16 planes (3, N, k*Cp), Cp = channels rounded up to
+// 16, so every (tap, chunk) block is 16-byte aligned.  One barrier per (chunk, tap) step of 24 MFMAs per wave; the weights
+// of the next step and (on the last tap) the next span are prefetched into registers during the MFMAs.
+struct ConvX6Args {
+    GemmNTArgs g;                 // C, M, N, bias, prologue, epilogue pointers, part, B3 (planes; Kp = k*Cp), mtiles = B*tps, ntiles
+    long long sample_pitch;       // floats between samples of the input
+    int rows_in;                  // valid input rows per sample (loads are clamped to it)
+    int cin, cp, k;               // input channels, padded channels, taps
+    int trows;                    // valid output rows per sample
+    int tps;                      // m-tiles per sample
+};
+constexpr int X6T_SPAN = TM + 15;                  // k <= 16
+constexpr int X6T_APLANE = X6T_SPAN * X6_PITCH;
+constexpr int X6T_ABUF = 3 * X6T_APLANE;
+constexpr int X6T_BBUF = 3 * X6_PLANE;
+constexpr size_t X6T_LDS_BYTES = (size_t)2 * (X6T_ABUF + X6T_BBUF) * sizeof(unsigned short);
+
 template <int V, bool PRO, int EPI>
-__global__ void __launch_bounds__(256, 2) clconv_nt_x6_kernel(const GemmNTArgs a) {
-    constexpr int VPR = KC / V, RPP = 256 / VPR, NPASS = TM / RPP;
+__global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca) {
+    const GemmNTArgs& a = ca.g;
+    constexpr int VPR = KC / V;                               // vectors per span row
+    constexpr int APASS = (X6T_SPAN * VPR + 255) / 256;       // staging passes of the span (V=4: 3, V=2: 5, V=1: 9)
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-    __bf16* smem = reinterpret_cast<__bf16*>(smem16);
+    __bf16* Abuf = reinterpret_cast<__bf16*>(smem16);
+    __bf16* Bbuf = Abuf + 2 * X6T_ABUF;
 
     const int nwg = a.mtiles * a.ntiles;
     int lid = blockIdx.x;
@@ -284,16 +325,15 @@ __global__ void __launch_bounds__(256, 2) clconv_nt_x6_kernel(const GemmNTArgs a
         if (lid < per * 8) lid = (lid & 7) * per + (lid >> 3);
     }
     const int mt = lid / a.ntiles, nt = lid - mt * a.ntiles;
-    const int m0 = mt * TM, n0 = nt * TN;
+    const int bi = mt / ca.tps, tt = mt - bi * ca.tps;
+    const int t0 = tt * TM, n0 = nt * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave & 1, wn = wave >> 1;
+    const int span = TM + ca.k - 1;
+    const int nvec = span * VPR;
 
-    const int sq = tid % VPR, sr = tid / VPR;
-    const float* arow[NPASS];
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) arow[p] = a.A + row_off(a.am, min(m0 + sr + p * RPP, a.M - 1)) + sq * V;
-    // B planes: thread <-> (row tid/2, 8-element half tid&1)
+    const float* abase = a.A + (long long)bi * ca.sample_pitch;
     const int brw = tid >> 1, bh = tid & 1;
     const unsigned short* bsrc = a.B3 + (size_t)min(n0 + brw, a.N - 1) * a.Kp + 8 * bh;
     const size_t bplane = (size_t)a.N * a.Kp;
@@ -306,67 +346,93 @@ __global__ void __launch_bounds__(256, 2) clconv_nt_x6_kernel(const GemmNTArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float ra[NPASS][V];
-    uint4 rb[3];
+    float ra[APASS][V];
     float pa[V], pb[V];
     bool a_ok = false;
-    const int nchunk = (a.K + KC - 1) / KC;
+    // Weight prefetch registers: two sets of three planes (scalars, not arrays: arrays captured by the lambdas below end
+    // up in scratch).  The loads for step s+2 are issued at the top of step s, so they have two steps to land.
+    uint4 rb00, rb01, rb02, rb10, rb11, rb12;
+    const int ncc = ca.cp / KC;
+    const int nstep = ncc * ca.k;
 
-    auto gload = [&](int c) {
-        const int kk = c * KC + sq * V;
-        a_ok = kk < a.K;
-        if (PRO && a_ok) {
-            const int ch = kk % a.pro_c;
-            vload<V>(pa, a.pro_a + ch);
-            vload<V>(pb, a.pro_b + ch);
-        }
+    auto aload = [&](int cc) {
+        const int ch = cc * KC + (tid % VPR) * V;          // 256 % VPR == 0: a thread keeps its channel offset in every pass
+        a_ok = ch < ca.cin;                                  // V divides cin: a vector is entirely inside or outside
+        if (PRO && a_ok) { vload<V>(pa, a.pro_a + ch); vload<V>(pb, a.pro_b + ch); }
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            if (a_ok) vload<V>(ra[p], arow[p] + c * KC);
+        for (int p = 0; p < APASS; ++p) {
+            const int idx = tid + p * 256;
+            const int row = idx / VPR;
+            if (a_ok && idx < nvec) vload<V>(ra[p], abase + (long long)min(t0 + row, ca.rows_in - 1) * ca.cin + ch);
             else {
 #pragma unroll
                 for (int v = 0; v < V; ++v) ra[p][v] = 0.f;
             }
         }
-        const bool b_ok = c * KC + 8 * bh < a.Kp;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-            rb[pl] = b_ok ? *reinterpret_cast<const uint4*>(bsrc + pl * bplane + c * KC) : make_uint4(0u, 0u, 0u, 0u);
     };
-    auto lstore = [&](int buf) {
-        __bf16* st = smem + buf * X6_STAGE;
+    auto astore = [&](int buf) {
+        __bf16* st = Abuf + buf * X6T_ABUF;
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            __bf16 x0[V], x1[V], x2[V];
+        for (int p = 0; p < APASS; ++p) {
+            const int idx = tid + p * 256;
+            if (idx < nvec) {
+                const int row = idx / VPR, q = idx - row * VPR;
+                __bf16 x0[V], x1[V], x2[V];
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                float t = ra[p][v];
-                if (PRO && a_ok) t = fmaxf(fmaf(pa[v], t, pb[v]), 0.f);
-                split3(t, x0[v], x1[v], x2[v]);
+                for (int v = 0; v < V; ++v) {
+                    float t = ra[p][v];
+                    if (PRO && a_ok) t = fmaxf(fmaf(pa[v], t, pb[v]), 0.f);
+                    split3(t, x0[v], x1[v], x2[v]);
+                }
+                __bf16* d = st + row * X6_PITCH + q * V;
+#pragma unroll
+                for (int v = 0; v < V; ++v) { d[v] = x0[v]; d[X6T_APLANE + v] = x1[v]; d[2 * X6T_APLANE + v] = x2[v]; }
             }
-            __bf16* d = st + (sr + p * RPP) * X6_PITCH + sq * V;
-#pragma unroll
-            for (int v = 0; v < V; ++v) { d[v] = x0[v]; d[X6_PLANE + v] = x1[v]; d[2 * X6_PLANE + v] = x2[v]; }
         }
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-            *reinterpret_cast<uint4*>(st + (3 + pl) * X6_PLANE + brw * X6_PITCH + 8 * bh) = rb[pl];
     };
+    // step index -> offset of its (tap, chunk) block in a weight row; steps past the end re-read the last block (the loads
+    // stay unconditional so that the compiler's vmcnt bookkeeping is exact on every path)
+    auto boff = [&](int st) {
+        st = min(st, nstep - 1);
+        const int cc = st / ca.k, j = st - cc * ca.k;
+        return (size_t)j * ca.cp + cc * KC;
+    };
+    auto bstore = [&](int buf, const uint4& r0, const uint4& r1, const uint4& r2) {
+        __bf16* st = Bbuf + buf * X6T_BBUF + brw * X6_PITCH + 8 * bh;
+        *reinterpret_cast<uint4*>(st) = r0;
+        *reinterpret_cast<uint4*>(st + X6_PLANE) = r1;
+        *reinterpret_cast<uint4*>(st + 2 * X6_PLANE) = r2;
+    };
+#define IGN_BLOAD(r0, r1, r2, st)                                                       \
+    do {                                                                                \
+        const size_t off_ = boff(st);                                                   \
+        r0 = *reinterpret_cast<const uint4*>(bsrc + off_);                              \
+        r1 = *reinterpret_cast<const uint4*>(bsrc + bplane + off_);                     \
+        r2 = *reinterpret_cast<const uint4*>(bsrc + 2 * bplane + off_);                 \
+    } while (0)
 
-    gload(0);
-    lstore(0);
+    aload(0);
+    IGN_BLOAD(rb00, rb01, rb02, 0);
+    IGN_BLOAD(rb10, rb11, rb12, 1);
+    astore(0);
+    bstore(0, rb00, rb01, rb02);
     __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunk) gload(c + 1);
-        const __bf16* As = smem + buf * X6_STAGE + (wm * 64 + l31) * X6_PITCH + 8 * h;
-        const __bf16* Bs = smem + buf * X6_STAGE + 3 * X6_PLANE + (wn * 64 + l31) * X6_PITCH + 8 * h;
+
+    int cc = 0, j = 0;
+    auto body = [&](int step, bool odd) {
+        // registers of parity (step & 1) held step `step` (already in LDS): reuse them for step + 2
+        if (odd) IGN_BLOAD(rb10, rb11, rb12, step + 2);
+        else IGN_BLOAD(rb00, rb01, rb02, step + 2);
+        const bool next_span = cc + 1 < ncc;
+        if (j == 0 && next_span) aload(cc + 1);             // k steps ahead of its use
+        const __bf16* As = Abuf + (cc & 1) * X6T_ABUF + (wm * 64 + l31 + j) * X6_PITCH + 8 * h;
+        const __bf16* Bs = Bbuf + (step & 1) * X6T_BBUF + (wn * 64 + l31) * X6_PITCH + 8 * h;
         bf16x8 af[2][3], bf[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                af[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * X6_PLANE + i * 32 * X6_PITCH);
+                af[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * X6T_APLANE + i * 32 * X6_PITCH);
                 bf[i][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * X6_PLANE + i * 32 * X6_PITCH);
             }
 #define IGN_X6(pa_, pb_)                                                                                   \
@@ -374,34 +440,52 @@ __global__ void __launch_bounds__(256, 2) clconv_nt_x6_kernel(const GemmNTArgs a
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[1][pb_], acc[0][1], 0, 0, 0);   \
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[0][pb_], acc[1][0], 0, 0, 0);   \
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[1][pb_], acc[1][1], 0, 0, 0);
-        IGN_X6(2, 0) IGN_X6(0, 2) IGN_X6(1, 1) IGN_X6(1, 0) IGN_X6(0, 1) IGN_X6(0, 0)     // small terms first
+        IGN_X6(2, 0) IGN_X6(0, 2) IGN_X6(1, 1) IGN_X6(1, 0) IGN_X6(0, 1) IGN_X6(0, 0)
 #undef IGN_X6
-        if (c + 1 < nchunk) lstore(buf ^ 1);
+        // step + 1 goes to LDS from the OTHER register set (loaded during step - 1)
+        if (odd) bstore((step + 1) & 1, rb00, rb01, rb02);
+        else bstore((step + 1) & 1, rb10, rb11, rb12);
+        if (j + 1 == ca.k) {
+            if (next_span) astore((cc + 1) & 1);
+            j = 0; ++cc;
+        } else {
+            ++j;
+        }
         __syncthreads();
+    };
+    for (int step = 0; step < nstep; step += 2) {
+        body(step, false);
+        if (step + 1 < nstep) body(step + 1, true);
     }
-    nt_epilogue<EPI>(a, acc, reinterpret_cast<float*>(smem16), mt, m0, n0);
+#undef IGN_BLOAD
+    const int m0 = bi * ca.trows + t0;
+    nt_epilogue<EPI>(a, acc, reinterpret_cast<float*>(smem16), mt, m0, n0, bi * ca.trows + min(ca.trows, t0 + TM));
 }
 
-// Wt3[p][co][j*Ci + ci] = split_p(W[co][ci][j]) (row pitch Kp, zero tail);  Wd3[p][ci][jj*Co + co] = split_p(W[co][ci][k-1-jj])
-__global__ void __launch_bounds__(256) pack_weights_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wt3,
-                                                              unsigned short* __restrict__ wd3, int Co, int Ci, int k, int Kpf,
-                                                              int Kpd) {
-    const long long nf = (long long)Co * Kpf, nd = wd3 ? (long long)Ci * Kpd : 0;
+// Tap-major planes for the kernel above: Wt3[p][co][j*Cip + ci], Wd3[p][ci][jj*Cop + co] (zero in the padded channels)
+__global__ void __launch_bounds__(256) pack_weights_x3t_kernel(const float* __restrict__ w, unsigned short* __restrict__ wt3,
+                                                               unsigned short* __restrict__ wd3, int Co, int Ci, int k, int Cip,
+                                                               int Cop) {
+    const long long nf = (long long)Co * k * Cip, nd = wd3 ? (long long)Ci * k * Cop : 0;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     float v = 0.f;
     __bf16* dst;
     long long plane;
     if (i < nf) {
-        const int kk = (int)(i % Kpf);
-        const long long co = i / Kpf;
-        if (kk < k * Ci) { const int j = kk / Ci, ci = kk - j * Ci; v = w[(co * Ci + ci) * k + j]; }
+        const int ci = (int)(i % Cip);
+        const long long t = i / Cip;
+        const int j = (int)(t % k);
+        const long long co = t / k;
+        if (ci < Ci) v = w[(co * Ci + ci) * k + j];
         dst = reinterpret_cast<__bf16*>(wt3) + i;
         plane = nf;
     } else if (i < nf + nd) {
         const long long e = i - nf;
-        const int kk = (int)(e % Kpd);
-        const long long ci = e / Kpd;
-        if (kk < k * Co) { const int jj = kk / Co, co = kk - jj * Co; v = w[((long long)co * Ci + ci) * k + (k - 1 - jj)]; }
+        const int co = (int)(e % Cop);
+        const long long t = e / Cop;
+        const int jj = (int)(t % k);
+        const long long ci = t / k;
+        if (co < Co) v = w[((long long)co * Ci + ci) * k + (k - 1 - jj)];
         dst = reinterpret_cast<__bf16*>(wd3) + e;
         plane = nd;
     } else {
@@ -784,37 +868,38 @@ static int launch_nt(const GemmNTArgs& a, int V, bool pro, hipStream_t s) {
 }
 
 template <int EPI>
-static int launch_nt_x6(const GemmNTArgs& a, int V, bool pro, hipStream_t s) {
-    const dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(256);
-#define IGN_X6L(VV, PP)                                                                                                        \
-    do {                                                                                                                       \
-        static bool once = false;                                                                                              \
-        if (!once) {                                                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_nt_x6_kernel<VV, PP, EPI>),                         \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6_LDS_BYTES);                          \
-            once = true;                                                                                                       \
-        }                                                                                                                      \
-        hipLaunchKernelGGL((clconv_nt_x6_kernel<VV, PP, EPI>), grid, block, X6_LDS_BYTES, s, a);                                \
+static int launch_x6t(const ConvX6Args& a, int V, bool pro, hipStream_t s) {
+    const dim3 grid((unsigned)(a.g.mtiles * a.g.ntiles)), block(256);
+#define IGN_X6T(VV, PP)                                                                                                      \
+    do {                                                                                                                     \
+        static bool once = false;                                                                                            \
+        if (!once) {                                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_x6t_kernel<VV, PP, EPI>),                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6T_LDS_BYTES);                       \
+            once = true;                                                                                                     \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((clconv_x6t_kernel<VV, PP, EPI>), grid, block, X6T_LDS_BYTES, s, a);                               \
     } while (0)
-    if (V == 4) { if (pro) IGN_X6L(4, true); else IGN_X6L(4, false); }
-    else if (V == 2) { if (pro) IGN_X6L(2, true); else IGN_X6L(2, false); }
-    else { if (pro) IGN_X6L(1, true); else IGN_X6L(1, false); }
-#undef IGN_X6L
-    return ign_check_launch("clconv_nt_x6_kernel");
+    if (V == 4) { if (pro) IGN_X6T(4, true); else IGN_X6T(4, false); }
+    else if (V == 2) { if (pro) IGN_X6T(2, true); else IGN_X6T(2, false); }
+    else { if (pro) IGN_X6T(1, true); else IGN_X6T(1, false); }
+#undef IGN_X6T
+    return ign_check_launch("clconv_x6t_kernel");
 }
 
-extern "C" int ign_clconv_kpad(int K) { return (K + 7) / 8 * 8; }
+extern "C" int ign_clconv_kpad(int C) { return (C + 15) / 16 * 16; }
+extern "C" long long ign_clconv_x6_mtiles(int B, int rows) { return (long long)B * ((rows + TM - 1) / TM); }
 
 extern "C" int ign_clconv_pack_weights_x3(const float* w_oik, void* wt3_fwd, void* wt3_dgrad, int Co, int Ci, int k, void* stream) {
     if (!w_oik || !wt3_fwd || Co <= 0 || Ci <= 0 || k <= 0) {
         ign_set_error("ign_clconv_pack_weights_x3: bad argument (Co=%d Ci=%d k=%d)", Co, Ci, k);
         return IGN_E_ARG;
     }
-    const int Kpf = ign_clconv_kpad(k * Ci), Kpd = ign_clconv_kpad(k * Co);
-    const long long n = (long long)Co * Kpf + (wt3_dgrad ? (long long)Ci * Kpd : 0);
-    hipLaunchKernelGGL(pack_weights_x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oik,
-                       (unsigned short*)wt3_fwd, (unsigned short*)wt3_dgrad, Co, Ci, k, Kpf, Kpd);
-    return ign_check_launch("pack_weights_x3_kernel");
+    const int Cip = ign_clconv_kpad(Ci), Cop = ign_clconv_kpad(Co);
+    const long long n = (long long)Co * k * Cip + (wt3_dgrad ? (long long)Ci * k * Cop : 0);
+    hipLaunchKernelGGL(pack_weights_x3t_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oik,
+                       (unsigned short*)wt3_fwd, (unsigned short*)wt3_dgrad, Co, Ci, k, Cip, Cop);
+    return ign_check_launch("pack_weights_x3t_kernel");
 }
 
 extern "C" long long ign_clconv_mtiles(long long M) { return (M + TM - 1) / TM; }
@@ -846,7 +931,15 @@ static int clconv_fwd_impl(const char* who, bool x6, const float* x, const void*
     a.pro_a = pro_a; a.pro_b = pro_b; a.pro_c = Ci; a.part = stat_part;
     a.mtiles = (int)((M + TM - 1) / TM); a.ntiles = (Co + TN - 1) / TN;
     IgnScopedTimer tm("clconv_fwd", (hipStream_t)stream);
-    if (x6) return launch_nt_x6<EPI_BIAS_STATS>(a, vec_width(Ci), pro_a != nullptr, (hipStream_t)stream);
+    if (x6) {
+        if (k > 16) { ign_set_error("%s: k=%d > 16 taps", who, k); return IGN_E_UNSUP; }
+        ConvX6Args c{};
+        c.g = a;
+        c.cin = Ci; c.cp = ign_clconv_kpad(Ci); c.k = k; c.g.Kp = k * c.cp;
+        c.sample_pitch = (long long)Tin * Ci; c.rows_in = Tin; c.trows = Tout; c.tps = (Tout + TM - 1) / TM;
+        c.g.mtiles = B * c.tps;
+        return launch_x6t<EPI_BIAS_STATS>(c, vec_width(Ci), pro_a != nullptr, (hipStream_t)stream);
+    }
     return launch_nt<EPI_BIAS_STATS>(a, vec_width(Ci), pro_a != nullptr, (hipStream_t)stream);
 }
 
@@ -879,7 +972,15 @@ static int clconv_dgrad_impl(const char* who, bool x6, const float* dyp, const v
     a.part = stat_part; a.ey = y_in; a.ea = a_in; a.eb = b_in; a.emean = mean_in; a.einv = invstd_in;
     a.mtiles = (int)((M + TM - 1) / TM); a.ntiles = (Ci + TN - 1) / TN;
     IgnScopedTimer tm("clconv_dgrad", (hipStream_t)stream);
-    if (x6) return launch_nt_x6<EPI_MASK_STATS>(a, vec_width(Co), false, (hipStream_t)stream);
+    if (x6) {
+        if (k > 16) { ign_set_error("%s: k=%d > 16 taps", who, k); return IGN_E_UNSUP; }
+        ConvX6Args c{};
+        c.g = a;
+        c.cin = Co; c.cp = ign_clconv_kpad(Co); c.k = k; c.g.Kp = k * c.cp;
+        c.sample_pitch = (long long)(Tout + 2 * (k - 1)) * Co; c.rows_in = Tout + 2 * (k - 1); c.trows = Tin; c.tps = (Tin + TM - 1) / TM;
+        c.g.mtiles = B * c.tps;
+        return launch_x6t<EPI_MASK_STATS>(c, vec_width(Co), false, (hipStream_t)stream);
+    }
     return launch_nt<EPI_MASK_STATS>(a, vec_width(Co), false, (hipStream_t)stream);
 }
 

@@ -61,6 +61,22 @@ __global__ void __launch_bounds__(256) bench_kernel(float* out, float seed) {
                               "v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4\n"
                               : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6)
                               : "v"(*(double*)&x0));)
+        } else if (MODE == 8) {   // 64 x v_sad_u32 acc, x, s_w, acc   (|x - w| + acc on 32-bit unsigned: ONE op per element)
+            REP8(asm volatile("v_sad_u32 %0, %8, %9, %0\n v_sad_u32 %1, %10, %9, %1\n v_sad_u32 %2, %11, %9, %2\n v_sad_u32 %3, %12, %9, %3\n"
+                              "v_sad_u32 %4, %8, %9, %4\n v_sad_u32 %5, %10, %9, %5\n v_sad_u32 %6, %11, %9, %6\n v_sad_u32 %7, %12, %9, %7\n"
+                              : "+v"(*(unsigned*)&a0), "+v"(*(unsigned*)&a1), "+v"(*(unsigned*)&a2), "+v"(*(unsigned*)&a3),
+                                "+v"(*(unsigned*)&a4), "+v"(*(unsigned*)&a5), "+v"(*(unsigned*)&a6), "+v"(*(unsigned*)&a7)
+                              : "v"(*(unsigned*)&x0), "s"(w), "v"(*(unsigned*)&x1), "v"(*(unsigned*)&x2), "v"(*(unsigned*)&x3));)
+        } else if (MODE == 9) {   // the same with a float flush every 16 elements: 64 v_sad + 4 x (v_cvt_f32_u32 ; v_add_f32)
+            REP8(asm volatile("v_sad_u32 %0, %8, %9, 0\n v_sad_u32 %1, %10, %9, 0\n v_sad_u32 %2, %11, %9, 0\n v_sad_u32 %3, %12, %9, 0\n"
+                              "v_sad_u32 %0, %10, %9, %0\n v_sad_u32 %1, %11, %9, %1\n v_sad_u32 %2, %12, %9, %2\n v_sad_u32 %3, %8, %9, %3\n"
+                              : "+v"(*(unsigned*)&a0), "+v"(*(unsigned*)&a1), "+v"(*(unsigned*)&a2), "+v"(*(unsigned*)&a3),
+                                "+v"(*(unsigned*)&a4), "+v"(*(unsigned*)&a5), "+v"(*(unsigned*)&a6), "+v"(*(unsigned*)&a7)
+                              : "v"(*(unsigned*)&x0), "s"(w), "v"(*(unsigned*)&x1), "v"(*(unsigned*)&x2), "v"(*(unsigned*)&x3));)
+            asm volatile("v_cvt_f32_u32 %4, %0\n v_add_f32 %8, %8, %4\n v_cvt_f32_u32 %5, %1\n v_add_f32 %9, %9, %5\n"
+                         "v_cvt_f32_u32 %6, %2\n v_add_f32 %10, %10, %6\n v_cvt_f32_u32 %7, %3\n v_add_f32 %11, %11, %7\n"
+                         : "+v"(*(unsigned*)&a0), "+v"(*(unsigned*)&a1), "+v"(*(unsigned*)&a2), "+v"(*(unsigned*)&a3),
+                           "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
@@ -88,18 +104,20 @@ int main() {
     const int threads = 256;
     CHECK(hipMalloc(&out, (size_t)256 * 16 * threads * sizeof(float)));
     // VALU instructions per iteration of the REP8 body
-    const int valu[8] = {64, 64, 64, 48, 32, 48, 64, 64};
-    const char* names[8] = {"v_add_f32", "v_sub+v_add|abs| (fwd loop)", "v_pk_add_f32", "cmp/nop/cndmask/add (bwd loop)",
-                            "cmpx/add/s_mov exec", "2x cmp(sgpr) / 2x cndmask / 2x add", "v_fma_f32", "v_pk_fma_f32"};
-    const int elems[8] = {64, 32, 128, 16, 16, 16, 64, 128};   // useful per-lane results per iteration
+    const int valu[10] = {64, 64, 64, 48, 32, 48, 64, 64, 64, 72};
+    const char* names[10] = {"v_add_f32", "v_sub+v_add|abs| (fwd loop)", "v_pk_add_f32", "cmp/nop/cndmask/add (bwd loop)",
+                            "cmpx/add/s_mov exec", "2x cmp(sgpr) / 2x cndmask / 2x add", "v_fma_f32", "v_pk_fma_f32",
+                            "v_sad_u32 (|x-w|+acc, 1 op/elem)", "v_sad_u32 x16 + cvt/add flush"};
+    const int elems[10] = {64, 32, 128, 16, 16, 16, 64, 128, 64, 64};   // useful per-lane results per iteration
     for (int wps = 1; wps <= 8; wps *= 2) {                    // waves per SIMD
         const int blocks = 256 * wps;                          // 256 CUs x wps blocks of 4 waves
         printf("--- %d wave(s) per SIMD (%d blocks x %d threads)\n", wps, blocks, threads);
-        double ms[8];
+        double ms[10];
         ms[0] = run<0>(out, blocks, threads); ms[1] = run<1>(out, blocks, threads); ms[2] = run<2>(out, blocks, threads);
         ms[3] = run<3>(out, blocks, threads); ms[4] = run<4>(out, blocks, threads); ms[5] = run<5>(out, blocks, threads);
         ms[6] = run<6>(out, blocks, threads); ms[7] = run<7>(out, blocks, threads);
-        for (int m = 0; m < 8; ++m) {
+        ms[8] = run<8>(out, blocks, threads); ms[9] = run<9>(out, blocks, threads);
+        for (int m = 0; m < 10; ++m) {
             const double waves = (double)blocks * threads / 64.0;
             const double winst = waves * ITERS * valu[m];
             const double per_simd_per_us = winst / 1024.0 / (ms[m] * 1e3);     // wave-instr / us / SIMD

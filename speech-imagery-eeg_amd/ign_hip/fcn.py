@@ -17,8 +17,11 @@ import torch
 from . import _lib
 
 
-# "f32": v_mfma_f32_32x32x2_f32; "bf16x6": the split-bf16 product on the bf16 matrix cores (fp32 rounding-level accuracy)
-CONV_MATH = os.environ.get("IGN_CONV_MATH", "f32")
+# Arithmetic of the forward / data-gradient GEMMs (the weight gradient is fp32 MFMA in both):
+#   "bf16x6": exact 3-way bf16 split of every fp32 operand, six partial products accumulated in fp32 on the bf16 matrix
+#             cores -- error vs float64 at the fp32 kernel's level (<= 3e-6 of max; tests/test_gpu_fcn.py), 1.6x its speed;
+#   "f32":    v_mfma_f32_32x32x2_f32 (runs at the fp32 VECTOR rate on gfx950).
+CONV_MATH = os.environ.get("IGN_CONV_MATH", "bf16x6")
 DEBUG = None       # set to a dict to capture the backward intermediates (tests/diag_fcn.py)
 
 
@@ -76,12 +79,12 @@ class FcnBodyFn(torch.autograd.Function):
                 raise _lib.IgnError(f"fcn_body block {l + 1}: input {tuple(h.shape)} vs weight {tuple(w.shape)}")
             st = states[l]
             y = torch.empty(B, Tout, Co, **f32)
-            nparts = int(L.ign_clconv_mtiles(B * Tout))
+            nparts = int(L.ign_clconv_x6_mtiles(B, Tout) if x6 else L.ign_clconv_mtiles(B * Tout))
             part = torch.empty(nparts, 2, Co, **f32) if st.use_batch_stats else None
             want_wd = l > 0 and need_grad
             if x6:
-                wt = torch.empty(3, Co, int(L.ign_clconv_kpad(k * Ci)), device=dev, dtype=torch.bfloat16)
-                wd = torch.empty(3, Ci, int(L.ign_clconv_kpad(k * Co)), device=dev, dtype=torch.bfloat16) if want_wd else None
+                wt = torch.empty(3, Co, k * int(L.ign_clconv_kpad(Ci)), device=dev, dtype=torch.bfloat16)
+                wd = torch.empty(3, Ci, k * int(L.ign_clconv_kpad(Co)), device=dev, dtype=torch.bfloat16) if want_wd else None
                 _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt), _ptr(wd), Co, Ci, k, _stream()), "ign_clconv_pack_weights_x3")
                 _lib.check(L.ign_clconv_fwd_x6(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part), B, Tin, Ci, Co, k,
                                                _stream()), "ign_clconv_fwd_x6")
@@ -167,7 +170,7 @@ class FcnBodyFn(torch.autograd.Function):
             if l > 0:
                 pa_, pb_, pm_, pi_ = affine[l - 1]
                 g = torch.empty(B, Tin, Ci, **f32)
-                nparts = int(L.ign_clconv_mtiles(B * Tin))
+                nparts = int(L.ign_clconv_x6_mtiles(B, Tin) if x6 else L.ign_clconv_mtiles(B * Tin))
                 part = torch.empty(nparts, 2, Ci, **f32)
                 dgrad = L.ign_clconv_dgrad_x6 if x6 else L.ign_clconv_dgrad
                 _lib.check(dgrad(_ptr(dyp), _ptr(wds[l]), _ptr(inputs[l]), _ptr(pa_), _ptr(pb_), _ptr(pm_), _ptr(pi_),

@@ -1,19 +1,16 @@
 """FCN deep expert (IGN/model/FullyConvNet.py:7-59): 3 x (Conv1d + BatchNorm1d + ReLU) -> GAP -> Linear.
 
-State-dict keys match the reference (``block{1,2,3}.{0,1}.*``, ``fc.*``).  Interim status: the
-convolutions run through torch's ROCm backend (MIOpen implicit-GEMM fp32-MFMA kernels, ~100-120 TFLOP/s measured); the
-hand-written implicit-GEMM kernel of SURVEY K7 is the next kernel on this path.
-
-Layout: the loader hands over x as (B, T, C), which IS the channels-last image (B, C, 1, T) -- so the whole expert runs
-as 2-D convolutions over that zero-copy view in NHWC, the layout MIOpen's igemm kernels compute in.  Feeding them
-(B, C, T) instead costs a transposed copy of the input plus 17 NCHW<->NHWC transposes of the activations per step
-(1.4 ms of 19 at the benchmark shape, profiles/r1c).
+State-dict keys match the reference (``block{1,2,3}.{0,1}.*``, ``fc.*``).  On the GPU the three blocks and the pool run as
+one autograd node over the hand-written channels-last implicit-GEMM kernels (ign_hip/fcn.py, csrc/ign_clconv.hip): the
+loader's (B, T, C) batch IS the GEMM operand (the im2col row of (b, t) is x[b, t:t+k, :], contiguous), BatchNorm statistics
+come out of the GEMM epilogue and BatchNorm's affine + ReLU are applied while the next GEMM stages its operand.
+``IGN_FCN_MIOPEN=1`` routes the convolutions through torch's MIOpen backend instead (A/B measurements only).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-
-import os
 
 from ign_hip import fcn, ops
 

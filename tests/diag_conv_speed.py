@@ -24,10 +24,10 @@ for (Tin, Ci, Co, k, pro) in [(1000, 122, 128, 8, False), (993, 128, 256, 5, Tru
     x = torch.randn(B, Tin, Ci, device=dev); w = torch.randn(Co, Ci, k, device=dev) / (Ci * k) ** 0.5; b = torch.randn(Co, device=dev)
     pa = (torch.rand(Ci, device=dev) + 0.5) if pro else None; pb = torch.randn(Ci, device=dev) if pro else None
     y = torch.empty(B, Tout, Co, device=dev); y6 = torch.empty_like(y)
-    part = torch.empty(int(L.ign_clconv_mtiles(B * Tout)), 2, Co, device=dev)
+    part = torch.empty(int(L.ign_clconv_x6_mtiles(B, Tout)), 2, Co, device=dev)
     wt = torch.empty(Co, k * Ci, device=dev); wd = torch.empty(Ci, k * Co, device=dev)
-    wt3 = torch.empty(3, Co, int(L.ign_clconv_kpad(k * Ci)), device=dev, dtype=torch.bfloat16)
-    wd3 = torch.empty(3, Ci, int(L.ign_clconv_kpad(k * Co)), device=dev, dtype=torch.bfloat16)
+    wt3 = torch.empty(3, Co, k * int(L.ign_clconv_kpad(Ci)), device=dev, dtype=torch.bfloat16)
+    wd3 = torch.empty(3, Ci, k * int(L.ign_clconv_kpad(Co)), device=dev, dtype=torch.bfloat16)
     _lib.check(L.ign_clconv_pack_weights(p(w), p(wt), p(wd), Co, Ci, k, s()), "pack")
     _lib.check(L.ign_clconv_pack_weights_x3(p(w), p(wt3), p(wd3), Co, Ci, k, s()), "pack3")
     flops = 2.0 * B * Tout * Co * Ci * k
@@ -38,7 +38,7 @@ for (Tin, Ci, Co, k, pro) in [(1000, 122, 128, 8, False), (993, 128, 256, 5, Tru
     if pro:
         dyp = torch.randn(B, Tout + 2 * (k - 1), Co, device=dev)
         g = torch.empty(B, Tin, Ci, device=dev); g6 = torch.empty_like(g)
-        partd = torch.empty(int(L.ign_clconv_mtiles(B * Tin)), 2, Ci, device=dev)
+        partd = torch.empty(int(L.ign_clconv_x6_mtiles(B, Tin)), 2, Ci, device=dev)
         mean = torch.randn(Ci, device=dev); inv = torch.rand(Ci, device=dev) + 0.5
         flops = 2.0 * B * Tin * Co * Ci * k
         t32 = timeit(lambda: _lib.check(L.ign_clconv_dgrad(p(dyp), p(wd), p(x), p(pa), p(pb), p(mean), p(inv), p(g), p(partd), B, Tin, Ci, Co, k, s()), "d"))
