@@ -626,6 +626,183 @@ __global__ void __launch_bounds__(256, 2) clconv_tn_kernel(const GemmTNArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient, split bf16
+// dW[co][j][ci] = sum_{b,t} dy[b,t,co] * in[b,t+j,ci] on the bf16 matrix cores (same six-term split as above).
+// The reduction index is the ROW index of both operands, so the MFMA needs each operand column-major; the operands are
+// staged row-major (as they arrive: coalesced loads, one split per element) and read with gfx950's transposing LDS read
+// ds_read_b64_tr_b16, which hands lane i the 4 consecutive rows of column i.  Because rows stay rows in LDS, tap j is
+// again just a row offset: one staged (16*NR + k - 1)-row span of the input serves all k taps, and the dy fragments are
+// read once per unit and reused by every tap.  Workgroup tile: 64 co x 64 ci x k taps (wave: 32 x 32 x k taps = k
+// accumulators), reduction over units of 16*NR output rows that never straddle a sample, split over unit ranges.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int WG_PITCH = 64 + 32;             // bf16 per staged row: 192 B; four rows' 32-dword windows tile the 64 banks
+
+struct WgradX6Args {
+    const float* dy; long long dy_sample_pitch; int dy_row0;     // dy[b][dy_row0 + t][co], row pitch Co
+    const float* x; long long x_sample_pitch;                      // in[b][t][ci], row pitch Ci
+    const float* pro_a; const float* pro_b;                        // in = relu(pro_a*x + pro_b) (or raw x)
+    float* part;                                                   // (nsplit, Co, k*Ci)
+    int B, Tin, Tout, Ci, Co, k;
+    int cps;                                                       // units per sample
+    int nunits, nsplit, citiles;
+};
+
+__device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p1));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int KT, int NR, int VX, bool PRO>
+__global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Args a) {
+    constexpr int RU = 16 * NR;                     // output rows per unit
+    constexpr int SPAN = RU + KT - 1;               // input rows per unit
+    constexpr int PPLANE = RU * WG_PITCH, QPLANE = SPAN * WG_PITCH;
+    constexpr int STAGE = 3 * (PPLANE + QPLANE);
+    constexpr int XVPR = 64 / VX;                   // input vectors per row
+    constexpr int XPASS = (SPAN * XVPR + 255) / 256;
+    constexpr int DPASS = NR;                       // dy: RU rows x 16 float4 = 256 * NR vectors
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    __bf16* smem = reinterpret_cast<__bf16*>(smem16);
+
+    const int tile = blockIdx.x;
+    const int cot = tile / a.citiles, cit = tile - cot * a.citiles;
+    const int co0 = cot * 64, ci0 = cit * 64;
+    const int split = blockIdx.y;
+    const int per = (a.nunits + a.nsplit - 1) / a.nsplit;
+    const int u_begin = split * per, u_end = min(a.nunits, u_begin + per);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wco = wave & 1, wci = wave >> 1;
+
+    // staging coordinates
+    const int dr = tid >> 4, dc = (tid & 15) * 4;            // dy: row dr (+16 per pass), 4 channels from dc
+    const bool d_ok = co0 + dc < a.Co;                        // Co % 4 == 0
+    const int xq = (tid % XVPR) * VX;                         // input: channel offset inside the tile (256 % XVPR == 0)
+    const bool x_ok = ci0 + xq < a.Ci;                        // VX divides Ci
+    float pa[VX], pb[VX];
+    if (PRO && x_ok) { vload<VX>(pa, a.pro_a + ci0 + xq); vload<VX>(pb, a.pro_b + ci0 + xq); }
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    float rd[DPASS][4], rx[XPASS][VX];
+    auto gload = [&](int u) {
+        const int b = u / a.cps, t0 = (u - b * a.cps) * RU;
+        const float* dyb = a.dy + (long long)b * a.dy_sample_pitch + (long long)a.dy_row0 * a.Co + co0 + dc;
+        const float* xb = a.x + (long long)b * a.x_sample_pitch + ci0 + xq;
+#pragma unroll
+        for (int p = 0; p < DPASS; ++p) {
+            const int t = t0 + dr + 16 * p;
+            if (d_ok && t < a.Tout) vload<4>(rd[p], dyb + (long long)t * a.Co);
+            else { rd[p][0] = rd[p][1] = rd[p][2] = rd[p][3] = 0.f; }
+        }
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+            const int row = (tid + p * 256) / XVPR;
+            if (x_ok && row < SPAN) vload<VX>(rx[p], xb + (long long)min(t0 + row, a.Tin - 1) * a.Ci);
+            else {
+#pragma unroll
+                for (int v = 0; v < VX; ++v) rx[p][v] = 0.f;
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        __bf16* P = smem + buf * STAGE;
+        __bf16* Q = P + 3 * PPLANE;
+#pragma unroll
+        for (int p = 0; p < DPASS; ++p) {
+            __bf16* d = P + (dr + 16 * p) * WG_PITCH + dc;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                __bf16 x0, x1, x2;
+                split3(rd[p][v], x0, x1, x2);
+                d[v] = x0; d[PPLANE + v] = x1; d[2 * PPLANE + v] = x2;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+            const int row = (tid + p * 256) / XVPR;
+            if (row < SPAN) {
+                __bf16* d = Q + row * WG_PITCH + xq;
+#pragma unroll
+                for (int v = 0; v < VX; ++v) {
+                    float t = rx[p][v];
+                    if (PRO && x_ok) t = fmaxf(fmaf(pa[v], t, pb[v]), 0.f);
+                    __bf16 x0, x1, x2;
+                    split3(t, x0, x1, x2);
+                    d[v] = x0; d[QPLANE + v] = x1; d[2 * QPLANE + v] = x2;
+                }
+            }
+        }
+    };
+
+    // transposed-read addresses: 16-lane group G = lane>>4 reads the 4-row x 16-column block whose rows are supplied by
+    // lanes 4q+p (row q, columns 4p..4p+3); lane u of the group receives column u.  For the 32x32x16 operand lane (i, g)
+    // needs rows 8g..8g+7 of column i: two reads (rows 8g..8g+3 and 8g+4..8g+7) of the block at columns 16*(G&1).
+    const int u16 = lane & 15, q4 = u16 >> 2, p4 = u16 & 3, G1 = (lane >> 4) & 1;
+    const int row_lo = 8 * h + q4;
+    const int acol = wco * 32 + 16 * G1 + 4 * p4;
+    const int bcol = wci * 32 + 16 * G1 + 4 * p4;
+
+    if (u_begin < u_end) {
+        gload(u_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int u = u_begin; u < u_end; ++u, buf ^= 1) {
+        if (u + 1 < u_end) gload(u + 1);
+        const __bf16* P = smem + buf * STAGE;
+        const __bf16* Q = P + 3 * PPLANE;
+#pragma unroll
+        for (int s = 0; s < NR; ++s) {
+            bf16x8 af[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const __bf16* base = P + pl * PPLANE + (16 * s + row_lo) * WG_PITCH + acol;
+                af[pl] = lds_tr8(base, base + 4 * WG_PITCH);
+            }
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                bf16x8 bf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const __bf16* base = Q + pl * QPLANE + (16 * s + row_lo + j) * WG_PITCH + bcol;
+                    bf[pl] = lds_tr8(base, base + 4 * WG_PITCH);
+                }
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[j], 0, 0, 0);
+            }
+        }
+        if (u + 1 < u_end) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = a.part + (long long)split * a.Co * a.k * a.Ci;
+    const int ci = ci0 + wci * 32 + l31;
+    if (ci < a.Ci) {
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco * 32 + acc_row16(r, h);
+                if (co < a.Co) out[((long long)co * a.k + j) * a.Ci + ci] = acc[j][r];
+            }
+    }
+}
+
 // dW[co][ci][j] = sum_s part[s][co][j*Ci + ci]   (s ascending: bitwise reproducible); torch (Co, Ci, k) layout
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit,
                                                            int Co, int Ci, int k) {
@@ -1046,6 +1223,79 @@ extern "C" int ign_clconv_wgrad(const float* dyp, int dy_pad, const float* x, co
     }
     int rc;
     if ((rc = ign_check_launch("clconv_tn_kernel"))) return rc;
+    const long long n = (long long)Co * Ci * k;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace, dw_oik,
+                       a.nsplit, Co, Ci, k);
+    return ign_check_launch("wgrad_reduce_kernel");
+}
+
+template <int KT, int NR>
+static int launch_wgrad_x6(const WgradX6Args& a, int V, bool pro, dim3 grid, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * 3 * ((16 * NR) + (16 * NR + KT - 1)) * WG_PITCH * sizeof(unsigned short);
+#define IGN_WG(VV, PP)                                                                                                       \
+    do {                                                                                                                     \
+        static bool once = false;                                                                                            \
+        if (!once) {                                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_wgrad_x6_kernel<KT, NR, VV, PP>),                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+            once = true;                                                                                                     \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((clconv_wgrad_x6_kernel<KT, NR, VV, PP>), grid, dim3(256), lds, s, a);                             \
+    } while (0)
+    if (V == 4) { if (pro) IGN_WG(4, true); else IGN_WG(4, false); }
+    else if (V == 2) { if (pro) IGN_WG(2, true); else IGN_WG(2, false); }
+    else { if (pro) IGN_WG(1, true); else IGN_WG(1, false); }
+#undef IGN_WG
+    return ign_check_launch("clconv_wgrad_x6_kernel");
+}
+
+static int wgrad_x6_rows_per_unit(int k) { return (k == 8 || k == 5) ? 16 : (k == 3 || k == 2) ? 32 : 0; }
+static int wgrad_x6_splits(int nunits, int tiles) {
+    int s = (512 + tiles - 1) / tiles;                        // ~2 workgroups per CU
+    const int max_s = (nunits + 15) / 16;                     // at least 16 units per split
+    if (s > max_s) s = max_s;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" size_t ign_clconv_wgrad_x6_workspace_bytes(int B, int Tin, int Ci, int Co, int k) {
+    const int Tout = Tin - k + 1, ru = wgrad_x6_rows_per_unit(k);
+    if (B <= 0 || Tout <= 0 || Ci <= 0 || Co <= 0 || !ru) return 0;
+    const int tiles = ((Co + 63) / 64) * ((Ci + 63) / 64);
+    const int nunits = B * ((Tout + ru - 1) / ru);
+    return (size_t)wgrad_x6_splits(nunits, tiles) * Co * k * Ci * sizeof(float);
+}
+
+extern "C" int ign_clconv_wgrad_x6(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
+                                   float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream) {
+    static const char* who = "ign_clconv_wgrad_x6";
+    const int Tout = Tin - k + 1, ru = wgrad_x6_rows_per_unit(k);
+    if (!dyp || !x || !dw_oik || !workspace || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || dy_pad < 0 ||
+        ((pro_a == nullptr) != (pro_b == nullptr))) {
+        ign_set_error("%s: bad argument (B=%d Tin=%d Ci=%d Co=%d k=%d pad=%d)", who, B, Tin, Ci, Co, k, dy_pad);
+        return IGN_E_ARG;
+    }
+    if (Co % 4 || !ru) { ign_set_error("%s: needs Co %% 4 == 0 and k in {2,3,5,8} (Co=%d k=%d)", who, Co, k); return IGN_E_UNSUP; }
+    hipStream_t s = (hipStream_t)stream;
+    WgradX6Args a{};
+    a.dy = dyp; a.dy_sample_pitch = (long long)(Tout + 2 * dy_pad) * Co; a.dy_row0 = dy_pad;
+    a.x = x; a.x_sample_pitch = (long long)Tin * Ci; a.pro_a = pro_a; a.pro_b = pro_b;
+    a.part = (float*)workspace; a.B = B; a.Tin = Tin; a.Tout = Tout; a.Ci = Ci; a.Co = Co; a.k = k;
+    a.cps = (Tout + ru - 1) / ru; a.nunits = B * a.cps;
+    a.citiles = (Ci + 63) / 64;
+    const int tiles = ((Co + 63) / 64) * a.citiles;
+    a.nsplit = wgrad_x6_splits(a.nunits, tiles);
+    const dim3 grid((unsigned)tiles, (unsigned)a.nsplit);
+    const int V = vec_width(Ci);
+    const bool pro = pro_a != nullptr;
+    int rc;
+    {
+        IgnScopedTimer tm("clconv_wgrad", s);
+        if (k == 8) rc = launch_wgrad_x6<8, 1>(a, V, pro, grid, s);
+        else if (k == 5) rc = launch_wgrad_x6<5, 1>(a, V, pro, grid, s);
+        else if (k == 3) rc = launch_wgrad_x6<3, 2>(a, V, pro, grid, s);
+        else rc = launch_wgrad_x6<2, 2>(a, V, pro, grid, s);
+    }
+    if (rc) return rc;
     const long long n = (long long)Co * Ci * k;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace, dw_oik,
                        a.nsplit, Co, Ci, k);

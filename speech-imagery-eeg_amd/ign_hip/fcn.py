@@ -156,10 +156,13 @@ class FcnBodyFn(torch.autograd.Function):
             del g
             # weight gradient; the operand below is relu(bn(y_{l-1})) recomputed on the fly (raw x for the first block)
             pa, pb = (affine[l - 1][0], affine[l - 1][1]) if l > 0 else (None, None)
-            ws = torch.empty(int(L.ign_clconv_wgrad_workspace_bytes(B, Tin, Ci, Co, k)) // 4, **f32)
+            wx6 = x6 and k in (2, 3, 5, 8)
+            ws_bytes = (L.ign_clconv_wgrad_x6_workspace_bytes if wx6 else L.ign_clconv_wgrad_workspace_bytes)(B, Tin, Ci, Co, k)
+            ws = torch.empty(int(ws_bytes) // 4, **f32)
             dw = torch.empty(Co, Ci, k, **f32)
-            _lib.check(L.ign_clconv_wgrad(_ptr(dyp), pad, _ptr(inputs[l]), _ptr(pa), _ptr(pb), _ptr(dw), _ptr(ws), B, Tin, Ci, Co, k,
-                                          _stream()), "ign_clconv_wgrad")
+            wgrad = L.ign_clconv_wgrad_x6 if wx6 else L.ign_clconv_wgrad
+            _lib.check(wgrad(_ptr(dyp), pad, _ptr(inputs[l]), _ptr(pa), _ptr(pb), _ptr(dw), _ptr(ws), B, Tin, Ci, Co, k,
+                             _stream()), "ign_clconv_wgrad")
             del ws
             grads[4 * l + 0] = dw
             # The bias in front of a batch-statistics BatchNorm has an identically zero gradient (the batch mean removes

@@ -35,6 +35,14 @@ for (Tin, Ci, Co, k, pro) in [(1000, 122, 128, 8, False), (993, 128, 256, 5, Tru
     t6 = timeit(lambda: _lib.check(L.ign_clconv_fwd_x6(p(x), p(wt3), p(b), p(pa), p(pb), p(y6), p(part), B, Tin, Ci, Co, k, s()), "f6"))
     err = float((y - y6).abs().max() / y.abs().max())
     print(f"fwd  Ci={Ci} Co={Co} k={k}: f32 {t32:.3f} ms ({flops/t32/1e9:.0f} TFLOP/s)  bf16x6 {t6:.3f} ms ({flops/t6/1e9:.0f} TFLOP/s-equiv)  max rel diff {err:.1e}", flush=True)
+    dy0 = torch.randn(B, Tout, Co, device=dev)
+    dw = torch.empty(Co, Ci, k, device=dev); dw6 = torch.empty_like(dw)
+    ws = torch.empty(int(L.ign_clconv_wgrad_workspace_bytes(B, Tin, Ci, Co, k)) // 4, device=dev)
+    ws6 = torch.empty(int(L.ign_clconv_wgrad_x6_workspace_bytes(B, Tin, Ci, Co, k)) // 4, device=dev)
+    t32 = timeit(lambda: _lib.check(L.ign_clconv_wgrad(p(dy0), 0, p(x), p(pa), p(pb), p(dw), p(ws), B, Tin, Ci, Co, k, s()), "w"))
+    t6 = timeit(lambda: _lib.check(L.ign_clconv_wgrad_x6(p(dy0), 0, p(x), p(pa), p(pb), p(dw6), p(ws6), B, Tin, Ci, Co, k, s()), "w6"))
+    err = float((dw - dw6).abs().max() / dw.abs().max())
+    print(f"wgrad Ci={Ci} Co={Co} k={k}: f32 {t32:.3f} ms ({flops/t32/1e9:.0f} TFLOP/s)  bf16x6 {t6:.3f} ms ({flops/t6/1e9:.0f} TFLOP/s-equiv)  max rel diff {err:.1e}", flush=True)
     if pro:
         dyp = torch.randn(B, Tout + 2 * (k - 1), Co, device=dev)
         g = torch.empty(B, Tin, Ci, device=dev); g6 = torch.empty_like(g)

@@ -151,7 +151,8 @@ def _away_from_kink(y, a, b, margin=1e-3):
     return torch.where(bad, y + 4 * margin / a, y)
 
 
-@pytest.mark.parametrize("B,Tin,Ci,Co,k", [(2, 989, 256, 128, 3), (2, 993, 128, 256, 5), (3, 50, 64, 128, 3), (1, 9, 128, 256, 2)])
+@pytest.mark.parametrize("B,Tin,Ci,Co,k", [(2, 989, 256, 128, 3), (2, 993, 128, 256, 5), (3, 50, 64, 128, 3), (1, 9, 128, 256, 2),
+                                           (2, 100, 120, 128, 8), (3, 77, 36, 64, 8)])
 @pytest.mark.parametrize("math", ["f32", "bf16x6"])
 def test_clconv_dgrad_and_wgrad_kernels(B, Tin, Ci, Co, k, math):
     """ign_clconv_dgrad (ReLU mask + BatchNorm-backward sums in the epilogue) and ign_clconv_wgrad (prologue recomputes
@@ -204,10 +205,13 @@ def test_clconv_dgrad_and_wgrad_kernels(B, Tin, Ci, Co, k, math):
     assert _rel(gin, g_ref) < 3e-6
     assert _rel(part[:, 0].double().sum(0), s1_ref) < TOL and _rel(part[:, 1].double().sum(0), s2_ref) < TOL
 
-    ws = torch.empty(int(L.ign_clconv_wgrad_workspace_bytes(B, Tin, Ci, Co, k)) // 4, device=dev)
+    x6w = math == "bf16x6" and k in (2, 3, 5, 8)
+    nbytes = (L.ign_clconv_wgrad_x6_workspace_bytes if x6w else L.ign_clconv_wgrad_workspace_bytes)(B, Tin, Ci, Co, k)
+    ws = torch.empty(int(nbytes) // 4, device=dev)
     dw = torch.full((Co, Ci, k), float("nan"), device=dev)
-    _lib.check(L.ign_clconv_wgrad(_p(dypd), pad, _p(yind), _p(ad), _p(bd), _p(dw), _p(ws), B, Tin, Ci, Co, k, _s()), "wgrad")
-    assert _rel(dw, wdbl.grad) < TOL
+    wgrad = L.ign_clconv_wgrad_x6 if x6w else L.ign_clconv_wgrad
+    _lib.check(wgrad(_p(dypd), pad, _p(yind), _p(ad), _p(bd), _p(dw), _p(ws), B, Tin, Ci, Co, k, _s()), "wgrad")
+    assert _rel(dw, wdbl.grad) < 3e-6
 
 
 def test_fcn_body_is_deterministic_and_matches_full_batch_shape():
