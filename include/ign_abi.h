@@ -47,6 +47,13 @@ const char* ign_last_error(void);
 int ign_instnorm_fwd(const float* x_btc, float* xn_bct, float* xt_bct, int B, int T, int C, float eps,
                      void* stream);
 
+/* On-GPU input pipeline of the CHISCO loader: raw (B,C,T) recordings -> standardised (B,T,C) batches.
+ * Replaces, per batch, Normalizer('per_sample_std') of IGN/data_factory/eeg.py:332-367 (per sample and channel over time:
+ * (x - mean) / (std(ddof=1) + eps)) and the (C,T) -> (T,C) item transpose that IGN/data_factory/uea.py:7-42 batches.
+ * stats_ws: B*C*2 floats of workspace (mean, 1/(std+eps) per row).                                                    */
+int ign_standardise_nct_to_btc(const float* x_nct, float* out_btc, float* stats_ws, int B, int C, int T, float eps,
+                               void* stream);
+
 /* Shapelet transform of ONE length group: sliding-window distance + gate, never materialising (B,Tw,K,C,L).
  * Replaces IGN/model/Shapelet.py:60-84 (GATE_RBF) / :96-111 (GATE_LTS).   Tw = (T-L)/stride + 1.
  *   xn_bct   (B,C,T)    normalised input

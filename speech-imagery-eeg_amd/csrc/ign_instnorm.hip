@@ -69,3 +69,75 @@ extern "C" int ign_instnorm_fwd(const float* x_btc, float* xn_bct, float* xt_bct
                        xt_bct, B, T, C, CT, eps);
     return ign_check_launch("instnorm_kernel");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// On-GPU input pipeline of the CHISCO loader: raw (B, C, T) microvolt recordings -> per-sample, per-channel standardised
+// (B, T, C) batches, i.e. Normalizer('per_sample_std') of IGN/data_factory/eeg.py:332-367 followed by the (C,T) -> (T,C)
+// item transpose of the UEA item contract, for a whole batch in two HBM passes instead of B CPU passes in the DataLoader.
+//   pass 1: one wave per (b, c) row: mean and unbiased variance in two sweeps over the row held in registers / L1
+//           (no E[x^2] - E[x]^2 cancellation: the recordings carry offsets of 1e4 uV);
+//   pass 2: 64 (t) x 32 (c) tiles transposed through LDS: coalesced 256-byte reads along t, 128-byte writes along c.
+__global__ void __launch_bounds__(256) std_rowstats_kernel(const float* __restrict__ x, float* __restrict__ stats, int rows,
+                                                           int T, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * T;
+    float s = 0.f;
+    for (int t = lane; t < T; t += 64) s += xr[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)T;
+    float v = 0.f;
+    for (int t = lane; t < T; t += 64) {
+        const float dv = xr[t] - mean;
+        v = fmaf(dv, dv, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) {
+        stats[2 * (size_t)row] = mean;
+        stats[2 * (size_t)row + 1] = 1.f / (sqrtf(v / (float)(T - 1)) + eps);      // ddof = 1, eps outside the sqrt
+    }
+}
+
+__global__ void __launch_bounds__(256) std_apply_transpose_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                                  float* __restrict__ out, int C, int T) {
+    __shared__ float tile[32][65];
+    const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int cc = w * 8 + i, c = c0 + cc, t = t0 + lane;
+        float v = 0.f;
+        if (c < C && t < T) {
+            const size_t row = (size_t)b * C + c;
+            v = (x[row * T + t] - stats[2 * row]) * stats[2 * row + 1];
+        }
+        tile[cc][lane] = v;
+    }
+    __syncthreads();
+    const int cc = threadIdx.x & 31, tr = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int tl = tr * 8 + i, t = t0 + tl, c = c0 + cc;
+        if (t < T && c < C) out[((size_t)b * T + t) * C + c] = tile[cc][tl];
+    }
+}
+
+extern "C" int ign_standardise_nct_to_btc(const float* x_nct, float* out_btc, float* stats_ws, int B, int C, int T, float eps,
+                                          void* stream) {
+    if (!x_nct || !out_btc || !stats_ws || B <= 0 || C <= 0 || T <= 1) {
+        ign_set_error("ign_standardise_nct_to_btc: null pointer or bad dimension (B=%d C=%d T=%d)", B, C, T);
+        return IGN_E_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = B * C;
+    IgnScopedTimer tm("standardise", s);
+    hipLaunchKernelGGL(std_rowstats_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x_nct, stats_ws, rows, T, eps);
+    int rc;
+    if ((rc = ign_check_launch("std_rowstats_kernel"))) return rc;
+    hipLaunchKernelGGL(std_apply_transpose_kernel, dim3((T + 63) / 64, (C + 31) / 32, B), dim3(256), 0, s, x_nct, stats_ws, out_btc,
+                       C, T);
+    return ign_check_launch("std_apply_transpose_kernel");
+}

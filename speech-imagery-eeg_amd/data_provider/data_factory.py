@@ -10,7 +10,7 @@ import torch.distributed as dist
 from torch.utils.data import DataLoader, Sampler
 
 from data_provider.data_loader import UEAloader
-from data_provider.eeg_npy import EEGNpyDataset, EEGNpyDataset3Class
+from data_provider.eeg_npy import EEGNpyDataset, EEGNpyDataset3Class, collate_raw
 from data_provider.synthetic import SyntheticEEG
 from data_provider.uea import collate_fn
 
@@ -55,8 +55,10 @@ def data_provider(args, flag, bin_edges=None):
         data_set = Data(flag=flag, n=n if flag == 'train' else max(args.batch_size, n // 8), seq_len=T, enc_in=C,
                         num_classes=N)
     elif args.data in ('EEG', 'EEG3'):
+        # on a GPU the items stay RAW and the batch is standardised + transposed on the device (device_prefetch.py)
+        raw = bool(getattr(args, 'device_standardise', torch.cuda.is_available()))
         data_set = Data(root_path=args.root_path, flag=flag, test_size=getattr(args, 'test_size', 0.2),
-                        val_size=getattr(args, 'val_size', 0.1))
+                        val_size=getattr(args, 'val_size', 0.1), raw=raw)
     else:
         data_set = Data(root_path=args.root_path, flag=flag)
 
@@ -65,7 +67,9 @@ def data_provider(args, flag, bin_edges=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and flag == 'train':
         sampler = RankShardSampler(len(data_set), dist.get_rank(), dist.get_world_size(), shuffle,
                                    seed=max(0, getattr(args, 'seed', 0)))
+    raw = bool(getattr(data_set, 'raw', False))
     loader = DataLoader(data_set, batch_size=args.batch_size, shuffle=(shuffle and sampler is None), sampler=sampler,
-                        num_workers=args.num_workers, drop_last=False,
-                        collate_fn=lambda b: collate_fn(b, max_len=max_len))
+                        num_workers=args.num_workers, drop_last=False, pin_memory=torch.cuda.is_available(),
+                        collate_fn=collate_raw if raw else (lambda b: collate_fn(b, max_len=max_len)))
+    loader.device_transform = 'standardise_raw' if raw else None
     return data_set, loader

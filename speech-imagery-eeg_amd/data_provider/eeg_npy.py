@@ -36,7 +36,8 @@ def split_indices(n, flag, test_size=0.2, val_size=0.1, seed=42):
 class EEGNpyDataset(Dataset):
     num_label_classes = 39
 
-    def __init__(self, root_path, flag='train', label_map=None, test_size=0.2, val_size=0.1, mmap=True, **_):
+    def __init__(self, root_path, flag='train', label_map=None, test_size=0.2, val_size=0.1, mmap=True, raw=False, **_):
+        self.raw = bool(raw)      # True: items are RAW (C,T) recordings; the batch is standardised on the GPU instead
         xp, yp = os.path.join(root_path, "X.npy"), os.path.join(root_path, "y.npy")
         if not (os.path.exists(xp) and os.path.exists(yp)):
             raise FileNotFoundError(f"{root_path}: expected X.npy (n,C,T) and y.npy (n,) exported from the CHISCO "
@@ -55,8 +56,17 @@ class EEGNpyDataset(Dataset):
 
     def __getitem__(self, i):
         j = self.idx[i]
-        x = per_sample_standardise(np.asarray(self.X[j], dtype=np.float32))
-        return torch.from_numpy(x.T.copy()), torch.tensor([self.y[j]], dtype=torch.int64)
+        x = np.asarray(self.X[j], dtype=np.float32)
+        y = torch.tensor([self.y[j]], dtype=torch.int64)
+        if self.raw:              # device pipeline: data_provider.device_prefetch.standardise_raw_batch does the rest
+            return torch.from_numpy(np.ascontiguousarray(x)), y
+        return torch.from_numpy(per_sample_standardise(x).T.copy()), y
+
+
+def collate_raw(data):
+    """list of (X[C,T] raw, y[1]) -> (X[B,C,T], y[B,1], None): the batch contract before the device transform."""
+    feats, labels = zip(*data)
+    return torch.stack(feats, dim=0), torch.stack(labels, dim=0), None
 
 
 class EEGNpyDataset3Class(EEGNpyDataset):

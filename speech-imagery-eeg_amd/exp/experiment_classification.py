@@ -23,7 +23,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from data_provider.data_factory import data_provider
-from ign_hip.ddp import FlatParamBucket
+from data_provider.device_prefetch import DevicePrefetcher, standardise_raw_batch
+from ign_hip.ddp import FlatAdam, FlatParamBucket
 from models.FullyConvNet import FullyConvNetwork
 from models.InterpGN import InterpGN, dnn_dict
 from models.Shapelet import DistThresholdSBM, ShapeBottleneckModel
@@ -84,13 +85,21 @@ class Experiment(object):
         self.val_data, self.val_loader = data_provider(args, flag="val")
         self.test_data, self.test_loader = data_provider(args, flag="test")
         self._get_params_from_data()
+        # host -> device double buffering (and, for raw CHISCO shards, the on-GPU standardise + transpose)
+        self.train_loader, self.val_loader, self.test_loader = (self._prefetch(l) for l in
+                                                                (self.train_loader, self.val_loader, self.test_loader))
 
         self.model = self._build_model().to(self.device)
+        # On the GPU the step uses the flat path of bench.py: gradients are views into one buffer (a single RCCL all-reduce
+        # under torch.distributed) and Adam is one ign_adam_step launch over the flat parameter buffer.
         self.bucket = None
-        if self.distributed:
+        if self.distributed or self.device.type == 'cuda':
             self.bucket = FlatParamBucket(self.model, self.world)
             self.bucket.broadcast_state(0)
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.args.lr)
+        if self.device.type == 'cuda':
+            self.optimizer = FlatAdam(self.bucket, lr=self.args.lr)
+        else:
+            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.args.lr)
         self.scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(self.optimizer, T_0=self.args.train_epochs)
         self.checkpoint_dir = "./checkpoints/{}/{}/dnn-{}_seed-{}_k-{}_div-{}_reg-{}_eps-{}_beta-{}_dfunc-{}_cls-{}".format(
             args.model, args.dataset, args.dnn_type, args.seed, args.num_shapelet, args.lambda_div, args.lambda_reg,
@@ -102,6 +111,12 @@ class Experiment(object):
         print(f"Experiment: model={args.model} dnn={getattr(args, 'dnn_type', None)} device={self.device} "
               f"world={self.world} seq_len={args.seq_len} enc_in={args.enc_in} num_class={args.num_class} "
               f"train/val/test={len(self.train_data)}/{len(self.val_data)}/{len(self.test_data)}")
+
+    def _prefetch(self, loader):
+        transform = standardise_raw_batch if getattr(loader, 'device_transform', None) == 'standardise_raw' else None
+        if self.device.type != 'cuda' and transform is None:
+            return loader
+        return DevicePrefetcher(loader, self.device, transform=transform)
 
     # ------------------------------------------------------------------------------------------------
     def _get_params_from_data(self):

@@ -13,6 +13,8 @@ import torch.distributed as dist
 
 
 class FlatParamBucket:
+    ALIGN = 64          # floats
+
     def __init__(self, module, world_size=None, process_group=None):
         self.group = process_group
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
@@ -20,14 +22,17 @@ class FlatParamBucket:
         if not self.params:
             raise ValueError("module has no trainable parameters")
         dev, dt = self.params[0].device, self.params[0].dtype
-        n = sum(p.numel() for p in self.params)
-        self.flat_grad = torch.zeros(n, device=dev, dtype=dt)
-        off = 0
+        # every parameter starts on a 256-byte boundary of the flat buffer: the HIP kernels read parameters and write
+        # gradients with 16-byte vector accesses (the zero padding in between is inert for the all-reduce and for Adam)
+        self.offsets, n = [], 0
         for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.flat_grad = torch.zeros(n, device=dev, dtype=dt)
+        for p, off in zip(self.params, self.offsets):
             if p.device != dev or p.dtype != dt:
                 raise ValueError("all parameters must share one device and dtype")
             p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
-            off += p.numel()
         self.module = module
 
     @property
@@ -65,44 +70,47 @@ def shard_indices(n, rank, world, epoch=0, seed=0, shuffle=True):
     return perm[rank * per:(rank + 1) * per]
 
 
-class FlatAdam:
+class FlatAdam(torch.optim.Optimizer):
     """Adam over ONE flat parameter buffer: a single `ign_adam_step` launch per optimizer step instead of torch's
     per-tensor (or multi-tensor) update -- torch.optim.Adam semantics (betas (0.9, 0.999), eps 1e-8, no weight decay),
     as constructed at IGN/exp/experiment_classification.py:136.
 
     Parameters become views into `flat_param` (same trick as the gradient bucket), so the model, its state_dict and
-    checkpoints are unaffected.  Needs the bucket (its flat gradient is the kernel's input).
+    checkpoints are unaffected.  Needs the bucket (its flat gradient is the kernel's input).  A torch Optimizer
+    subclass, so lr schedulers (CosineAnnealingWarmRestarts at :137) attach to it; the learning rate is read from
+    ``param_groups[0]['lr']`` at every step.
     """
 
     def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         from . import _lib
-        self._lib = _lib
-        self.bucket, self.lr, self.betas, self.eps = bucket, lr, betas, eps
-        self.step_count = 0
         ps = bucket.params
         if not ps[0].is_cuda:
             raise _lib.IgnError("FlatAdam runs on the GPU only")
-        self.flat_param = torch.empty_like(bucket.flat_grad)
-        off = 0
+        super().__init__(ps, dict(lr=lr, betas=betas, eps=eps))
+        self._lib = _lib
+        self.bucket, self.lr, self.betas, self.eps = bucket, lr, betas, eps
+        self.step_count = 0
+        self.flat_param = torch.zeros_like(bucket.flat_grad)
         with torch.no_grad():
-            for p in ps:
+            for p, off in zip(ps, bucket.offsets):
                 n = p.numel()
                 self.flat_param[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_param[off:off + n].view_as(p)
-                off += n
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
-        self.param_groups = [{"lr": lr}]          # so lr schedulers that poke param_groups keep working
 
-    def step(self):
+    @torch.no_grad()
+    def step(self, closure=None):
         import ctypes
+        loss = closure() if closure is not None else None
         self.step_count += 1
-        lr = self.param_groups[0]["lr"]
+        g = self.param_groups[0]
         ptr = lambda t: ctypes.c_void_p(t.data_ptr())
         self._lib.check(self._lib.lib().ign_adam_step(
             ptr(self.flat_param), ptr(self.bucket.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-            self.flat_param.numel(), lr, self.betas[0], self.betas[1], self.eps, self.step_count,
+            self.flat_param.numel(), g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count,
             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ign_adam_step")
+        return loss
 
     def zero_grad(self, set_to_none=False):
         self.bucket.zero_grad()

@@ -41,6 +41,19 @@ def instance_norm(x_btc, want_raw=False, eps=1e-8):
     return xn, xt
 
 
+def standardise_nct_to_btc(x_nct, eps=1e-8):
+    """Raw (B,C,T) recordings -> per-sample / per-channel standardised (B,T,C) batch on the GPU (the CHISCO loader's
+    Normalizer('per_sample_std') + item transpose, IGN/data_factory/eeg.py:332-367, for the whole batch at once)."""
+    _need_gpu("standardise_nct_to_btc", x_nct)
+    x = x_nct.contiguous()
+    B, C, T = x.shape
+    out = torch.empty(B, T, C, device=x.device, dtype=torch.float32)
+    ws = torch.empty(B * C * 2, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().ign_standardise_nct_to_btc(_ptr(x), _ptr(out), _ptr(ws), B, C, T, eps, _stream()),
+               "ign_standardise_nct_to_btc")
+    return out
+
+
 class ShapeletBankFn(torch.autograd.Function):
     """All length groups of a shapelet bank in one autograd node.
 

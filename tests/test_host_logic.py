@@ -241,3 +241,41 @@ def test_abi_exports_every_declared_symbol():
     # argument errors are reported without touching a device
     assert _lib.lib().ign_instnorm_fwd(None, None, None, 1, 1, 1, 1e-8, None) == -1001
     assert b"null pointer" in _lib.lib().ign_last_error()
+
+
+def test_raw_chisco_items_and_prefetcher_passthrough(tmp_path):
+    """The device input pipeline's host side: raw (C,T) items + collate_raw carry exactly the data whose standardised,
+    transposed form the CPU path yields; on a CPU device the prefetcher is a pass-through that applies the transform."""
+    import numpy as np
+    import torch
+    import speech_imagery_eeg_amd  # noqa: F401
+    from data_provider.device_prefetch import DevicePrefetcher
+    from data_provider.eeg_npy import EEGNpyDataset3Class, collate_raw, per_sample_standardise
+    from data_provider.uea import collate_fn
+    rng = np.random.RandomState(0)
+    X = (rng.randn(30, 5, 40) * 50 + 1e4).astype(np.float32)
+    y = rng.randint(0, 39, size=30)
+    np.save(tmp_path / "X.npy", X)
+    np.save(tmp_path / "y.npy", y)
+    cpu = EEGNpyDataset3Class(str(tmp_path), flag="train")
+    raw = EEGNpyDataset3Class(str(tmp_path), flag="train", raw=True)
+    assert len(cpu) == len(raw) == 21 and raw.num_classes == 3
+    xb, yb, none = collate_raw([raw[i] for i in range(4)])
+    xc, yc, mask = collate_fn([cpu[i] for i in range(4)], max_len=40)
+    assert none is None and xb.shape == (4, 5, 40) and torch.equal(yb, yc) and bool(mask.all())
+    ref = torch.from_numpy(per_sample_standardise(xb.numpy())).permute(0, 2, 1)
+    assert torch.allclose(ref, xc, atol=1e-6)
+
+    def to_btc(batch):        # the CPU twin of standardise_raw_batch
+        x, yy, _ = batch
+        xs = torch.from_numpy(per_sample_standardise(x.numpy())).permute(0, 2, 1).contiguous()
+        return xs, yy, torch.ones(xs.shape[0], xs.shape[1], dtype=torch.bool)
+
+    loader = torch.utils.data.DataLoader(raw, batch_size=8, shuffle=False, collate_fn=collate_raw)
+    pf = DevicePrefetcher(loader, "cpu", transform=to_btc)
+    assert len(pf) == 3 and pf.dataset is raw
+    got = list(pf)
+    want = list(torch.utils.data.DataLoader(cpu, batch_size=8, shuffle=False, collate_fn=lambda b: collate_fn(b, max_len=40)))
+    assert len(got) == len(want) == 3
+    for (a, b_, m), (c, d, n) in zip(got, want):
+        assert torch.allclose(a, c, atol=1e-6) and torch.equal(b_, d) and torch.equal(m, n)
