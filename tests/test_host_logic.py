@@ -203,7 +203,15 @@ def test_experiment_harness_with_oracle_models(tmp_path, monkeypatch):
         e.train()
         assert os.path.exists(os.path.join(e.checkpoint_dir, "checkpoint.pth"))
         loss, res, df = e.test(result_dir=str(tmp_path / "result"))
-        assert df is None and res.preds.shape == (12,) and 0.0 <= res.accuracy <= 1.0 and np.isfinite(loss)
+        assert res.preds.shape == (12,) and 0.0 <= res.accuracy <= 1.0 and np.isfinite(loss)
+        # the test summary the reference intends (exp:500-532): one CSV row with these columns
+        import glob
+        files = glob.glob(str(tmp_path / "result" / f"BasicMotions-0-{model}-*.csv"))
+        assert len(files) >= 1 and df is not None
+        cols = set(open(files[0]).readline().strip().split(","))
+        assert {"model", "dataset", "seed", "test_accuracy", "epoch_stop", "shapelet_score", "w_count_0.5", "w_ratio_0.1",
+                "w_max", "w_gini_clip", "w_gini_abs", "eta_mean", "eta_std"} <= cols
+        assert abs(float(df["test_accuracy"][0]) - res.accuracy) < 1e-12 and 0.0 <= float(df["w_gini_abs"][0]) <= 1.0
         nfeat = 4 * 5 * 6 if model == "InterpGN" else 6 * 2 * 6            # D4: IGN ignores --num_shapelet
         assert res.p.shape == (12, nfeat) and res.w.shape == (4, nfeat) and len(res.shapelets) == nfeat // 6 * 6
         if model == "InterpGN":
