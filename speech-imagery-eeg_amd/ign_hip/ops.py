@@ -6,7 +6,10 @@ import torch
 
 from . import _lib
 
+import os
+
 DIST_L1, DIST_MSE, DIST_COS, DIST_PEARSON = 0, 1, 2, 3
+LINEAR_IMPL = os.environ.get("IGN_LINEAR", "hip")      # "torch": route ops.linear to hipBLASLt (A/B measurements)
 GATE_RBF, GATE_LTS = 0x00, 0x10
 
 
@@ -231,6 +234,66 @@ def head_linear(x, w, bias=None):
             or w.dtype != torch.float32 or torch.is_autocast_enabled():
         return torch.nn.functional.linear(x, w, bias)
     return HeadLinearFn.apply(x, w, bias)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b for the dense layers of the two encoder baselines (IGN/layers/SelfAttention_Family.py:195-211,
+    IGN/layers/Transformer_EncDec.py:33-48, nn.TransformerEncoderLayer in IGN/model/eegcnn.py:219-228) on the library's own
+    GEMM kernels instead of hipBLASLt: a Linear layer is the k = 1 case of the channels-last convolution, so forward and the
+    input gradient run on the split-bf16 kernel (fp32 accuracy on the bf16 matrix cores, ign_clconv_fwd_x6 with the weight
+    resp. its transpose), the weight gradient on the fp32-MFMA TN kernel (ign_clconv_wgrad)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        L = _lib.lib()
+        Co, Ci = w.shape
+        x2 = x.reshape(-1, Ci)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        M = x2.shape[0]
+        w = w.contiguous()
+        dev = x.device
+        need_dx = ctx.needs_input_grad[0]
+        wt3 = torch.empty(3, Co, int(L.ign_clconv_kpad(Ci)), device=dev, dtype=torch.bfloat16)
+        wd3 = torch.empty(3, Ci, int(L.ign_clconv_kpad(Co)), device=dev, dtype=torch.bfloat16) if need_dx else None
+        _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt3), _ptr(wd3), Co, Ci, 1, _stream()), "ign_clconv_pack_weights_x3")
+        y = torch.empty(M, Co, device=dev, dtype=torch.float32)
+        _lib.check(L.ign_clconv_fwd_x6(_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, 1, M, Ci, Co, 1, _stream()),
+                   "ign_clconv_fwd_x6")
+        ctx.save_for_backward(x2)
+        ctx.wd3, ctx.dims, ctx.has_bias, ctx.xshape = wd3, (M, Ci, Co), bias is not None, x.shape
+        return y.view(*x.shape[:-1], Co)
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        (x2,) = ctx.saved_tensors
+        M, Ci, Co = ctx.dims
+        g2 = gy.reshape(M, Co)
+        g2 = g2 if g2.is_contiguous() else g2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, Ci, device=g2.device, dtype=torch.float32)
+            _lib.check(L.ign_clconv_fwd_x6(_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, 1, M, Co, Ci, 1, _stream()),
+                       "ign_clconv_fwd_x6(dx)")
+            dx = dx.view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            ws = torch.empty(int(L.ign_clconv_wgrad_workspace_bytes(1, M, Ci, Co, 1)) // 4, device=g2.device, dtype=torch.float32)
+            dw = torch.empty(Co, Ci, device=g2.device, dtype=torch.float32)
+            _lib.check(L.ign_clconv_wgrad(_ptr(g2), 0, _ptr(x2), None, None, _ptr(dw), _ptr(ws), 1, M, Ci, Co, 1, _stream()),
+                       "ign_clconv_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g2.sum(dim=0)
+        return dx, dw, db
+
+
+def linear(x, w, bias=None):
+    """nn.Linear / 1x1 Conv1d on the hand-written GEMM kernels; shapes they do not cover (and autocast, and CPU tensors of
+    the reference-side tests) go to torch's GEMM."""
+    if (not x.is_cuda or x.dtype != torch.float32 or w.dtype != torch.float32 or torch.is_autocast_enabled()
+            or w.shape[0] % 4 or x.numel() == 0 or x.shape[-1] != w.shape[1]
+            or x.numel() // x.shape[-1] >= (1 << 30) or LINEAR_IMPL != "hip"):
+        return torch.nn.functional.linear(x, w, bias)
+    return LinearFn.apply(x, w, bias)
 
 
 class GiniGateFn(torch.autograd.Function):

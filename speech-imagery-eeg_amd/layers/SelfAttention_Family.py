@@ -46,8 +46,9 @@ class AttentionLayer(nn.Module):
     def forward(self, queries, keys, values, attn_mask, tau=None, delta=None):
         B, L, _ = queries.shape
         S, H = keys.shape[1], self.n_heads
-        q = self.query_projection(queries).view(B, L, H, -1)
-        k = self.key_projection(keys).view(B, S, H, -1)
-        v = self.value_projection(values).view(B, S, H, -1)
+        lin = lambda m, t: ops.linear(t, m.weight, m.bias)
+        q = lin(self.query_projection, queries).view(B, L, H, -1)
+        k = lin(self.key_projection, keys).view(B, S, H, -1)
+        v = lin(self.value_projection, values).view(B, S, H, -1)
         out, attn = self.inner_attention(q, k, v, attn_mask, tau=tau, delta=delta)
-        return self.out_projection(out.reshape(B, L, -1)), attn
+        return lin(self.out_projection, out.reshape(B, L, -1)), attn

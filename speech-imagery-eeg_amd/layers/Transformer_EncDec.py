@@ -4,6 +4,8 @@ classification path and not rebuilt."""
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ign_hip import ops
+
 
 class EncoderLayer(nn.Module):
     def __init__(self, attention, d_model, d_ff=None, dropout=0.1, activation="relu"):
@@ -21,9 +23,9 @@ class EncoderLayer(nn.Module):
         new_x, attn = self.attention(x, x, x, attn_mask=attn_mask, tau=tau, delta=delta)
         x = self.norm1(x + self.dropout(new_x))
         # the k=1 convolutions are plain GEMMs over (B*T, d): apply them without the two transposes
-        y = F.linear(x, self.conv1.weight.squeeze(-1), self.conv1.bias)
+        y = ops.linear(x, self.conv1.weight.squeeze(-1), self.conv1.bias)
         y = self.dropout(self.activation(y))
-        y = self.dropout(F.linear(y, self.conv2.weight.squeeze(-1), self.conv2.bias))
+        y = self.dropout(ops.linear(y, self.conv2.weight.squeeze(-1), self.conv2.bias))
         return self.norm2(x + y), attn
 
 

@@ -132,11 +132,12 @@ def _encoder_layer_forward(layer, x, n_heads):
     """One post-norm nn.TransformerEncoderLayer (relu) evaluated with the fused attention core."""
     B, S, d = x.shape
     sa = layer.self_attn
-    qkv = F.linear(x, sa.in_proj_weight, sa.in_proj_bias).view(B, S, 3, n_heads, d // n_heads)
+    qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias).view(B, S, 3, n_heads, d // n_heads)
     o = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 1.0 / math.sqrt(d // n_heads))
-    a = F.linear(o.reshape(B, S, d), sa.out_proj.weight, sa.out_proj.bias)
+    a = ops.linear(o.reshape(B, S, d), sa.out_proj.weight, sa.out_proj.bias)
     x = layer.norm1(x + layer.dropout1(a))
-    ff = layer.linear2(layer.dropout(F.relu(layer.linear1(x))))
+    ff = ops.linear(layer.dropout(F.relu(ops.linear(x, layer.linear1.weight, layer.linear1.bias))), layer.linear2.weight,
+                    layer.linear2.bias)
     return layer.norm2(x + layer.dropout2(ff))
 
 

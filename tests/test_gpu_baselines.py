@@ -219,3 +219,29 @@ def test_eegcnn_block_matches_reference_ops_in_eval_and_train():
                 assert float((u - v).abs().max()) < 2e-3 * sc, n
             for k in m.state_dict():
                 assert _rel(m.state_dict()[k].float(), ref.state_dict()[k].float()) < 2e-4, k
+
+
+@pytest.mark.parametrize("shape,Co,bias", [((256, 100, 512), 256, True), ((3, 77, 64), 512, True), ((5, 130), 12, False),
+                                           ((2, 1000, 512), 2048, True)])
+def test_linear_on_own_gemm_kernels(shape, Co, bias):
+    """ops.linear (split-bf16 forward / input gradient, fp32-MFMA weight gradient) against float64 torch."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    g = torch.Generator().manual_seed(sum(shape) + Co)
+    Ci = shape[-1]
+    x = torch.randn(*shape, generator=g)
+    w = torch.randn(Co, Ci, generator=g) / Ci ** 0.5
+    b = torch.randn(Co, generator=g) if bias else None
+    gy = torch.randn(*shape[:-1], Co, generator=g)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True) if bias else None
+    (F.linear(xd, wd, bd) * gy.double()).sum().backward()
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    bg = b.to(dev).requires_grad_(True) if bias else None
+    y = ops.linear(xg, wg, bg)
+    (y * gy.to(dev)).sum().backward()
+    assert _rel(y, F.linear(xd, wd, bd)) < 3e-6
+    assert _rel(xg.grad, xd.grad) < 3e-6 and _rel(wg.grad, wd.grad) < 1e-5
+    if bias:
+        assert _rel(bg.grad, bd.grad) < 1e-5
