@@ -126,6 +126,7 @@ def main():
     torch.set_num_threads(host_cores())
     import speech_imagery_eeg_amd  # noqa: F401
     from ign_hip import _lib
+    from ign_hip import ops as ign_ops
     from ign_hip.ddp import FlatAdam, FlatParamBucket
     from models.InterpGN import InterpGN
 
@@ -156,7 +157,8 @@ def main():
         x, y = xs[i % n_batches], ys[i % n_batches]
         if args.config == "ign":
             out, info = model(x, mask, None, None)
-            loss = F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y)
+            # = F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y), as Experiment.train
+            loss = ign_ops.ign_loss(info.shapelet_preds, info.dnn_preds, y, 1.0)[0] + info.loss.mean()
         elif args.config == "eegcnn":
             out, info = model(x.permute(0, 2, 1).contiguous())        # (B,C,T), no mask
             loss = F.cross_entropy(out, y) + info.loss.mean()

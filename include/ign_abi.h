@@ -122,6 +122,13 @@ int ign_gate_fwd(const float* sbm, const float* dnn, float* out, float* eta, int
 int ign_gate_bwd(const float* sbm, const float* dnn, const float* gout, const float* geta, float* gsbm, float* gdnn,
                  int B, int N, float gating_value, int use_gating_value, void* stream);
 
+/* IGN's training-loss tail in one launch: gini gate + CE(mixture, y) + beta*CE(sbm, y) (batch means) and the gradients of
+ * that sum w.r.t. both experts' logits.  Replaces IGN/exp/experiment_classification.py:320-329 (the two F.cross_entropy
+ * terms) together with IGN/model/InterpGN.py:44-52 and their autograd.  labels: int64 (B), values in [0, N).
+ * out (B,N), eta (B), loss2 = {CE(out,y), CE(sbm,y), their beta-weighted sum}, gsbm / gdnn (B,N) = d(CE(out,y) + beta*CE(sbm,y)) / d logits.  N <= 16. */
+int ign_loss_fwd_bwd(const float* sbm, const float* dnn, const long long* labels, float* out, float* eta, float* loss2,
+                     float* gsbm, float* gdnn, int B, int N, float beta, void* stream);
+
 /* Shapelet diversity regulariser of one length group, forward and gradient in one launch.
  * Replaces IGN/model/Shapelet.py:223-230:  mean_{c,i,j} exp(-||w[i,c,:] - w[j,c,:] + eps||_2) (1 - delta_ij), eps = 1e-6.
  * loss_part_c (C): per-channel partial sums (their sum is the group's loss); gw_kcl (K,C,L): d loss / d w.  K <= 16.  */

@@ -176,6 +176,80 @@ __global__ void __launch_bounds__(256) gate_bwd_kernel(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fused training-loss tail
+// IGN's per-step loss tail, IGN/exp/experiment_classification.py:320-329 + IGN/model/InterpGN.py:44-52, in ONE launch:
+//   out = eta*s + (1-eta)*d (gini gate);  loss = CE(out, y) + beta*CE(s, y)  (batch means);  and the gradients of that
+//   loss w.r.t. both experts' logits -- what torch spends ~40 softmax / nll / mean / add kernels (forward + backward) on,
+//   all of them serialised between the last forward kernel and the first backward kernel.
+// One block; thread <-> rows b, b+256, ...; the two CE sums are reduced through LDS in thread order (deterministic).
+constexpr int LOSS_NMAX = 16;
+__global__ void __launch_bounds__(256) ign_loss_kernel(const float* __restrict__ s, const float* __restrict__ d,
+                                                       const long long* __restrict__ y, float* __restrict__ out,
+                                                       float* __restrict__ eta_out, float* __restrict__ loss2,
+                                                       float* __restrict__ gs, float* __restrict__ gd, int B, int N, float beta) {
+    __shared__ float red[2][256];
+    float ce_o = 0.f, ce_s = 0.f;
+    const float invB = 1.f / (float)B;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        float sv[LOSS_NMAX], ov[LOSS_NMAX], q[LOSS_NMAX];
+        const float* sr = s + (long long)b * N;
+        const float* dr = d + (long long)b * N;
+        const int yb = (int)y[b];
+        float mx = -INFINITY;
+        for (int n = 0; n < N; ++n) { sv[n] = sr[n]; mx = fmaxf(mx, sv[n]); }
+        float z = 0.f, z2 = 0.f;
+        for (int n = 0; n < N; ++n) { q[n] = expf(sv[n] - mx); z += q[n]; z2 += q[n] * q[n]; }
+        const float G = z2 / (z * z);
+        const float eta = ((float)N * G - 1.f) / (float)(N - 1);
+        eta_out[b] = eta;
+        const float lse_s = mx + logf(z);
+        ce_s += lse_s - sv[yb];
+        float mo = -INFINITY;
+        for (int n = 0; n < N; ++n) {
+            ov[n] = eta * sv[n] + (1.f - eta) * dr[n];
+            out[(long long)b * N + n] = ov[n];
+            mo = fmaxf(mo, ov[n]);
+        }
+        float zo = 0.f;
+        for (int n = 0; n < N; ++n) zo += expf(ov[n] - mo);
+        ce_o += mo + logf(zo) - ov[yb];
+        // gradients: g_out = (softmax(out) - onehot)/B ; through the gate (see gate_bwd_kernel) ; + beta*(softmax(s) - onehot)/B
+        float dot = 0.f;
+        float go[LOSS_NMAX];
+        for (int n = 0; n < N; ++n) {
+            go[n] = (expf(ov[n] - mo) / zo - (n == yb ? 1.f : 0.f)) * invB;
+            dot += go[n] * (sv[n] - dr[n]);
+        }
+        const float c = 2.f * (float)N / (float)(N - 1) * dot;
+        for (int n = 0; n < N; ++n) {
+            const float qn = q[n] / z;
+            gs[(long long)b * N + n] = eta * go[n] + c * qn * (qn - G) + beta * (qn - (n == yb ? 1.f : 0.f)) * invB;
+            gd[(long long)b * N + n] = (1.f - eta) * go[n];
+        }
+    }
+    red[0][threadIdx.x] = ce_o;
+    red[1][threadIdx.x] = ce_s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b2 = 0.f;
+        for (int i = 0; i < 256; ++i) { a += red[0][i]; b2 += red[1][i]; }
+        loss2[0] = a * invB;
+        loss2[1] = b2 * invB;
+        loss2[2] = a * invB + beta * (b2 * invB);
+    }
+}
+
+extern "C" int ign_loss_fwd_bwd(const float* sbm, const float* dnn, const long long* labels, float* out, float* eta, float* loss2,
+                                float* gsbm, float* gdnn, int B, int N, float beta, void* stream) {
+    if (!sbm || !dnn || !labels || !out || !eta || !loss2 || !gsbm || !gdnn || B <= 0 || N < 2 || N > LOSS_NMAX) {
+        ign_set_error("ign_loss_fwd_bwd: null pointer or bad dimension (B=%d N=%d, N <= %d)", B, N, LOSS_NMAX);
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(ign_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sbm, dnn, labels, out, eta, loss2, gsbm, gdnn, B, N,
+                       beta);
+    return ign_check_launch("ign_loss_kernel");
+}
+
 // ------------------------------------------------------------------------------------------------ Adam
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float lr, float b1, float b2,

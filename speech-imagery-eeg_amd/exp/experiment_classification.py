@@ -24,6 +24,7 @@ import torch.nn.functional as F
 
 from data_provider.data_factory import data_provider
 from data_provider.device_prefetch import DevicePrefetcher, standardise_raw_batch
+from ign_hip import ops as ign_ops
 from ign_hip.ddp import FlatAdam, FlatParamBucket
 from models.FullyConvNet import FullyConvNetwork
 from models.InterpGN import InterpGN, dnn_dict
@@ -201,12 +202,18 @@ class Experiment(object):
                 batch_x, label, padding_mask = self._to_device(batch_x, label, padding_mask)
                 with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=amp):
                     logits, info = self._forward(batch_x, padding_mask)
-                    loss = F.cross_entropy(logits, label)
-                    if a.model != 'DNN':
-                        loss = loss + info.loss.mean()
-                    if a.model == 'InterpGN':
+                    if a.model == 'InterpGN' and logits.is_cuda and not amp:
+                        # CE(mixture) + beta*CE(sbm) and both logit gradients in one launch (ops.ign_loss) instead of
+                        # ~40 softmax / nll / mean kernels between the forward and the backward pass
                         beta = compute_beta(epoch, a.train_epochs, a.beta_schedule)
-                        loss = loss + beta * F.cross_entropy(info.shapelet_preds, label)
+                        loss = ign_ops.ign_loss(info.shapelet_preds, info.dnn_preds, label, beta)[0] + info.loss.mean()
+                    else:
+                        loss = F.cross_entropy(logits, label)
+                        if a.model != 'DNN':
+                            loss = loss + info.loss.mean()
+                        if a.model == 'InterpGN':
+                            beta = compute_beta(epoch, a.train_epochs, a.beta_schedule)
+                            loss = loss + beta * F.cross_entropy(info.shapelet_preds, label)
                 if a.gradient_accumulation_steps > 1:
                     loss = loss / a.gradient_accumulation_steps
                 loss.backward()

@@ -29,6 +29,7 @@ SIGNATURES = {
     "ign_head_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]),
     "ign_gate_fwd": (ci, [vp, vp, vp, vp, ci, ci, cf, ci, vp]),
     "ign_gate_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, cf, ci, vp]),
+    "ign_loss_fwd_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp]),
     "ign_diversity_fwd_bwd": (ci, [vp, vp, vp, ci, ci, ci, cf, vp]),
     "ign_adam_step": (ci, [vp, vp, vp, vp, ll, cf, cf, cf, cf, ci, vp]),
     "ign_conv1_sumsq_workspace_bytes": (sz, [ci, ci, ci]),

@@ -328,6 +328,35 @@ def gini_gate(sbm_out, dnn_out, gating_value=None):
     return GiniGateFn.apply(sbm_out.float(), dnn_out.float(), gating_value)
 
 
+class IgnLossFn(torch.autograd.Function):
+    """CE(gate(sbm, dnn), y) + beta * CE(sbm, y) with both gradients from one launch (ign_loss_fwd_bwd)."""
+
+    @staticmethod
+    def forward(ctx, sbm, dnn, y, beta):
+        _need_gpu("ign_loss", sbm, dnn)
+        sbm, dnn = sbm.contiguous(), dnn.contiguous()
+        y = y.contiguous().long()
+        B, N = sbm.shape
+        out, gs, gd = torch.empty_like(sbm), torch.empty_like(sbm), torch.empty_like(sbm)
+        eta = torch.empty(B, 1, device=sbm.device, dtype=torch.float32)
+        loss2 = torch.empty(3, device=sbm.device, dtype=torch.float32)
+        _lib.check(_lib.lib().ign_loss_fwd_bwd(_ptr(sbm), _ptr(dnn), _ptr(y), _ptr(out), _ptr(eta), _ptr(loss2), _ptr(gs), _ptr(gd),
+                                               B, N, float(beta), _stream()), "ign_loss_fwd_bwd")
+        ctx.save_for_backward(gs, gd)
+        ctx.mark_non_differentiable(out, eta)
+        return loss2[2], out, eta
+
+    @staticmethod
+    def backward(ctx, gl, gout, geta):
+        gs, gd = ctx.saved_tensors
+        return gl * gs, gl * gd, None, None
+
+
+def ign_loss(sbm_out, dnn_out, y, beta=1.0):
+    """-> (CE(mix, y) + beta*CE(sbm, y), mix, eta); mix / eta are reporting outputs (no gradient flows through them)."""
+    return IgnLossFn.apply(sbm_out.float(), dnn_out.float(), y, beta)
+
+
 class Conv1SumSqFn(torch.autograd.Function):
     """m2[f] = sum_{rows,t} ((w1[f] (*) x_row)[t] - mu[f])^2 without storing the convolution (ign_conv1_sumsq_*).
     d m2 / d mu = -2 sum (y1 - mu) = 0 when mu is the batch mean, which is the only use (BatchNorm-1 of EEG-CNN)."""

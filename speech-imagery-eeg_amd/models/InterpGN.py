@@ -79,8 +79,10 @@ class InterpGN(nn.Module):
             out, eta = gini_gate(sbm_out, deep_out, gating_value)
         else:
             out, eta = ops.gini_gate(sbm_out, deep_out, gating_value)
+        # the SBM expert has just evaluated the regularisers on the same weights (IGN/model/Shapelet.py:206-210); the
+        # reference recomputes them here (InterpGN.py:54-60) -- same value, same gradient, a dozen kernel launches less
         return out, ModelInfo(d=info.d, p=info.p, eta=eta, shapelet_preds=sbm_out, dnn_preds=deep_out,
-                              preds=out, loss=self.loss().unsqueeze(0))
+                              preds=out, loss=info.loss)
 
     def loss(self):
         return self.sbm.loss()

@@ -258,3 +258,30 @@ def test_diversity_kernel_vs_torch():
         assert abs(loss.item() - ref.item()) <= 1e-5 * max(abs(ref.item()), 1e-3) + 1e-9, (K, C, L)
         scale = float(wd.grad.abs().max())
         assert float((w.grad.cpu().double() - wd.grad).abs().max()) <= 1e-4 * scale + 1e-12, (K, C, L)
+
+
+@pytest.mark.parametrize("B,N,beta", [(256, 3, 1.0), (8, 4, 0.37), (700, 3, 0.0), (1, 2, 1.0)])
+def test_fused_loss_tail_vs_torch(B, N, beta):
+    """ops.ign_loss (gate + CE(mixture) + beta*CE(sbm) + both logit gradients in one launch) against the torch composition
+    of IGN/exp/experiment_classification.py:320-329 in float64."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    from models.InterpGN import gini_gate
+    g = torch.Generator().manual_seed(B + N)
+    s = (torch.randn(B, N, generator=g) * 2).requires_grad_(True)
+    d = (torch.randn(B, N, generator=g) * 2).requires_grad_(True)
+    y = torch.randint(0, N, (B,), generator=g)
+    sd, dd = s.detach().double().requires_grad_(True), d.detach().double().requires_grad_(True)
+    out_r, eta_r = gini_gate(sd, dd)
+    loss_r = F.cross_entropy(out_r, y) + beta * F.cross_entropy(sd, y)
+    (loss_r * 1.7).backward()
+    sg, dg = s.detach().to(dev).requires_grad_(True), d.detach().to(dev).requires_grad_(True)
+    loss, out, eta = ops.ign_loss(sg, dg, y.to(dev), beta)
+    (loss * 1.7).backward()
+    assert abs(float(loss) - float(loss_r)) < 1e-5 * max(1.0, abs(float(loss_r)))
+    rel = lambda a, b: float((a.detach().double().cpu() - b.detach()).abs().max() / b.detach().abs().max().clamp_min(1e-12))
+    assert rel(out, out_r) < 1e-5 and rel(eta, eta_r) < 1e-5
+    assert rel(sg.grad, sd.grad) < 1e-4 and rel(dg.grad, dd.grad) < 1e-4
