@@ -271,11 +271,19 @@ def main():
                     return {"ms_per_step": ms, "achieved": tf_alg, "peak": 157.3, "frac": tf_alg / 157.3}
                 fcn_f = 2.0 * B * (993 * 128 * 976 + 989 * 256 * 640 + 987 * 128 * 768)
                 fcn_d = 2.0 * B * (993 * 128 * 1280 + 989 * 256 * 384)                          # data gradients of blocks 3, 2
+                # measured instruction-issue ceilings of the two inner loops in isolation (profiles/r1_valu_microbench.txt):
+                # forward v_sub + v_add|abs| 32.3 T elements/s, backward v_cmpx + masked v_add 24.4 T elements/s; the nominal
+                # 157.3 TFLOP/s counts an FMA as 2 flop, which neither loop can issue
+                E_ops = f_fwd / 2.0
                 res["roofline"]["isolated"] = {
                     "shp_bwd_kernel": {"ms_per_step": iso["shp_bwd"][0], "achieved": _tf(f_bwd, iso["shp_bwd"][0]),
-                                       "frac": _tf(f_bwd, iso["shp_bwd"][0]) / PEAK_FP32_VALU_TFLOPS},
+                                       "frac": _tf(f_bwd, iso["shp_bwd"][0]) / PEAK_FP32_VALU_TFLOPS,
+                                       "frac_of_issue_ceiling": (E_ops / (iso["shp_bwd"][0] * 1e-3) / 24.4e12)
+                                       if iso["shp_bwd"][0] > 0 else 0.0},
                     "shp_fwd_kernel": {"ms_per_step": iso["shp_fwd"][0], "achieved": _tf(f_fwd, iso["shp_fwd"][0]),
-                                       "frac": _tf(f_fwd, iso["shp_fwd"][0]) / PEAK_FP32_VALU_TFLOPS},
+                                       "frac": _tf(f_fwd, iso["shp_fwd"][0]) / PEAK_FP32_VALU_TFLOPS,
+                                       "frac_of_issue_ceiling": (E_ops / (iso["shp_fwd"][0] * 1e-3) / 32.3e12)
+                                       if iso["shp_fwd"][0] > 0 else 0.0},
                     **{f"clconv_{nm} (mfma)": _conv_roof(_tf(fl, iso[f"clconv_{nm}"][0]), iso[f"clconv_{nm}"][0])
                        for nm, fl in (("fwd", fcn_f), ("dgrad", fcn_d), ("wgrad", fcn_f))},
                     "steps": args.iso_steps}
