@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--iso-steps", type=int, default=8, help="steps of the serial (one-stream) pass that measures isolated "
                     "kernel durations for the roofline object")
     ap.add_argument("--cpu-sample", type=int, default=4, help="samples for the CPU baseline step (0 = skip)")
+    ap.add_argument("--groups", choices=["4x5", "6x10"], default="4x5",
+                    help="shapelet bank of the IGN config: 4x5 = what the reference driver builds (4 length groups x 5 shapelets, "
+                         "SURVEY D4; the headline); 6x10 = the SBM/LTS bank (6 groups x 10, lengths .05-.8 T) as a stress case")
     ap.add_argument("--config", choices=["ign", "eegcnn", "transformer"], default="ign",
                     help="ign = BASELINE.json's headline (config 1 / 5); eegcnn / transformer = the baselines of "
                          "configs 3 / 4 on the same synthetic tensors")
@@ -134,7 +137,8 @@ def main():
     B, T, C = args.batch, cfg.seq_len, cfg.enc_in
     torch.manual_seed(0)                       # same initial replica on every rank
     if args.config == "ign":
-        model = InterpGN(cfg)
+        model = InterpGN(cfg) if args.groups == "4x5" else \
+            InterpGN(cfg, num_shapelet=[10] * 6, shapelet_len=[0.05, 0.1, 0.2, 0.3, 0.5, 0.8])
     elif args.config == "eegcnn":
         from models.eegcnn import EEGCNNTransformer
         cfg.eegcnn_layers, cfg.eegcnn_pooling, cfg.eegcnn_dropout1, cfg.eegcnn_dropout2 = 2, 'mean', 0.0, 0.0
@@ -239,12 +243,15 @@ def main():
             fwd_tflops = (f_fwd * args.steps) / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
             traffic = None
             try:    # HBM bytes per step of the dominant kernel, from the committed PMC passes (see profiles/traffic.json)
+                if args.groups != "4x5":
+                    raise KeyError("the PMC passes were collected for the headline bank only")
                 traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["shp_bwd_kernel"]["bytes_per_step"]
             except Exception:
                 pass
             from ign_hip import fcn as _fcn
             res["config"] = dict(common, workload="Synthetic CHISCO-shape EEG (122ch x 1000, 3-class) IGN(FCN expert), "
-                                 "driver-default groups K=5 x L{100,200,300,500}, Adam lr 5e-3, fp32",
+                                 + ("driver-default groups K=5 x L{100,200,300,500}" if args.groups == "4x5" else
+                                    "stress bank K=10 x L{50,100,200,300,500,800}") + ", Adam lr 5e-3, fp32",
                                  conv_math=_fcn.CONV_MATH + (" (fp32 operands split exactly into 3 bf16 terms, 6 partial products "
                                                             "accumulated in fp32; <= 3e-6 vs float64, same as the fp32-MFMA "
                                                             "kernel; IGN_CONV_MATH=f32 selects that one)"
