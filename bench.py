@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--iso-steps", type=int, default=8, help="steps of the serial (one-stream) pass that measures isolated "
                     "kernel durations for the roofline object")
     ap.add_argument("--cpu-sample", type=int, default=4, help="samples for the CPU baseline step (0 = skip)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step (fwd + loss + bwd + Adam) as one captured hipGraph (single GPU; pays off in "
+                         "launch-bound regimes such as --batch 32, the UEA setting of run_uea.sh)")
     ap.add_argument("--groups", choices=["4x5", "6x10"], default="4x5",
                     help="shapelet bank of the IGN config: 4x5 = what the reference driver builds (4 length groups x 5 shapelets, "
                          "SURVEY D4; the headline); 6x10 = the SBM/LTS bank (6 groups x 10, lengths .05-.8 T) as a stress case")
@@ -149,7 +152,8 @@ def main():
         model = TransformerModel(cfg)
     model = model.to(dev).train()
     bucket = FlatParamBucket(model, world)     # flat fp32 grad bucket: one RCCL all-reduce per step
-    opt = FlatAdam(bucket, lr=5e-3)            # one ign_adam_step launch over the flat parameter buffer
+    use_graph = args.graph and world == 1 and args.config == "ign"
+    opt = FlatAdam(bucket, lr=5e-3, capturable=use_graph)   # one ign_adam_step launch over the flat parameter buffer
 
     n_batches = min(args.steps + args.warmup, max(1, N_TRAIN // (B * world)))
     log(f"generating {n_batches} synthetic batches on the host ...")
@@ -157,8 +161,20 @@ def main():
     log("warm-up ...")
     mask = torch.ones(B, T, device=dev)
 
+    def step_xy(x, y):
+        out, info = model(x, mask, None, None)
+        loss = ign_ops.ign_loss(info.shapelet_preds, info.dnn_preds, y, 1.0)[0] + info.loss.mean()
+        loss.backward()
+        opt.step()
+        bucket.zero_grad()
+        return loss.detach()
+
+    graphed = None
+
     def step(i):
         x, y = xs[i % n_batches], ys[i % n_batches]
+        if graphed is not None:
+            return graphed(x, y)
         if args.config == "ign":
             out, info = model(x, mask, None, None)
             # = F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y), as Experiment.train
@@ -174,6 +190,9 @@ def main():
         bucket.zero_grad()
         return loss.detach()
 
+    if use_graph:
+        from ign_hip.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(step_xy, (xs[0], ys[0]))
     for i in range(args.warmup):
         step(i)
 
@@ -207,6 +226,7 @@ def main():
         from models.InterpGN import InterpGN as _IGN
         was = _IGN.expert_streams
         _IGN.expert_streams = False
+        graphed = None                                   # the isolated pass runs eagerly
         try:
             step(0)
             torch.cuda.synchronize()
@@ -233,7 +253,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
         }
         common = {"per_gpu_batch": B, "global_batch": B * world, "samples_per_epoch": N_TRAIN,
-                  "parallelism": f"dp{world}", "final_loss": float(last)}
+                  "parallelism": f"dp{world}", "final_loss": float(last), "hipgraph": bool(use_graph)}
         if args.config == "ign":
             groups = [(s.n, s.length) for s in model.sbm.shapelets]
             f_fwd, f_bwd = shapelet_algorithmic_flops(B, C, T, groups)

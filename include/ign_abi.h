@@ -140,6 +140,11 @@ int ign_diversity_fwd_bwd(const float* w_kcl, float* loss_part_c, float* gw_kcl,
 int ign_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                   float beta1, float beta2, float eps, int step, void* stream);
 
+/* The same step with the step count kept on the device (*step_dev is incremented, bc_dev[2] receives the bias
+ * corrections): nothing host-side changes between steps, so the launch sequence can be captured into a hipGraph.      */
+int ign_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                      float beta1, float beta2, float eps, int* step_dev, float* bc_dev, void* stream);
+
 /* EEG-CNN block 1 without its (B,F1,C,T) intermediate (1 GB at B=256) -- see csrc/ign_eegcnn.hip for the algebra.
  * Replaces the BatchNorm-1 batch statistics of IGN/model/eegcnn.py:90-91 (block1_conv1 -> block1_bn1):
  *   y1[r,f,t] = sum_j w1[f,j] xpad[r, t+j]   (rows r = (b,c); 'same' zero padding, pad_left on the left)

@@ -279,6 +279,27 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// Graph-capturable Adam: the step count lives on the device, so a captured launch sequence stays valid when replayed.
+__global__ void adam_tick_kernel(int* __restrict__ step_dev, float* __restrict__ bc_dev, float b1, float b2) {
+    const int step = ++(*step_dev);
+    bc_dev[0] = (float)(1.0 - pow((double)b1, (double)step));
+    bc_dev[1] = (float)sqrt(1.0 - pow((double)b2, (double)step));
+}
+
+__global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long long n, float lr, float b1, float b2,
+                                                       float eps, const float* __restrict__ bc_dev) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float bc1 = bc_dev[0], bc2_sqrt = bc_dev[1];
+    const float step = lr / bc1;
+    for (long long j = i; j < min(n, i + 4); ++j) {
+        float pv = p[j], gv = g[j], mv = m[j], vv = v[j];
+        ADAM1(pv, gv, mv, vv)
+        p[j] = pv; m[j] = mv; v[j] = vv;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" int ign_head_fwd(const float* X, const float* W, const float* bias, float* out, int B, int F, int N,
                             long long ldx, void* stream) {
@@ -361,6 +382,22 @@ extern "C" int ign_adam_step(float* p, const float* g, float* m, float* v, long 
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
                        eps, (float)bc1, (float)sqrt(bc2));
     return ign_check_launch("adam_kernel");
+}
+
+extern "C" int ign_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                                 float eps, int* step_dev, float* bc_dev, void* stream) {
+    if (!p || !g || !m || !v || !step_dev || !bc_dev || n <= 0) {
+        ign_set_error("ign_adam_step_dev: null pointer or n <= 0");
+        return IGN_E_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step_dev, bc_dev, beta1, beta2);
+    int rc;
+    if ((rc = ign_check_launch("adam_tick_kernel"))) return rc;
+    IgnScopedTimer tm("adam", s);
+    const long long blocks = (n / 4 + 256) / 256;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, bc_dev);
+    return ign_check_launch("adam_dev_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------ shapelet diversity

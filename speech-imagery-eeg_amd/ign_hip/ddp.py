@@ -81,7 +81,7 @@ class FlatAdam(torch.optim.Optimizer):
     ``param_groups[0]['lr']`` at every step.
     """
 
-    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         from . import _lib
         ps = bucket.params
         if not ps[0].is_cuda:
@@ -98,6 +98,10 @@ class FlatAdam(torch.optim.Optimizer):
                 p.data = self.flat_param[off:off + n].view_as(p)
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        # capturable: the step count lives on the device (ign_adam_step_dev), so the step can sit inside a hipGraph
+        self.capturable = bool(capturable)
+        self.step_dev = torch.zeros(1, device=self.flat_param.device, dtype=torch.int32) if capturable else None
+        self.bc_dev = torch.zeros(2, device=self.flat_param.device, dtype=torch.float32) if capturable else None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -106,6 +110,12 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_count += 1
         g = self.param_groups[0]
         ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+        if self.capturable:
+            self._lib.check(self._lib.lib().ign_adam_step_dev(
+                ptr(self.flat_param), ptr(self.bucket.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                self.flat_param.numel(), g["lr"], g["betas"][0], g["betas"][1], g["eps"], ptr(self.step_dev), ptr(self.bc_dev),
+                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ign_adam_step_dev")
+            return loss
         self._lib.check(self._lib.lib().ign_adam_step(
             ptr(self.flat_param), ptr(self.bucket.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
             self.flat_param.numel(), g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count,

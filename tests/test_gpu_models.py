@@ -285,3 +285,54 @@ def test_fused_loss_tail_vs_torch(B, N, beta):
     rel = lambda a, b: float((a.detach().double().cpu() - b.detach()).abs().max() / b.detach().abs().max().clamp_min(1e-12))
     assert rel(out, out_r) < 1e-5 and rel(eta, eta_r) < 1e-5
     assert rel(sg.grad, sd.grad) < 1e-4 and rel(dg.grad, dd.grad) < 1e-4
+
+
+def test_graphed_train_step_equals_eager():
+    """One IGN step (two expert streams, fused loss tail, backward, capturable flat Adam) captured as a hipGraph and replayed
+    must walk the same parameter trajectory as the eager step."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    import copy
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    from ign_hip.ddp import FlatAdam, FlatParamBucket
+    from ign_hip.graph import GraphedTrainStep
+    from models.InterpGN import InterpGN
+    cfg = make_cfg()
+    torch.manual_seed(0)
+    base = InterpGN(cfg)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(8, 100, 6, generator=g).to(dev) for _ in range(4)]
+    ys = [(torch.arange(8) % 4).to(dev) for _ in range(4)]
+    mask = torch.ones(8, 100, device=dev)
+    finals = {}
+    for mode in ("eager", "graph"):
+        model = copy.deepcopy(base).to(dev).train()
+        bucket = FlatParamBucket(model, 1)
+        opt = FlatAdam(bucket, lr=5e-3, capturable=(mode == "graph"))
+
+        def step(x, y, model=model, bucket=bucket, opt=opt):
+            out, info = model(x, mask, None, None)
+            loss = ops.ign_loss(info.shapelet_preds, info.dnn_preds, y, 1.0)[0] + info.loss.mean()
+            loss.backward()
+            opt.step()
+            bucket.zero_grad()
+            return loss.detach()
+
+        if mode == "graph":
+            sd = copy.deepcopy(model.state_dict())
+            stepper = GraphedTrainStep(step, (xs[0], ys[0]), warmup=2)
+            model.load_state_dict(sd)                           # undo the warm-up / capture steps
+            opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_dev.zero_()
+        else:
+            stepper = step
+        losses = [float(stepper(x, y)) for x, y in zip(xs, ys)]
+        torch.cuda.synchronize()
+        finals[mode] = (losses, {k: v.detach().clone() for k, v in model.state_dict().items()})
+    for a, b in zip(finals["eager"][0], finals["graph"][0]):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(a))
+    for k, v in finals["eager"][1].items():
+        w = finals["graph"][1][k]
+        if v.dtype.is_floating_point:
+            assert float((v - w).abs().max()) <= 1e-6 * max(1.0, float(v.abs().max())), k
