@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--alt-steps", type=int, default=16, help="steps of the second timed region that runs the FCN convolution "
+                    "GEMMs on the fp32-MFMA kernels instead of the split-bf16 ones (0 = skip)")
     ap.add_argument("--iso-steps", type=int, default=8, help="steps of the serial (one-stream) pass that measures isolated "
                     "kernel durations for the roofline object")
     ap.add_argument("--cpu-sample", type=int, default=4, help="samples for the CPU baseline step (0 = skip)")
@@ -218,6 +220,32 @@ def main():
     fwd_ms, fwd_n = _lib.timing_read("shp_fwd")
     bwd_ms, bwd_n = _lib.timing_read("shp_bwd")
 
+    # The same K steps with the convolution GEMMs on the fp32-MFMA kernels (v_mfma_f32_32x32x2_f32), reported next to the
+    # headline so that both arithmetic choices are measured in one run (results agree to ~1e-6).
+    alt = None
+    if args.config == "ign" and args.alt_steps > 0:
+        from ign_hip import fcn as _fcn_alt
+        if _fcn_alt.CONV_MATH == "bf16x6":
+            _fcn_alt.CONV_MATH = "f32"
+            try:
+                for i in range(2):
+                    step(i)
+                fence()
+                t1 = time.perf_counter()
+                for i in range(args.alt_steps):
+                    step(args.warmup + i)
+                fence()
+                dt_alt = time.perf_counter() - t1
+                if world > 1:
+                    tt = torch.tensor([dt_alt], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt_alt = float(tt.item())
+                alt = {"conv_math": "f32 (v_mfma_f32_32x32x2_f32)", "steps": args.alt_steps,
+                       "ms_per_step": 1e3 * dt_alt / args.alt_steps,
+                       "value": (args.alt_steps * B * world / N_TRAIN) / dt_alt, "unit": "epochs/s"}
+            finally:
+                _fcn_alt.CONV_MATH = "bf16x6"
+
     # Kernel durations free of co-running kernels: in the timed region the two experts of IGN run on two HIP streams, so
     # a kernel's event bracket also contains the time it shared the CUs with the other expert.  A short serial pass
     # (same step, one stream) right after the timed region gives the isolated durations the roofline fractions refer to.
@@ -285,6 +313,8 @@ def main():
                                "fwd_kernel": {"kernel": "shp_fwd_kernel", "achieved": fwd_tflops,
                                               "frac": fwd_tflops / PEAK_FP32_VALU_TFLOPS,
                                               "ms_per_step": fwd_ms / max(1, args.steps), "launches": fwd_n}}
+            if alt is not None:
+                res["fp32_mfma_conv"] = alt
             if iso:
                 def _tf(flops, ms):
                     return flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
