@@ -168,7 +168,7 @@ int ign_dwconv1d_bwd_weight(const float* x, const float* dy, float* dw, void* wo
                             int pad_left, void* stream);
 
 /* ---- FCN expert: channels-last 1-D convolution as an implicit GEMM on the fp32 matrix cores, BatchNorm + ReLU
- * folded into the GEMM prologues / epilogues (csrc/ign_clconv.hip).  Replaces IGN/model/FullyConvNet.py:31-59
+ * folded into the GEMM prologues / epilogues (csrc/ign_clconv_{f32,x6}.hip, ign_bn.hip).  Replaces IGN/model/FullyConvNet.py:31-59
  * (3 x [Conv1d -> BatchNorm1d -> ReLU] -> AdaptiveAvgPool1d) and its autograd.  Activations are (B, T, C) row-major
  * (the loader's layout); a 'valid' convolution: Tout = Tin - k + 1.  All sums are fixed-order (deterministic).
  *

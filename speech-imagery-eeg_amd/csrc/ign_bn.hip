@@ -1,0 +1,284 @@
+// BatchNorm1d / ReLU / average-pool glue of the FCN expert (IGN/model/FullyConvNet.py:33-34,40-41,47-49,55-57) around the
+// convolution GEMMs of ign_clconv_*.hip: partial-sum finalisation, the last block's BatchNorm+ReLU+pool and its backward,
+// and the elementwise BatchNorm-backward pass that writes dL/dy in the zero-padded layout the GEMMs read.
+#include "ign_clconv.h"
+
+// ------------------------------------------------------------------------------------------------ BatchNorm glue
+// Sum of the per-tile partials (nparts, 2, C) for 32 channels per block: 32 slices of the partials are summed in
+// parallel (ascending inside a slice), then the 32 slice sums are combined in fixed order in double.
+__device__ __forceinline__ void bn_sum_partials(const float* __restrict__ part, int nparts, int C, double* s_out, double* q_out) {
+    __shared__ double sh[2][32][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        const int per = (nparts + 31) / 32;
+        const int i0 = sl * per, i1 = min(nparts, i0 + per);
+        float fs = 0.f, fq = 0.f;              // <= 64 addends of like magnitude per slice in fp32, slices combined in double
+        int n = 0;
+        for (int i = i0; i < i1; ++i) {
+            fs += part[((size_t)i * 2 + 0) * C + c];
+            fq += part[((size_t)i * 2 + 1) * C + c];
+            if (++n == 64) { s += (double)fs; q += (double)fq; fs = fq = 0.f; n = 0; }
+        }
+        s += (double)fs; q += (double)fq;
+    }
+    sh[0][sl][cl] = s;
+    sh[1][sl][cl] = q;
+    __syncthreads();
+    s = q = 0.0;
+    if (sl == 0) {
+        for (int k = 0; k < 32; ++k) { s += sh[0][k][cl]; q += sh[1][k][cl]; }
+    }
+    *s_out = s; *q_out = q;
+}
+
+// forward finalize: mean, biased var -> a = gamma*invstd, b = beta - a*mean; running stats (unbiased var).
+__global__ void __launch_bounds__(1024) bn_finalize_fwd_kernel(const float* __restrict__ part, int nparts, long long R, int C,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                       float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ a,
+                                       float* __restrict__ b, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    double s, q;
+    bn_sum_partials(part, nparts, C, &s, &q);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) != 0 || c >= C) return;
+    const double m = s / (double)R;
+    double var = q / (double)R - m * m;
+    if (var < 0.0) var = 0.0;
+    const float inv = (float)(1.0 / sqrt(var + (double)eps));
+    const float av = gamma[c] * inv;
+    a[c] = av;
+    b[c] = beta[c] - av * (float)m;
+    mean_out[c] = (float)m;
+    invstd_out[c] = inv;
+    if (run_mean) {
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+        const double unb = (R > 1) ? var * (double)R / (double)(R - 1) : var;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void bn_affine_eval_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int C,
+                                      float* __restrict__ a, float* __restrict__ b, float* __restrict__ mean_out,
+                                      float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float inv = 1.f / sqrtf(run_var[c] + eps);
+    const float av = gamma[c] * inv;
+    a[c] = av;
+    b[c] = beta[c] - av * run_mean[c];
+    mean_out[c] = run_mean[c];
+    invstd_out[c] = inv;
+}
+
+__global__ void __launch_bounds__(1024) bn_finalize_bwd_kernel(const float* __restrict__ part, int nparts, int C,
+                                                               float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    double s, q;
+    bn_sum_partials(part, nparts, C, &s, &q);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) != 0 || c >= C) return;
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+}
+
+// Global average pool of relu(a*y + b) over time:  pooled[b][c] = (1/T) sum_t max(a_c*y[b,t,c] + b_c, 0).
+// One block per sample; thread <-> (row lane, 4 channels); the row lanes are combined through LDS in fixed order.
+__global__ void __launch_bounds__(256) bn_relu_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ a,
+                                                               const float* __restrict__ b, float* __restrict__ pooled, int T,
+                                                               int C) {
+    extern __shared__ float sm[];                         // [rif][C]
+    const int c4 = C / 4, rif = 256 / c4;
+    const int col = (threadIdx.x % c4) * 4, rofs = threadIdx.x / c4;
+    const float* yb = y + (size_t)blockIdx.x * T * C;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rofs < rif) {
+        const float4 av = *reinterpret_cast<const float4*>(a + col), bv = *reinterpret_cast<const float4*>(b + col);
+        for (int t = rofs; t < T; t += rif) {
+            const float4 yv = *reinterpret_cast<const float4*>(yb + (size_t)t * C + col);
+            s[0] += fmaxf(fmaf(av.x, yv.x, bv.x), 0.f);
+            s[1] += fmaxf(fmaf(av.y, yv.y, bv.y), 0.f);
+            s[2] += fmaxf(fmaf(av.z, yv.z, bv.z), 0.f);
+            s[3] += fmaxf(fmaf(av.w, yv.w, bv.w), 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sm[rofs * C + col + q] = s[q];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float u = 0.f;
+        for (int q = 0; q < rif; ++q) u += sm[q * C + c];
+        pooled[(size_t)blockIdx.x * C + c] = u / (float)T;
+    }
+}
+
+// Backward of the pool through ReLU: g[b,t,c] = (gpool[b,c]/T) * [a*y + b > 0]; per-block partials of sum g and
+// sum g*yhat (BatchNorm backward).  Grid (ceil(T / rows_per_block), B).
+constexpr int POOL_ROWS = 128;
+__global__ void __launch_bounds__(256) bn_relu_pool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gpool,
+                                                               const float* __restrict__ a, const float* __restrict__ b,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               float* __restrict__ g, float* __restrict__ part, int T, int C) {
+    extern __shared__ float sm[];                         // [2][rif][C]
+    const int c4 = C / 4, rif = 256 / c4;
+    const int col = (threadIdx.x % c4) * 4, rofs = threadIdx.x / c4;
+    const int bi = blockIdx.y;
+    const int t0 = blockIdx.x * POOL_ROWS, t1 = min(T, t0 + POOL_ROWS);
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rofs < rif) {
+        float av[4], bv[4], mv[4], iv[4], gp[4];
+        vload<4>(av, a + col); vload<4>(bv, b + col); vload<4>(mv, mean + col); vload<4>(iv, invstd + col);
+        vload<4>(gp, gpool + (size_t)bi * C + col);
+        const float invT = 1.f / (float)T;
+        for (int t = t0 + rofs; t < t1; t += rif) {
+            const size_t off = ((size_t)bi * T + t) * C + col;
+            float yy[4], gg[4];
+            vload<4>(yy, y + off);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                gg[q] = (fmaf(av[q], yy[q], bv[q]) > 0.f) ? gp[q] * invT : 0.f;
+                s0[q] += gg[q];
+                s1[q] = fmaf(gg[q], (yy[q] - mv[q]) * iv[q], s1[q]);
+            }
+            vstore<4>(g + off, gg);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sm[rofs * C + col + q] = s0[q]; sm[(rif + rofs) * C + col + q] = s1[q]; }
+    }
+    __syncthreads();
+    const size_t pi = (size_t)bi * gridDim.x + blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float u = 0.f, v = 0.f;
+        for (int q = 0; q < rif; ++q) { u += sm[q * C + c]; v += sm[(rif + q) * C + c]; }
+        part[(pi * 2 + 0) * C + c] = u;
+        part[(pi * 2 + 1) * C + c] = v;
+    }
+}
+
+// dy = a * (g - [training] (dbeta + yhat*dgamma)/R) = a*g + c1*y + c0 written into a per-sample zero-padded buffer
+// (B, pad + T + pad, C); the pad rows are zeroed here.  Thread <-> (row lane, 4 channels): the three per-channel
+// coefficients are formed once per thread, then the block walks APPLY_ROWS padded rows.
+constexpr int APPLY_ROWS = 64;
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                           const float* __restrict__ a, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ dbeta,
+                                                           const float* __restrict__ dgamma, float* __restrict__ dyp, int T, int C,
+                                                           int pad, long long rows_padded, float invR, int training) {
+    const int c4 = C / 4, rif = 256 / c4;
+    const int col = (threadIdx.x % c4) * 4, rofs = threadIdx.x / c4;
+    if (rofs >= rif) return;
+    float ca[4], c1[4], c0[4];
+    vload<4>(ca, a + col);
+    if (training) {
+        float mv[4], iv[4], db[4], dg[4];
+        vload<4>(mv, mean + col); vload<4>(iv, invstd + col); vload<4>(db, dbeta + col); vload<4>(dg, dgamma + col);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            c1[q] = -ca[q] * iv[q] * dg[q] * invR;
+            c0[q] = -ca[q] * (db[q] - mv[q] * iv[q] * dg[q]) * invR;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c1[q] = c0[q] = 0.f;
+    }
+    const int Tp = T + 2 * pad;
+    const long long r0 = (long long)blockIdx.x * APPLY_ROWS;
+    const long long r1 = min(rows_padded, r0 + APPLY_ROWS);
+    for (long long row = r0 + rofs; row < r1; row += rif) {
+        const long long bi = row / Tp;
+        const int tp = (int)(row - bi * Tp);
+        float out[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tp >= pad && tp < pad + T) {
+            const size_t off = ((size_t)bi * T + (tp - pad)) * C + col;
+            float gg[4], yy[4] = {0.f, 0.f, 0.f, 0.f};
+            vload<4>(gg, g + off);
+            if (training) vload<4>(yy, y + off);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[q] = fmaf(ca[q], gg[q], fmaf(c1[q], yy[q], c0[q]));
+        }
+        vstore<4>(dyp + (size_t)row * C + col, out);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static int bn_check(const char* who, long long R, int C) {
+    if (R <= 0 || C <= 0 || (C & 3) || C > 1024) {
+        ign_set_error("%s: need R > 0 and 4 <= C <= 1024 with C %% 4 == 0 (R=%lld C=%d)", who, R, C);
+        return IGN_E_ARG;
+    }
+    return 0;
+}
+
+extern "C" int ign_bn_finalize_fwd(const float* part, int nparts, long long R, int C, const float* gamma, const float* beta,
+                                   float eps, float momentum, float* running_mean, float* running_var, float* a, float* b,
+                                   float* mean, float* invstd, void* stream) {
+    if (!part || nparts <= 0 || R <= 0 || C <= 0 || !gamma || !beta || !a || !b || !mean || !invstd) {
+        ign_set_error("ign_bn_finalize_fwd: bad argument");
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, nparts, R, C, gamma, beta,
+                       eps, momentum, running_mean, running_var, a, b, mean, invstd);
+    return ign_check_launch("bn_finalize_fwd_kernel");
+}
+
+extern "C" int ign_bn_affine_eval(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                                  float eps, int C, float* a, float* b, float* mean, float* invstd, void* stream) {
+    if (!running_mean || !running_var || !gamma || !beta || C <= 0 || !a || !b || !mean || !invstd) {
+        ign_set_error("ign_bn_affine_eval: bad argument");
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(bn_affine_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, running_mean, running_var,
+                       gamma, beta, eps, C, a, b, mean, invstd);
+    return ign_check_launch("bn_affine_eval_kernel");
+}
+
+extern "C" int ign_bn_finalize_bwd(const float* part, int nparts, int C, float* dbeta, float* dgamma, void* stream) {
+    if (!part || nparts <= 0 || C <= 0 || !dbeta || !dgamma) {
+        ign_set_error("ign_bn_finalize_bwd: bad argument");
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, nparts, C, dbeta, dgamma);
+    return ign_check_launch("bn_finalize_bwd_kernel");
+}
+
+extern "C" int ign_bn_relu_pool_fwd(const float* y, const float* a, const float* b, float* pooled, int B, int T, int C,
+                                    void* stream) {
+    int rc;
+    if ((rc = bn_check("ign_bn_relu_pool_fwd", (long long)B * T, C))) return rc;
+    if (!y || !a || !b || !pooled) { ign_set_error("ign_bn_relu_pool_fwd: null pointer"); return IGN_E_ARG; }
+    const int rif = 256 / (C / 4);
+    IgnScopedTimer tm("bn_relu_pool_fwd", (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(B), dim3(256), (size_t)rif * C * 4, (hipStream_t)stream, y, a, b, pooled, T, C);
+    return ign_check_launch("bn_relu_pool_fwd_kernel");
+}
+
+extern "C" long long ign_bn_relu_pool_bwd_parts(int B, int T) { return (long long)B * ((T + POOL_ROWS - 1) / POOL_ROWS); }
+
+extern "C" int ign_bn_relu_pool_bwd(const float* y, const float* gpool, const float* a, const float* b, const float* mean,
+                                    const float* invstd, float* g, float* part, int B, int T, int C, void* stream) {
+    int rc;
+    if ((rc = bn_check("ign_bn_relu_pool_bwd", (long long)B * T, C))) return rc;
+    if (!y || !gpool || !a || !b || !mean || !invstd || !g || !part) { ign_set_error("ign_bn_relu_pool_bwd: null pointer"); return IGN_E_ARG; }
+    const int rif = 256 / (C / 4);
+    IgnScopedTimer tm("bn_relu_pool_bwd", (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_relu_pool_bwd_kernel, dim3((T + POOL_ROWS - 1) / POOL_ROWS, B), dim3(256), (size_t)2 * rif * C * 4,
+                       (hipStream_t)stream, y, gpool, a, b, mean, invstd, g, part, T, C);
+    return ign_check_launch("bn_relu_pool_bwd_kernel");
+}
+
+extern "C" int ign_bn_bwd_apply(const float* g, const float* y, const float* a, const float* mean, const float* invstd,
+                                const float* dbeta, const float* dgamma, float* dyp, int B, int T, int C, int pad, int training,
+                                void* stream) {
+    int rc;
+    if ((rc = bn_check("ign_bn_bwd_apply", (long long)B * T, C))) return rc;
+    if (!g || !a || !dyp || pad < 0 || (training && (!y || !mean || !invstd || !dbeta || !dgamma))) {
+        ign_set_error("ign_bn_bwd_apply: null pointer / negative pad");
+        return IGN_E_ARG;
+    }
+    const long long rows = (long long)B * (T + 2 * pad);
+    IgnScopedTimer tm("bn_bwd_apply", (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((rows + APPLY_ROWS - 1) / APPLY_ROWS)), dim3(256), 0, (hipStream_t)stream,
+                       g, y, a, mean, invstd, dbeta, dgamma, dyp, T, C, pad, rows, 1.0f / (float)((long long)B * T), training);
+    return ign_check_launch("bn_bwd_apply_kernel");
+}
+

@@ -1,0 +1,514 @@
+// Split-bf16 ("x6") convolution GEMMs: fp32-accurate products on the bf16 matrix cores.  Forward / data gradient with tap
+// reuse (clconv_x6t_kernel), weight gradient with transposing LDS reads (clconv_wgrad_x6_kernel), the weight pre-split, and
+// their C entry points.  The fp32-MFMA counterparts and the fwd / dgrad entry points that dispatch here: ign_clconv_f32.hip.
+#include "ign_clconv.h"
+
+// ------------------------------------------------------------------------------------------------ NT GEMM, split bf16
+// fp32-accurate product on the bf16 matrix cores.  gfx950 runs v_mfma_f32_32x32x2_f32 at the fp32 VECTOR rate
+// (64 FLOP/clk/SIMD, 157 TFLOP/s) -- the real matrix throughput is behind the 16-bit inputs (1024 FLOP/clk/SIMD).
+// Each fp32 operand is split exactly into three bf16 terms x = x0 + x1 + x2 (8 significant bits each, round-to-nearest;
+// the residuals are exact fp32 subtractions) and the product keeps the six terms of weight >= 2^-16,
+//     a*b ~= a0*b0 + (a0*b1 + a1*b0) + (a0*b2 + a1*b1 + a2*b0),        dropped: O(2^-24 |a b|),
+// every partial product exact (8 x 8 bits) and accumulated in fp32 by v_mfma_f32_32x32x16_bf16: 6 MFMAs of 16x the
+// rate = 2.7x the fp32-MFMA throughput at fp32 rounding-level error (measured against float64 in tests/test_gpu_fcn.py).
+// The activation operand is split while it is staged (after the BatchNorm+ReLU prologue); the weights arrive pre-split
+// (ign_clconv_pack_weights_x3).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int X6_PITCH = KC + 8;             // bf16 per staged row: 48 B, 12*i mod 64 dwords is conflict-free for b128 reads
+constexpr int X6_PLANE = TM * X6_PITCH;      // bf16 per plane per stage
+
+__device__ __forceinline__ void split3(float v, __bf16& x0, __bf16& x1, __bf16& x2) {
+    x0 = (__bf16)v;
+    float r = v - (float)x0;
+    x1 = (__bf16)r;
+    r -= (float)x1;
+    x2 = (__bf16)r;
+}
+
+// ---- split-bf16 convolution with tap reuse.  The im2col rows of 128 consecutive output positions of one sample overlap:
+// together they are the (128 + k - 1)-row span of the input.  Per 16-channel chunk that span is loaded, passed through the
+// prologue and split ONCE, and all k taps run from it with the MFMA row operand shifted by one LDS row per tap -- the plain
+// GEMM form above loads and splits every activation k times.  Weights: bf16 planes (3, N, k*Cp), Cp = channels rounded up to
+// 16, so every (tap, chunk) block is 16-byte aligned.  One barrier per (chunk, tap) step of 24 MFMAs per wave; the weights
+// of the next step and (on the last tap) the next span are prefetched into registers during the MFMAs.
+constexpr int X6T_SPAN = TM + 15;                  // k <= 16
+constexpr int X6T_APLANE = X6T_SPAN * X6_PITCH;
+constexpr int X6T_ABUF = 3 * X6T_APLANE;
+constexpr int X6T_BBUF = 3 * X6_PLANE;
+constexpr size_t X6T_LDS_BYTES = (size_t)2 * (X6T_ABUF + X6T_BBUF) * sizeof(unsigned short);
+
+template <int V, bool PRO, int EPI>
+__global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca) {
+    const GemmNTArgs& a = ca.g;
+    constexpr int VPR = KC / V;                               // vectors per span row
+    constexpr int APASS = (X6T_SPAN * VPR + 255) / 256;       // staging passes of the span (V=4: 3, V=2: 5, V=1: 9)
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    __bf16* Abuf = reinterpret_cast<__bf16*>(smem16);
+    __bf16* Bbuf = Abuf + 2 * X6T_ABUF;
+
+    const int nwg = a.mtiles * a.ntiles;
+    int lid = blockIdx.x;
+    {
+        const int per = nwg / 8;
+        if (lid < per * 8) lid = (lid & 7) * per + (lid >> 3);
+    }
+    const int mt = lid / a.ntiles, nt = lid - mt * a.ntiles;
+    const int bi = mt / ca.tps, tt = mt - bi * ca.tps;
+    const int t0 = tt * TM, n0 = nt * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int span = TM + ca.k - 1;
+    const int nvec = span * VPR;
+
+    const float* abase = a.A + (long long)bi * ca.sample_pitch;
+    const int brw = tid >> 1, bh = tid & 1;
+    const unsigned short* bsrc = a.B3 + (size_t)min(n0 + brw, a.N - 1) * a.Kp + 8 * bh;
+    const size_t bplane = (size_t)a.N * a.Kp;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[APASS][V];
+    float pa[V], pb[V];
+    bool a_ok = false;
+    // Weight prefetch registers: two sets of three planes (scalars, not arrays: arrays captured by the lambdas below end
+    // up in scratch).  The loads for step s+2 are issued at the top of step s, so they have two steps to land.
+    uint4 rb00, rb01, rb02, rb10, rb11, rb12;
+    const int ncc = ca.cp / KC;
+    const int nstep = ncc * ca.k;
+
+    auto aload = [&](int cc) {
+        const int ch = cc * KC + (tid % VPR) * V;          // 256 % VPR == 0: a thread keeps its channel offset in every pass
+        a_ok = ch < ca.cin;                                  // V divides cin: a vector is entirely inside or outside
+        if (PRO && a_ok) { vload<V>(pa, a.pro_a + ch); vload<V>(pb, a.pro_b + ch); }
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+            const int idx = tid + p * 256;
+            const int row = idx / VPR;
+            if (a_ok && idx < nvec) vload<V>(ra[p], abase + (long long)min(t0 + row, ca.rows_in - 1) * ca.cin + ch);
+            else {
+#pragma unroll
+                for (int v = 0; v < V; ++v) ra[p][v] = 0.f;
+            }
+        }
+    };
+    auto astore = [&](int buf) {
+        __bf16* st = Abuf + buf * X6T_ABUF;
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+            const int idx = tid + p * 256;
+            if (idx < nvec) {
+                const int row = idx / VPR, q = idx - row * VPR;
+                __bf16 x0[V], x1[V], x2[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    float t = ra[p][v];
+                    if (PRO && a_ok) t = fmaxf(fmaf(pa[v], t, pb[v]), 0.f);
+                    split3(t, x0[v], x1[v], x2[v]);
+                }
+                __bf16* d = st + row * X6_PITCH + q * V;
+#pragma unroll
+                for (int v = 0; v < V; ++v) { d[v] = x0[v]; d[X6T_APLANE + v] = x1[v]; d[2 * X6T_APLANE + v] = x2[v]; }
+            }
+        }
+    };
+    // step index -> offset of its (tap, chunk) block in a weight row; steps past the end re-read the last block (the loads
+    // stay unconditional so that the compiler's vmcnt bookkeeping is exact on every path)
+    auto boff = [&](int st) {
+        st = min(st, nstep - 1);
+        const int cc = st / ca.k, j = st - cc * ca.k;
+        return (size_t)j * ca.cp + cc * KC;
+    };
+    auto bstore = [&](int buf, const uint4& r0, const uint4& r1, const uint4& r2) {
+        __bf16* st = Bbuf + buf * X6T_BBUF + brw * X6_PITCH + 8 * bh;
+        *reinterpret_cast<uint4*>(st) = r0;
+        *reinterpret_cast<uint4*>(st + X6_PLANE) = r1;
+        *reinterpret_cast<uint4*>(st + 2 * X6_PLANE) = r2;
+    };
+#define IGN_BLOAD(r0, r1, r2, st)                                                       \
+    do {                                                                                \
+        const size_t off_ = boff(st);                                                   \
+        r0 = *reinterpret_cast<const uint4*>(bsrc + off_);                              \
+        r1 = *reinterpret_cast<const uint4*>(bsrc + bplane + off_);                     \
+        r2 = *reinterpret_cast<const uint4*>(bsrc + 2 * bplane + off_);                 \
+    } while (0)
+
+    aload(0);
+    IGN_BLOAD(rb00, rb01, rb02, 0);
+    IGN_BLOAD(rb10, rb11, rb12, 1);
+    astore(0);
+    bstore(0, rb00, rb01, rb02);
+    __syncthreads();
+
+    int cc = 0, j = 0;
+    auto body = [&](int step, bool odd) {
+        // registers of parity (step & 1) held step `step` (already in LDS): reuse them for step + 2
+        if (odd) IGN_BLOAD(rb10, rb11, rb12, step + 2);
+        else IGN_BLOAD(rb00, rb01, rb02, step + 2);
+        const bool next_span = cc + 1 < ncc;
+        if (j == 0 && next_span) aload(cc + 1);             // k steps ahead of its use
+        const __bf16* As = Abuf + (cc & 1) * X6T_ABUF + (wm * 64 + l31 + j) * X6_PITCH + 8 * h;
+        const __bf16* Bs = Bbuf + (step & 1) * X6T_BBUF + (wn * 64 + l31) * X6_PITCH + 8 * h;
+        bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                af[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * X6T_APLANE + i * 32 * X6_PITCH);
+                bf[i][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * X6_PLANE + i * 32 * X6_PITCH);
+            }
+#define IGN_X6(pa_, pb_)                                                                                   \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[0][pb_], acc[0][0], 0, 0, 0);   \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[1][pb_], acc[0][1], 0, 0, 0);   \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[0][pb_], acc[1][0], 0, 0, 0);   \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[1][pb_], acc[1][1], 0, 0, 0);
+        IGN_X6(2, 0) IGN_X6(0, 2) IGN_X6(1, 1) IGN_X6(1, 0) IGN_X6(0, 1) IGN_X6(0, 0)
+#undef IGN_X6
+        // step + 1 goes to LDS from the OTHER register set (loaded during step - 1)
+        if (odd) bstore((step + 1) & 1, rb00, rb01, rb02);
+        else bstore((step + 1) & 1, rb10, rb11, rb12);
+        if (j + 1 == ca.k) {
+            if (next_span) astore((cc + 1) & 1);
+            j = 0; ++cc;
+        } else {
+            ++j;
+        }
+        __syncthreads();
+    };
+    for (int step = 0; step < nstep; step += 2) {
+        body(step, false);
+        if (step + 1 < nstep) body(step + 1, true);
+    }
+#undef IGN_BLOAD
+    const int m0 = bi * ca.trows + t0;
+    nt_epilogue<EPI>(a, acc, reinterpret_cast<float*>(smem16), mt, m0, n0, bi * ca.trows + min(ca.trows, t0 + TM));
+}
+
+// Tap-major planes for the kernel above: Wt3[p][co][j*Cip + ci], Wd3[p][ci][jj*Cop + co] (zero in the padded channels)
+__global__ void __launch_bounds__(256) pack_weights_x3t_kernel(const float* __restrict__ w, unsigned short* __restrict__ wt3,
+                                                               unsigned short* __restrict__ wd3, int Co, int Ci, int k, int Cip,
+                                                               int Cop) {
+    const long long nf = (long long)Co * k * Cip, nd = wd3 ? (long long)Ci * k * Cop : 0;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f;
+    __bf16* dst;
+    long long plane;
+    if (i < nf) {
+        const int ci = (int)(i % Cip);
+        const long long t = i / Cip;
+        const int j = (int)(t % k);
+        const long long co = t / k;
+        if (ci < Ci) v = w[(co * Ci + ci) * k + j];
+        dst = reinterpret_cast<__bf16*>(wt3) + i;
+        plane = nf;
+    } else if (i < nf + nd) {
+        const long long e = i - nf;
+        const int co = (int)(e % Cop);
+        const long long t = e / Cop;
+        const int jj = (int)(t % k);
+        const long long ci = t / k;
+        if (co < Co) v = w[((long long)co * Ci + ci) * k + (k - 1 - jj)];
+        dst = reinterpret_cast<__bf16*>(wd3) + e;
+        plane = nd;
+    } else {
+        return;
+    }
+    __bf16 x0, x1, x2;
+    split3(v, x0, x1, x2);
+    dst[0] = x0; dst[plane] = x1; dst[2 * plane] = x2;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient, split bf16
+// dW[co][j][ci] = sum_{b,t} dy[b,t,co] * in[b,t+j,ci] on the bf16 matrix cores (same six-term split as above).
+// The reduction index is the ROW index of both operands, so the MFMA needs each operand column-major; the operands are
+// staged row-major (as they arrive: coalesced loads, one split per element) and read with gfx950's transposing LDS read
+// ds_read_b64_tr_b16, which hands lane i the 4 consecutive rows of column i.  Because rows stay rows in LDS, tap j is
+// again just a row offset: one staged (16*NR + k - 1)-row span of the input serves all k taps, and the dy fragments are
+// read once per unit and reused by every tap.  Workgroup tile: 64 co x 64 ci x k taps (wave: 32 x 32 x k taps = k
+// accumulators), reduction over units of 16*NR output rows that never straddle a sample, split over unit ranges.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int WG_PITCH = 64 + 32;             // bf16 per staged row: 192 B; four rows' 32-dword windows tile the 64 banks
+
+struct WgradX6Args {
+    const float* dy; long long dy_sample_pitch; int dy_row0;     // dy[b][dy_row0 + t][co], row pitch Co
+    const float* x; long long x_sample_pitch;                      // in[b][t][ci], row pitch Ci
+    const float* pro_a; const float* pro_b;                        // in = relu(pro_a*x + pro_b) (or raw x)
+    float* part;                                                   // (nsplit, Co, k*Ci)
+    int B, Tin, Tout, Ci, Co, k;
+    int cps;                                                       // units per sample
+    int nunits, nsplit, citiles;
+};
+
+__device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p1));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int KT, int NR, int VX, bool PRO>
+__global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Args a) {
+    constexpr int RU = 16 * NR;                     // output rows per unit
+    constexpr int SPAN = RU + KT - 1;               // input rows per unit
+    constexpr int PPLANE = RU * WG_PITCH, QPLANE = SPAN * WG_PITCH;
+    constexpr int STAGE = 3 * (PPLANE + QPLANE);
+    constexpr int XVPR = 64 / VX;                   // input vectors per row
+    constexpr int XPASS = (SPAN * XVPR + 255) / 256;
+    constexpr int DPASS = NR;                       // dy: RU rows x 16 float4 = 256 * NR vectors
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    __bf16* smem = reinterpret_cast<__bf16*>(smem16);
+
+    const int tile = blockIdx.x;
+    const int cot = tile / a.citiles, cit = tile - cot * a.citiles;
+    const int co0 = cot * 64, ci0 = cit * 64;
+    const int split = blockIdx.y;
+    const int per = (a.nunits + a.nsplit - 1) / a.nsplit;
+    const int u_begin = split * per, u_end = min(a.nunits, u_begin + per);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wco = wave & 1, wci = wave >> 1;
+
+    // staging coordinates
+    const int dr = tid >> 4, dc = (tid & 15) * 4;            // dy: row dr (+16 per pass), 4 channels from dc
+    const bool d_ok = co0 + dc < a.Co;                        // Co % 4 == 0
+    const int xq = (tid % XVPR) * VX;                         // input: channel offset inside the tile (256 % XVPR == 0)
+    const bool x_ok = ci0 + xq < a.Ci;                        // VX divides Ci
+    float pa[VX], pb[VX];
+    if (PRO && x_ok) { vload<VX>(pa, a.pro_a + ci0 + xq); vload<VX>(pb, a.pro_b + ci0 + xq); }
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    float rd[DPASS][4], rx[XPASS][VX];
+    auto gload = [&](int u) {
+        const int b = u / a.cps, t0 = (u - b * a.cps) * RU;
+        const float* dyb = a.dy + (long long)b * a.dy_sample_pitch + (long long)a.dy_row0 * a.Co + co0 + dc;
+        const float* xb = a.x + (long long)b * a.x_sample_pitch + ci0 + xq;
+#pragma unroll
+        for (int p = 0; p < DPASS; ++p) {
+            const int t = t0 + dr + 16 * p;
+            if (d_ok && t < a.Tout) vload<4>(rd[p], dyb + (long long)t * a.Co);
+            else { rd[p][0] = rd[p][1] = rd[p][2] = rd[p][3] = 0.f; }
+        }
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+            const int row = (tid + p * 256) / XVPR;
+            if (x_ok && row < SPAN) vload<VX>(rx[p], xb + (long long)min(t0 + row, a.Tin - 1) * a.Ci);
+            else {
+#pragma unroll
+                for (int v = 0; v < VX; ++v) rx[p][v] = 0.f;
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        __bf16* P = smem + buf * STAGE;
+        __bf16* Q = P + 3 * PPLANE;
+#pragma unroll
+        for (int p = 0; p < DPASS; ++p) {
+            __bf16* d = P + (dr + 16 * p) * WG_PITCH + dc;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                __bf16 x0, x1, x2;
+                split3(rd[p][v], x0, x1, x2);
+                d[v] = x0; d[PPLANE + v] = x1; d[2 * PPLANE + v] = x2;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+            const int row = (tid + p * 256) / XVPR;
+            if (row < SPAN) {
+                __bf16* d = Q + row * WG_PITCH + xq;
+#pragma unroll
+                for (int v = 0; v < VX; ++v) {
+                    float t = rx[p][v];
+                    if (PRO && x_ok) t = fmaxf(fmaf(pa[v], t, pb[v]), 0.f);
+                    __bf16 x0, x1, x2;
+                    split3(t, x0, x1, x2);
+                    d[v] = x0; d[QPLANE + v] = x1; d[2 * QPLANE + v] = x2;
+                }
+            }
+        }
+    };
+
+    // transposed-read addresses: 16-lane group G = lane>>4 reads the 4-row x 16-column block whose rows are supplied by
+    // lanes 4q+p (row q, columns 4p..4p+3); lane u of the group receives column u.  For the 32x32x16 operand lane (i, g)
+    // needs rows 8g..8g+7 of column i: two reads (rows 8g..8g+3 and 8g+4..8g+7) of the block at columns 16*(G&1).
+    const int u16 = lane & 15, q4 = u16 >> 2, p4 = u16 & 3, G1 = (lane >> 4) & 1;
+    const int row_lo = 8 * h + q4;
+    const int acol = wco * 32 + 16 * G1 + 4 * p4;
+    const int bcol = wci * 32 + 16 * G1 + 4 * p4;
+
+    if (u_begin < u_end) {
+        gload(u_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int u = u_begin; u < u_end; ++u, buf ^= 1) {
+        if (u + 1 < u_end) gload(u + 1);
+        const __bf16* P = smem + buf * STAGE;
+        const __bf16* Q = P + 3 * PPLANE;
+#pragma unroll
+        for (int s = 0; s < NR; ++s) {
+            bf16x8 af[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const __bf16* base = P + pl * PPLANE + (16 * s + row_lo) * WG_PITCH + acol;
+                af[pl] = lds_tr8(base, base + 4 * WG_PITCH);
+            }
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                bf16x8 bf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const __bf16* base = Q + pl * QPLANE + (16 * s + row_lo + j) * WG_PITCH + bcol;
+                    bf[pl] = lds_tr8(base, base + 4 * WG_PITCH);
+                }
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[j], 0, 0, 0);
+            }
+        }
+        if (u + 1 < u_end) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = a.part + (long long)split * a.Co * a.k * a.Ci;
+    const int ci = ci0 + wci * 32 + l31;
+    if (ci < a.Ci) {
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco * 32 + acc_row16(r, h);
+                if (co < a.Co) out[((long long)co * a.k + j) * a.Ci + ci] = acc[j][r];
+            }
+    }
+}
+
+// dW[co][ci][j] = sum_s part[s][co][j*Ci + ci]   (s ascending: bitwise reproducible); torch (Co, Ci, k) layout
+// ------------------------------------------------------------------------------------------------ C ABI
+template <int EPI>
+static int launch_x6t(const ConvX6Args& a, int V, bool pro, hipStream_t s) {
+    const dim3 grid((unsigned)(a.g.mtiles * a.g.ntiles)), block(256);
+#define IGN_X6T(VV, PP)                                                                                                      \
+    do {                                                                                                                     \
+        static bool once = false;                                                                                            \
+        if (!once) {                                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_x6t_kernel<VV, PP, EPI>),                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6T_LDS_BYTES);                       \
+            once = true;                                                                                                     \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((clconv_x6t_kernel<VV, PP, EPI>), grid, block, X6T_LDS_BYTES, s, a);                               \
+    } while (0)
+    if (V == 4) { if (pro) IGN_X6T(4, true); else IGN_X6T(4, false); }
+    else if (V == 2) { if (pro) IGN_X6T(2, true); else IGN_X6T(2, false); }
+    else { if (pro) IGN_X6T(1, true); else IGN_X6T(1, false); }
+#undef IGN_X6T
+    return ign_check_launch("clconv_x6t_kernel");
+}
+
+int ign_clconv_launch_x6t(const ConvX6Args& a, int epi, int V, bool pro, hipStream_t s) {
+    return epi == EPI_BIAS_STATS ? launch_x6t<EPI_BIAS_STATS>(a, V, pro, s) : launch_x6t<EPI_MASK_STATS>(a, V, pro, s);
+}
+
+extern "C" int ign_clconv_kpad(int C) { return (C + 15) / 16 * 16; }
+extern "C" long long ign_clconv_x6_mtiles(int B, int rows) { return (long long)B * ((rows + TM - 1) / TM); }
+
+extern "C" int ign_clconv_pack_weights_x3(const float* w_oik, void* wt3_fwd, void* wt3_dgrad, int Co, int Ci, int k, void* stream) {
+    if (!w_oik || !wt3_fwd || Co <= 0 || Ci <= 0 || k <= 0) {
+        ign_set_error("ign_clconv_pack_weights_x3: bad argument (Co=%d Ci=%d k=%d)", Co, Ci, k);
+        return IGN_E_ARG;
+    }
+    const int Cip = ign_clconv_kpad(Ci), Cop = ign_clconv_kpad(Co);
+    const long long n = (long long)Co * k * Cip + (wt3_dgrad ? (long long)Ci * k * Cop : 0);
+    hipLaunchKernelGGL(pack_weights_x3t_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oik,
+                       (unsigned short*)wt3_fwd, (unsigned short*)wt3_dgrad, Co, Ci, k, Cip, Cop);
+    return ign_check_launch("pack_weights_x3t_kernel");
+}
+
+template <int KT, int NR>
+static int launch_wgrad_x6(const WgradX6Args& a, int V, bool pro, dim3 grid, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * 3 * ((16 * NR) + (16 * NR + KT - 1)) * WG_PITCH * sizeof(unsigned short);
+#define IGN_WG(VV, PP)                                                                                                       \
+    do {                                                                                                                     \
+        static bool once = false;                                                                                            \
+        if (!once) {                                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_wgrad_x6_kernel<KT, NR, VV, PP>),                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+            once = true;                                                                                                     \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((clconv_wgrad_x6_kernel<KT, NR, VV, PP>), grid, dim3(256), lds, s, a);                             \
+    } while (0)
+    if (V == 4) { if (pro) IGN_WG(4, true); else IGN_WG(4, false); }
+    else if (V == 2) { if (pro) IGN_WG(2, true); else IGN_WG(2, false); }
+    else { if (pro) IGN_WG(1, true); else IGN_WG(1, false); }
+#undef IGN_WG
+    return ign_check_launch("clconv_wgrad_x6_kernel");
+}
+
+static int wgrad_x6_rows_per_unit(int k) { return (k == 8 || k == 5) ? 16 : (k == 3 || k == 2) ? 32 : 0; }
+static int wgrad_x6_splits(int nunits, int tiles) {
+    int s = (512 + tiles - 1) / tiles;                        // ~2 workgroups per CU
+    const int max_s = (nunits + 15) / 16;                     // at least 16 units per split
+    if (s > max_s) s = max_s;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" size_t ign_clconv_wgrad_x6_workspace_bytes(int B, int Tin, int Ci, int Co, int k) {
+    const int Tout = Tin - k + 1, ru = wgrad_x6_rows_per_unit(k);
+    if (B <= 0 || Tout <= 0 || Ci <= 0 || Co <= 0 || !ru) return 0;
+    const int tiles = ((Co + 63) / 64) * ((Ci + 63) / 64);
+    const int nunits = B * ((Tout + ru - 1) / ru);
+    return (size_t)wgrad_x6_splits(nunits, tiles) * Co * k * Ci * sizeof(float);
+}
+
+extern "C" int ign_clconv_wgrad_x6(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
+                                   float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream) {
+    static const char* who = "ign_clconv_wgrad_x6";
+    const int Tout = Tin - k + 1, ru = wgrad_x6_rows_per_unit(k);
+    if (!dyp || !x || !dw_oik || !workspace || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || dy_pad < 0 ||
+        ((pro_a == nullptr) != (pro_b == nullptr))) {
+        ign_set_error("%s: bad argument (B=%d Tin=%d Ci=%d Co=%d k=%d pad=%d)", who, B, Tin, Ci, Co, k, dy_pad);
+        return IGN_E_ARG;
+    }
+    if (Co % 4 || !ru) { ign_set_error("%s: needs Co %% 4 == 0 and k in {2,3,5,8} (Co=%d k=%d)", who, Co, k); return IGN_E_UNSUP; }
+    hipStream_t s = (hipStream_t)stream;
+    WgradX6Args a{};
+    a.dy = dyp; a.dy_sample_pitch = (long long)(Tout + 2 * dy_pad) * Co; a.dy_row0 = dy_pad;
+    a.x = x; a.x_sample_pitch = (long long)Tin * Ci; a.pro_a = pro_a; a.pro_b = pro_b;
+    a.part = (float*)workspace; a.B = B; a.Tin = Tin; a.Tout = Tout; a.Ci = Ci; a.Co = Co; a.k = k;
+    a.cps = (Tout + ru - 1) / ru; a.nunits = B * a.cps;
+    a.citiles = (Ci + 63) / 64;
+    const int tiles = ((Co + 63) / 64) * a.citiles;
+    a.nsplit = wgrad_x6_splits(a.nunits, tiles);
+    const dim3 grid((unsigned)tiles, (unsigned)a.nsplit);
+    const int V = ign_vec_width(Ci);
+    const bool pro = pro_a != nullptr;
+    int rc;
+    {
+        IgnScopedTimer tm("clconv_wgrad", s);
+        if (k == 8) rc = launch_wgrad_x6<8, 1>(a, V, pro, grid, s);
+        else if (k == 5) rc = launch_wgrad_x6<5, 1>(a, V, pro, grid, s);
+        else if (k == 3) rc = launch_wgrad_x6<3, 2>(a, V, pro, grid, s);
+        else rc = launch_wgrad_x6<2, 2>(a, V, pro, grid, s);
+    }
+    if (rc) return rc;
+    return ign_clconv_launch_wgrad_reduce((const float*)workspace, dw_oik, a.nsplit, Co, Ci, k, s);
+}
+

@@ -1,5 +1,5 @@
 """The FCN expert's convolution stack as ONE autograd node over the channels-last implicit-GEMM kernels
-(include/ign_abi.h: ign_clconv_*, ign_bn_*; csrc/ign_clconv.hip).
+(include/ign_abi.h: ign_clconv_*, ign_bn_*; csrc/ign_clconv_{f32,x6}.hip, ign_bn.hip).
 
 Replaces ``block1 -> block2 -> block3 -> AdaptiveAvgPool1d`` of IGN/model/FullyConvNet.py:31-57.  What reaches HBM per
 block is only the raw convolution output y_l (needed by the backward anyway): BatchNorm's statistics come out of the

@@ -1,7 +1,7 @@
 """FCN deep expert (IGN/model/FullyConvNet.py:7-59): 3 x (Conv1d + BatchNorm1d + ReLU) -> GAP -> Linear.
 
 State-dict keys match the reference (``block{1,2,3}.{0,1}.*``, ``fc.*``).  On the GPU the three blocks and the pool run as
-one autograd node over the hand-written channels-last implicit-GEMM kernels (ign_hip/fcn.py, csrc/ign_clconv.hip): the
+one autograd node over the hand-written channels-last implicit-GEMM kernels (ign_hip/fcn.py, csrc/ign_clconv_{f32,x6}.hip, ign_bn.hip): the
 loader's (B, T, C) batch IS the GEMM operand (the im2col row of (b, t) is x[b, t:t+k, :], contiguous), BatchNorm statistics
 come out of the GEMM epilogue and BatchNorm's affine + ReLU are applied while the next GEMM stages its operand.
 ``IGN_FCN_MIOPEN=1`` routes the convolutions through torch's MIOpen backend instead (A/B measurements only).

@@ -1,4 +1,4 @@
-"""GPU parity of the FCN expert's hand-written convolution stack (csrc/ign_clconv.hip through the C ABI):
+"""GPU parity of the FCN expert's hand-written convolution stack (csrc/ign_clconv_{f32,x6}.hip, ign_bn.hip through the C ABI):
 implicit-GEMM Conv1d forward / data gradient / weight gradient with the BatchNorm + ReLU prologues and epilogues,
 against a float64 torch reference of IGN/model/FullyConvNet.py:31-59 on the CPU.  Tolerance 1e-4 (north_star)."""
 import ctypes
