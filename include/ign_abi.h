@@ -140,6 +140,10 @@ int ign_diversity_fwd_bwd(const float* w_kcl, float* loss_part_c, float* gw_kcl,
 int ign_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                   float beta1, float beta2, float eps, int step, void* stream);
 
+/* Copy `count` gradient tensors (src[i], n[i] floats) to flat + off[i] in one launch: the flat gradient bucket of the
+ * data-parallel step is filled by one kernel instead of one accumulate kernel per parameter.  src / off / n are HOST arrays. */
+int ign_gather_flat(const void* const* src, const long long* off, const long long* n, int count, float* flat, void* stream);
+
 /* The same step with the step count kept on the device (*step_dev is incremented, bc_dev[2] receives the bias
  * corrections): nothing host-side changes between steps, so the launch sequence can be captured into a hipGraph.      */
 int ign_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,

@@ -4,17 +4,19 @@
 #include "ign_clconv.h"
 
 // ------------------------------------------------------------------------------------------------ BatchNorm glue
-// Sum of the per-tile partials (nparts, 2, C) for 32 channels per block: 32 slices of the partials are summed in
-// parallel (ascending inside a slice), then the 32 slice sums are combined in fixed order in double.
+// Sum of the per-tile partials (nparts, 2, C) for BN_CH channels per block: BN_SL slices of the partials are summed in
+// parallel (ascending inside a slice, fp32 over <= 64 addends, then double), and the slice sums are combined in fixed order
+// in double.  Small blocks of channels keep C/BN_CH workgroups busy on a reduction that is only a few MB.
+constexpr int BN_CH = 8, BN_SL = 128;
 __device__ __forceinline__ void bn_sum_partials(const float* __restrict__ part, int nparts, int C, double* s_out, double* q_out) {
-    __shared__ double sh[2][32][33];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double sh[2][BN_SL][BN_CH + 1];
+    const int cl = threadIdx.x % BN_CH, sl = threadIdx.x / BN_CH;
+    const int c = blockIdx.x * BN_CH + cl;
     double s = 0.0, q = 0.0;
     if (c < C) {
-        const int per = (nparts + 31) / 32;
+        const int per = (nparts + BN_SL - 1) / BN_SL;
         const int i0 = sl * per, i1 = min(nparts, i0 + per);
-        float fs = 0.f, fq = 0.f;              // <= 64 addends of like magnitude per slice in fp32, slices combined in double
+        float fs = 0.f, fq = 0.f;
         int n = 0;
         for (int i = i0; i < i1; ++i) {
             fs += part[((size_t)i * 2 + 0) * C + c];
@@ -28,7 +30,7 @@ __device__ __forceinline__ void bn_sum_partials(const float* __restrict__ part, 
     __syncthreads();
     s = q = 0.0;
     if (sl == 0) {
-        for (int k = 0; k < 32; ++k) { s += sh[0][k][cl]; q += sh[1][k][cl]; }
+        for (int k = 0; k < BN_SL; ++k) { s += sh[0][k][cl]; q += sh[1][k][cl]; }
     }
     *s_out = s; *q_out = q;
 }
@@ -40,8 +42,8 @@ __global__ void __launch_bounds__(1024) bn_finalize_fwd_kernel(const float* __re
                                        float* __restrict__ b, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
     double s, q;
     bn_sum_partials(part, nparts, C, &s, &q);
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    if ((threadIdx.x >> 5) != 0 || c >= C) return;
+    const int c = blockIdx.x * BN_CH + threadIdx.x % BN_CH;
+    if (threadIdx.x / BN_CH != 0 || c >= C) return;
     const double m = s / (double)R;
     double var = q / (double)R - m * m;
     if (var < 0.0) var = 0.0;
@@ -76,8 +78,8 @@ __global__ void __launch_bounds__(1024) bn_finalize_bwd_kernel(const float* __re
                                                                float* __restrict__ dbeta, float* __restrict__ dgamma) {
     double s, q;
     bn_sum_partials(part, nparts, C, &s, &q);
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    if ((threadIdx.x >> 5) != 0 || c >= C) return;
+    const int c = blockIdx.x * BN_CH + threadIdx.x % BN_CH;
+    if (threadIdx.x / BN_CH != 0 || c >= C) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
 }
@@ -216,7 +218,7 @@ extern "C" int ign_bn_finalize_fwd(const float* part, int nparts, long long R, i
         ign_set_error("ign_bn_finalize_fwd: bad argument");
         return IGN_E_ARG;
     }
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, nparts, R, C, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + BN_CH - 1) / BN_CH), dim3(BN_CH * BN_SL), 0, (hipStream_t)stream, part, nparts, R, C, gamma, beta,
                        eps, momentum, running_mean, running_var, a, b, mean, invstd);
     return ign_check_launch("bn_finalize_fwd_kernel");
 }
@@ -237,7 +239,7 @@ extern "C" int ign_bn_finalize_bwd(const float* part, int nparts, int C, float* 
         ign_set_error("ign_bn_finalize_bwd: bad argument");
         return IGN_E_ARG;
     }
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, part, nparts, C, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + BN_CH - 1) / BN_CH), dim3(BN_CH * BN_SL), 0, (hipStream_t)stream, part, nparts, C, dbeta, dgamma);
     return ign_check_launch("bn_finalize_bwd_kernel");
 }
 

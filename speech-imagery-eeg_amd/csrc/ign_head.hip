@@ -279,6 +279,22 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// Gather per-parameter gradient tensors into the flat bucket in ONE launch (instead of one accumulate kernel per parameter):
+// blockIdx.y = table entry, blockIdx.x strides over its elements.
+constexpr int GATHER_MAX = 96;
+struct GatherTable {
+    const float* src[GATHER_MAX];
+    long long off[GATHER_MAX];
+    long long n[GATHER_MAX];
+};
+__global__ void __launch_bounds__(256) gather_flat_kernel(const GatherTable t, float* __restrict__ flat) {
+    const int e = blockIdx.y;
+    const float* __restrict__ src = t.src[e];
+    float* __restrict__ dst = flat + t.off[e];
+    const long long n = t.n[e];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
 // Graph-capturable Adam: the step count lives on the device, so a captured launch sequence stays valid when replayed.
 __global__ void adam_tick_kernel(int* __restrict__ step_dev, float* __restrict__ bc_dev, float b1, float b2) {
     const int step = ++(*step_dev);
@@ -382,6 +398,30 @@ extern "C" int ign_adam_step(float* p, const float* g, float* m, float* v, long 
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
                        eps, (float)bc1, (float)sqrt(bc2));
     return ign_check_launch("adam_kernel");
+}
+
+extern "C" int ign_gather_flat(const void* const* src, const long long* off, const long long* n, int count, float* flat,
+                               void* stream) {
+    if (!src || !off || !n || !flat || count < 0) {
+        ign_set_error("ign_gather_flat: null pointer or negative count");
+        return IGN_E_ARG;
+    }
+    for (int base = 0; base < count; base += GATHER_MAX) {
+        GatherTable t;
+        const int m = count - base < GATHER_MAX ? count - base : GATHER_MAX;
+        long long big = 1;
+        for (int i = 0; i < m; ++i) {
+            t.src[i] = (const float*)src[base + i]; t.off[i] = off[base + i]; t.n[i] = n[base + i];
+            if (!t.src[i] || t.n[i] < 0) { ign_set_error("ign_gather_flat: entry %d is null / negative", base + i); return IGN_E_ARG; }
+            if (t.n[i] > big) big = t.n[i];
+        }
+        const long long bx = (big + 256 * 8 - 1) / (256 * 8);            // ~8 elements per thread for the largest entry
+        hipLaunchKernelGGL(gather_flat_kernel, dim3((unsigned)(bx < 1 ? 1 : (bx > 1024 ? 1024 : bx)), (unsigned)m), dim3(256), 0,
+                           (hipStream_t)stream, t, flat);
+        int rc;
+        if ((rc = ign_check_launch("gather_flat_kernel"))) return rc;
+    }
+    return 0;
 }
 
 extern "C" int ign_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,

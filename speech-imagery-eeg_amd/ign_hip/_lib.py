@@ -32,6 +32,7 @@ SIGNATURES = {
     "ign_loss_fwd_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp]),
     "ign_diversity_fwd_bwd": (ci, [vp, vp, vp, ci, ci, ci, cf, vp]),
     "ign_adam_step": (ci, [vp, vp, vp, vp, ll, cf, cf, cf, cf, ci, vp]),
+    "ign_gather_flat": (ci, [vp, vp, vp, ci, vp, vp]),
     "ign_adam_step_dev": (ci, [vp, vp, vp, vp, ll, cf, cf, cf, cf, vp, vp, vp]),
     "ign_conv1_sumsq_workspace_bytes": (sz, [ci, ci, ci]),
     "ign_conv1_sumsq_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),

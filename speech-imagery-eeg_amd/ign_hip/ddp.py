@@ -29,10 +29,12 @@ class FlatParamBucket:
             self.offsets.append(n)
             n += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.flat_grad = torch.zeros(n, device=dev, dtype=dt)
+        self.views = []
         for p, off in zip(self.params, self.offsets):
             if p.device != dev or p.dtype != dt:
                 raise ValueError("all parameters must share one device and dtype")
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat_grad[off:off + p.numel()].view_as(p))
+            p.grad = None if self.flat_grad.is_cuda else self.views[-1]
         self.module = module
 
     @property
@@ -46,16 +48,54 @@ class FlatParamBucket:
         for t in list(self.module.parameters()) + list(self.module.buffers()):
             dist.broadcast(t.data, src=src, group=self.group)
 
+    def gather(self):
+        """Bring the gradients autograd produced into the flat buffer.
+
+        On the GPU ``zero_grad`` leaves ``p.grad = None``, so autograd hands every parameter a fresh gradient tensor (no
+        accumulate kernel); one ``ign_gather_flat`` launch copies them all into their slots and ``p.grad`` is pointed back
+        at the slot, so clipping, the all-reduce and the optimizer see one buffer.  Parameters whose ``.grad`` already is
+        the slot view (CPU path, or a second call) are left alone; parameters without a gradient get zeros."""
+        todo = []
+        for p, off, view in zip(self.params, self.offsets, self.views):
+            g = p.grad
+            if g is view:
+                continue
+            if g is None:
+                view.zero_()
+            else:
+                todo.append((g.contiguous(), off, view))
+            p.grad = view
+        if not todo:
+            return
+        if not self.flat_grad.is_cuda:
+            for g, _, view in todo:
+                view.copy_(g)
+            return
+        import ctypes
+        from . import _lib
+        n = len(todo)
+        src = (ctypes.c_void_p * n)(*[g.data_ptr() for g, _, _ in todo])
+        off = (ctypes.c_longlong * n)(*[o for _, o, _ in todo])
+        cnt = (ctypes.c_longlong * n)(*[g.numel() for g, _, _ in todo])
+        _lib.check(_lib.lib().ign_gather_flat(src, off, cnt, n, ctypes.c_void_p(self.flat_grad.data_ptr()),
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ign_gather_flat")
+
     def allreduce(self):
         """Average the gradients over ranks: one collective on the flat bucket."""
+        self.gather()
         if self.world == 1:
             return
         dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         self.flat_grad.div_(self.world)
 
     def zero_grad(self):
-        """Zero in place (``optimizer.zero_grad(set_to_none=True)`` would detach the views)."""
-        self.flat_grad.zero_()
+        """GPU: drop the gradients (``gather`` rebuilds the flat buffer at the next step, no zero-fill and no
+        accumulate kernels).  CPU: zero in place, the gradients stay views of the flat buffer."""
+        if self.flat_grad.is_cuda:
+            for p in self.params:
+                p.grad = None
+        else:
+            self.flat_grad.zero_()
 
 
 def shard_indices(n, rank, world, epoch=0, seed=0, shuffle=True):
@@ -107,6 +147,7 @@ class FlatAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         import ctypes
         loss = closure() if closure is not None else None
+        self.bucket.gather()
         self.step_count += 1
         g = self.param_groups[0]
         ptr = lambda t: ctypes.c_void_p(t.data_ptr())
