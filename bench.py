@@ -125,11 +125,19 @@ def main():
                          f"--nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # IGN_BENCH_REHEARSAL=1: every rank uses cuda:0 and the collective runs over gloo -- a functional rehearsal of the N > 1
+    # path on a one-GPU box (never a measurement; the JSON line says so)
+    rehearsal = os.environ.get("IGN_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     torch.set_num_threads(host_cores())
     import speech_imagery_eeg_amd  # noqa: F401
@@ -282,6 +290,8 @@ def main():
         }
         common = {"per_gpu_batch": B, "global_batch": B * world, "samples_per_epoch": N_TRAIN,
                   "parallelism": f"dp{world}", "final_loss": float(last), "hipgraph": bool(use_graph)}
+        if rehearsal:
+            common["rehearsal"] = "all ranks on cuda:0 over gloo: functional check of the N > 1 path, NOT a measurement"
         if args.config == "ign":
             groups = [(s.n, s.length) for s in model.sbm.shapelets]
             f_fwd, f_bwd = shapelet_algorithmic_flops(B, C, T, groups)
