@@ -101,6 +101,8 @@ def _ref_blocks(cfg_in, widths, ks, seed):
     (4, 37, 3, (64, 128, 64), (3, 3, 2), True),          # odd channels, ragged tiles, short kernels
     (2, 1000, 122, (128, 256, 128), (8, 5, 3), True),    # CHISCO shape (small batch)
     (3, 61, 9, (128, 256, 128), (8, 5, 3), False),
+    (1, 140, 1, (128, 256, 128), (8, 5, 3), True),       # univariate series (several UEA sets), one sample
+    (5, 30, 2, (128, 256, 128), (8, 5, 3), True),        # T barely above the kernel sizes
 ])
 @pytest.mark.parametrize("math", ["f32", "bf16x6"])
 def test_fcn_body_forward_backward(B, T, C, widths, ks, training, math, monkeypatch):
