@@ -163,6 +163,10 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
                 af[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * X6T_APLANE + i * 32 * X6_PITCH);
                 bf[i][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * X6_PLANE + i * 32 * X6_PITCH);
             }
+        // keep the twelve fragment reads together in front of the MFMAs (one exposed LDS latency per step instead of the
+        // three the scheduler otherwise creates by interleaving read groups with the first MFMAs), and the LDS stores of
+        // the prefetched operands behind them
+        __builtin_amdgcn_sched_barrier(0);
 #define IGN_X6(pa_, pb_)                                                                                   \
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[0][pb_], acc[0][0], 0, 0, 0);   \
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[1][pb_], acc[0][1], 0, 0, 0);   \
@@ -170,6 +174,7 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[1][pb_], acc[1][1], 0, 0, 0);
         IGN_X6(2, 0) IGN_X6(0, 2) IGN_X6(1, 1) IGN_X6(1, 0) IGN_X6(0, 1) IGN_X6(0, 0)
 #undef IGN_X6
+        __builtin_amdgcn_sched_barrier(0);
         // step + 1 goes to LDS from the OTHER register set (loaded during step - 1)
         if (odd) bstore((step + 1) & 1, rb00, rb01, rb02);
         else bstore((step + 1) & 1, rb10, rb11, rb12);
@@ -368,20 +373,31 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Ar
                 const __bf16* base = P + pl * PPLANE + (16 * s + row_lo) * WG_PITCH + acol;
                 af[pl] = lds_tr8(base, base + 4 * WG_PITCH);
             }
+            // software pipeline over the taps: the transposed reads of tap j+1 are in flight while tap j's six MFMAs run
+            bf16x8 bf[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const __bf16* base = Q + pl * QPLANE + (16 * s + row_lo) * WG_PITCH + bcol;
+                bf[0][pl] = lds_tr8(base, base + 4 * WG_PITCH);
+            }
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
-                bf16x8 bf[3];
+                if (j + 1 < KT) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    const __bf16* base = Q + pl * QPLANE + (16 * s + row_lo + j) * WG_PITCH + bcol;
-                    bf[pl] = lds_tr8(base, base + 4 * WG_PITCH);
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const __bf16* base = Q + pl * QPLANE + (16 * s + row_lo + j + 1) * WG_PITCH + bcol;
+                        bf[(j + 1) & 1][pl] = lds_tr8(base, base + 4 * WG_PITCH);
+                    }
                 }
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8(&b)[3] = bf[j & 1];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[0], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (u + 1 < u_end) lstore(buf ^ 1);
