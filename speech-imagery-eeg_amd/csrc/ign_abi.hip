@@ -230,10 +230,11 @@ static int plan_bwd(int B, int C, int T, int K, int L, int Tw, BwdPlan* p) {
     p->xs_len = (p->cpk * JJ + tc + 3) & ~3;
     p->lds = ((size_t)p->xs_len + (size_t)p->kb * tc + 8 * (size_t)p->kb) * 4;
     if (p->lds > 64 * 1024) return IGN_E_TOOBIG;
-    // batch slices: a few rows per block.  Many small blocks (thousands) keep the last scheduling round of the
-    // 256 CUs short -- with ~2000 blocks of 2-5 waves a third of the launch was tail (profiles/r1a) -- while 4 rows
-    // still amortise the per-block weight load / partial store.  Partials: nbs*K*C*L floats (<= 80 MB here).
-    int nbs = (B + 3) / 4;
+    // batch slices: two rows per block.  Many small blocks keep the last scheduling round of the 256 CUs short -- with
+    // ~2000 blocks of 2-5 waves a third of the launch was tail (profiles/r1a); rows per block 4 -> 2 -> 1 measured
+    // 5.60 -> 5.45 -> 5.35 ms over the four groups (L=500 reaches the 24.4 T elements/s issue ceiling) against a partial
+    // buffer that doubles each time.  Partials: nbs*K*C*L floats, capped at 256 MB.
+    int nbs = (B + 1) / 2;
     while (nbs > 1 && (size_t)nbs * K * C * L * 4 > ((size_t)256 << 20)) nbs = (nbs + 1) / 2;
     p->nbs = std::max(1, std::min(nbs, B));
     return 0;
