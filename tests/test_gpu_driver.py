@@ -102,3 +102,31 @@ def test_run_uea_sh_launcher(tmp_path):
     assert "accuracy:" in r.stdout
     ck = work / "checkpoints" / "InterpGN" / "BasicMotions"
     assert any("checkpoint.pth" in fs for _, _, fs in os.walk(ck)), r.stdout[-1000:]
+
+
+def test_harness_accumulation_and_clipping_on_the_flat_path(tmp_path, monkeypatch):
+    """Gradient accumulation (gradients stay per-parameter tensors between backward passes, gathered once per optimizer
+    step) and clipping (acts on the gathered flat-buffer views) through the GPU harness: equal to the same run on torch's
+    own Adam / per-tensor gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import speech_imagery_eeg_amd  # noqa
+    import run
+    from exp import experiment_classification as ec
+    _write_bm(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    finals = {}
+    for flat in (True, False):
+        a = _args(str(tmp_path), "InterpGN")
+        a.gradient_accumulation_steps, a.gradient_clip, a.train_epochs, a.min_epochs = 2, 0.5, 2, 10
+        run.set_seed(0)
+        if not flat:           # reference-style optimizer on the same HIP models
+            monkeypatch.setattr(ec, "FlatAdam", lambda bucket, lr: torch.optim.Adam(bucket.params, lr=lr))
+        e = ec.Experiment(a)
+        e.train()
+        finals[flat] = {k: v.detach().float().cpu().clone() for k, v in e.model.state_dict().items()}
+        monkeypatch.undo()
+        monkeypatch.chdir(tmp_path)
+    for k, v in finals[True].items():
+        w = finals[False][k]
+        assert float((v - w).abs().max()) <= 2e-4 * max(1.0, float(w.abs().max())), k
