@@ -105,7 +105,7 @@ def main():
                     "GEMMs on the fp32-MFMA kernels instead of the split-bf16 ones (0 = skip)")
     ap.add_argument("--iso-steps", type=int, default=8, help="steps of the serial (one-stream) pass that measures isolated "
                     "kernel durations for the roofline object")
-    ap.add_argument("--cpu-sample", type=int, default=4, help="samples for the CPU baseline step (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=12, help="samples for the CPU baseline step (0 = skip)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step (fwd + loss + bwd + Adam) as one captured hipGraph (single GPU; pays off in "
                          "launch-bound regimes such as --batch 32, the UEA setting of run_uea.sh)")
