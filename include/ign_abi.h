@@ -198,12 +198,14 @@ int ign_clconv_dgrad(const float* dyp, const float* wt_dgrad, const float* y_in,
  * gfx950 executes fp32-input MFMA at the fp32 vector rate; here every fp32 operand is split exactly into three bf16 terms
  * and the six partial products of weight >= 2^-16 are accumulated in fp32 (v_mfma_f32_32x32x16_bf16): 2.7x the fp32-MFMA
  * throughput, error vs float64 at the level of fp32 accumulation (tests/test_gpu_fcn.py).  The weights arrive pre-split:
- * ign_clconv_pack_weights_x3 writes wt3_fwd (3, Co, k*Cip) and (if not NULL) wt3_dgrad (3, Ci, k*Cop) as tap-major bf16
- * planes, Cip = ign_clconv_kpad(Ci), Cop = ign_clconv_kpad(Co) (zero in the padded channels).  Activations stay fp32 in HBM
+ * ign_clconv_pack_weights_x3 writes wt3_fwd (ign_clconv_x3_elems(Co, Ci, k) bf16) and, if not NULL, wt3_dgrad
+ * (ign_clconv_x3_elems(Ci, Co, k) bf16) in step-block-major order: the 3 planes x 128 rows x 16 channels that one (n-tile,
+ * 16-channel chunk, tap) step of the kernel consumes are one contiguous 12 KB block (zero in padded rows / channels).  Activations stay fp32 in HBM
  * and are split while they are staged into LDS -- once per (128 + k - 1)-row span and 16-channel chunk, shared by all k taps.
  * The x6 kernels tile every sample separately: stat_part has ign_clconv_x6_mtiles(B, Tout) [fwd] resp. (B, Tin) [dgrad]
  * rows.  k <= 16.                                                                                                       */
 int ign_clconv_kpad(int C);                          /* channels rounded up to 16 */
+long long ign_clconv_x3_elems(int rows, int chans, int k);   /* bf16 elements of a packed set: fwd (Co, Ci, k), dgrad (Ci, Co, k) */
 long long ign_clconv_x6_mtiles(int B, int rows);     /* rows of stat_part for the x6 kernels: B * ceil(rows / 128) */
 int ign_clconv_pack_weights_x3(const float* w_oik, void* wt3_fwd, void* wt3_dgrad, int Co, int Ci, int k, void* stream);
 int ign_clconv_fwd_x6(const float* x, const void* wt3_fwd, const float* bias, const float* pro_a, const float* pro_b,

@@ -16,6 +16,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int X6_PITCH = KC + 8;             // bf16 per staged row: 48 B, 12*i mod 64 dwords is conflict-free for b128 reads
 constexpr int X6_PLANE = TM * X6_PITCH;      // bf16 per plane per stage
+constexpr int X6_BLOCK = 3 * TN * KC;        // bf16 per packed weight block (one step of one n-tile): 3 planes x 128 rows x 16 k
 
 __device__ __forceinline__ void split3(float v, __bf16& x0, __bf16& x1, __bf16& x2) {
     x0 = (__bf16)v;
@@ -63,8 +64,12 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
 
     const float* abase = a.A + (long long)bi * ca.sample_pitch;
     const int brw = tid >> 1, bh = tid & 1;
-    const unsigned short* bsrc = a.B3 + (size_t)min(n0 + brw, a.N - 1) * a.Kp + 8 * bh;
-    const size_t bplane = (size_t)a.N * a.Kp;
+    // weights are packed step-block-major (ign_clconv_pack_weights_x3): the 3 planes x 128 rows x 16 k of one (n-tile, chunk,
+    // tap) step are ONE contiguous 12 KB block, so a wave's 16-byte loads cover 1 KB of consecutive addresses (the row-major
+    // layout made every 32-byte row piece pull its own 128-byte line from L2: 4x the traffic, and the issue of the three
+    // loads alone took ~1000 cycles per step)
+    const unsigned short* bsrc = a.B3 + (size_t)nt * (size_t)(ca.cp / KC) * ca.k * X6_BLOCK + (size_t)brw * KC + 8 * bh;
+    constexpr size_t bplane = (size_t)TN * KC;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -118,12 +123,11 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
             }
         }
     };
-    // step index -> offset of its (tap, chunk) block in a weight row; steps past the end re-read the last block (the loads
-    // stay unconditional so that the compiler's vmcnt bookkeeping is exact on every path)
+    // step index -> offset of its block; steps past the end re-read the last block (the loads stay unconditional so that
+    // the compiler's vmcnt bookkeeping is exact on every path)
     auto boff = [&](int st) {
         st = min(st, nstep - 1);
-        const int cc = st / ca.k, j = st - cc * ca.k;
-        return (size_t)j * ca.cp + cc * KC;
+        return (size_t)st * X6_BLOCK;            // step = chunk * k + tap
     };
     auto bstore = [&](int buf, const uint4& r0, const uint4& r1, const uint4& r2) {
         __bf16* st = Bbuf + buf * X6T_BBUF + brw * X6_PITCH + 8 * bh;
@@ -195,38 +199,37 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
     nt_epilogue<EPI>(a, acc, reinterpret_cast<float*>(smem16), mt, m0, n0, bi * ca.trows + min(ca.trows, t0 + TM));
 }
 
-// Tap-major planes for the kernel above: Wt3[p][co][j*Cip + ci], Wd3[p][ci][jj*Cop + co] (zero in the padded channels)
+// Step-block-major planes for the kernel above: block (n-tile, chunk cc, tap j) = [plane][row 0..127][16 channels of chunk cc]
+// of tap j, contiguous; rows past N and channels past C are zero.
+//   forward: rows = co, value W[co][ci][j];   data gradient: rows = ci, channels = co, value W[co][ci][k-1-jj].
 __global__ void __launch_bounds__(256) pack_weights_x3t_kernel(const float* __restrict__ w, unsigned short* __restrict__ wt3,
                                                                unsigned short* __restrict__ wd3, int Co, int Ci, int k, int Cip,
                                                                int Cop) {
-    const long long nf = (long long)Co * k * Cip, nd = wd3 ? (long long)Ci * k * Cop : 0;
+    const long long nf = (long long)((Co + TN - 1) / TN) * (Cip / KC) * k * (TN * KC);        // elements per plane set / 3
+    const long long nd = wd3 ? (long long)((Ci + TN - 1) / TN) * (Cop / KC) * k * (TN * KC) : 0;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool fwd = i < nf;
+    if (!fwd && i >= nf + nd) return;
+    const long long e = fwd ? i : i - nf;
+    // e = ((nt * ncc + cc) * k + j) * (128*16) + row * 16 + q
+    const int q = (int)(e % KC);
+    long long t = e / KC;
+    const int row = (int)(t % TN);
+    t /= TN;
+    const int j = (int)(t % k);
+    t /= k;
+    const int ncc = (fwd ? Cip : Cop) / KC;
+    const int cc = (int)(t % ncc);
+    const int nt = (int)(t / ncc);
+    const int n = nt * TN + row, c = cc * KC + q;
     float v = 0.f;
-    __bf16* dst;
-    long long plane;
-    if (i < nf) {
-        const int ci = (int)(i % Cip);
-        const long long t = i / Cip;
-        const int j = (int)(t % k);
-        const long long co = t / k;
-        if (ci < Ci) v = w[(co * Ci + ci) * k + j];
-        dst = reinterpret_cast<__bf16*>(wt3) + i;
-        plane = nf;
-    } else if (i < nf + nd) {
-        const long long e = i - nf;
-        const int co = (int)(e % Cop);
-        const long long t = e / Cop;
-        const int jj = (int)(t % k);
-        const long long ci = t / k;
-        if (co < Co) v = w[((long long)co * Ci + ci) * k + (k - 1 - jj)];
-        dst = reinterpret_cast<__bf16*>(wd3) + e;
-        plane = nd;
-    } else {
-        return;
-    }
+    if (fwd) { if (n < Co && c < Ci) v = w[((long long)n * Ci + c) * k + j]; }
+    else     { if (n < Ci && c < Co) v = w[((long long)c * Ci + n) * k + (k - 1 - j)]; }
     __bf16 x0, x1, x2;
     split3(v, x0, x1, x2);
-    dst[0] = x0; dst[plane] = x1; dst[2 * plane] = x2;
+    const long long blk = ((long long)(nt * ncc + cc) * k + j) * X6_BLOCK + (long long)row * KC + q;
+    __bf16* dst = reinterpret_cast<__bf16*>(fwd ? wt3 : wd3) + blk;
+    dst[0] = x0; dst[TN * KC] = x1; dst[2 * TN * KC] = x2;
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient, split bf16
@@ -444,6 +447,10 @@ int ign_clconv_launch_x6t(const ConvX6Args& a, int epi, int V, bool pro, hipStre
 }
 
 extern "C" int ign_clconv_kpad(int C) { return (C + 15) / 16 * 16; }
+// bf16 elements of a packed weight set with `rows` GEMM rows (output channels) and `chans` reduction channels
+extern "C" long long ign_clconv_x3_elems(int rows, int chans, int k) {
+    return 3LL * ((rows + TN - 1) / TN) * TN * k * ((chans + 15) / 16 * 16);
+}
 extern "C" long long ign_clconv_x6_mtiles(int B, int rows) { return (long long)B * ((rows + TM - 1) / TM); }
 
 extern "C" int ign_clconv_pack_weights_x3(const float* w_oik, void* wt3_fwd, void* wt3_dgrad, int Co, int Ci, int k, void* stream) {
@@ -452,7 +459,7 @@ extern "C" int ign_clconv_pack_weights_x3(const float* w_oik, void* wt3_fwd, voi
         return IGN_E_ARG;
     }
     const int Cip = ign_clconv_kpad(Ci), Cop = ign_clconv_kpad(Co);
-    const long long n = (long long)Co * k * Cip + (wt3_dgrad ? (long long)Ci * k * Cop : 0);
+    const long long n = ign_clconv_x3_elems(Co, Ci, k) / 3 + (wt3_dgrad ? ign_clconv_x3_elems(Ci, Co, k) / 3 : 0);
     hipLaunchKernelGGL(pack_weights_x3t_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oik,
                        (unsigned short*)wt3_fwd, (unsigned short*)wt3_dgrad, Co, Ci, k, Cip, Cop);
     return ign_check_launch("pack_weights_x3t_kernel");

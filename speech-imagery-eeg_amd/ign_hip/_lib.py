@@ -46,6 +46,7 @@ SIGNATURES = {
     "ign_clconv_dgrad": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ign_clconv_kpad": (ci, [ci]),
     "ign_clconv_x6_mtiles": (ll, [ci, ci]),
+    "ign_clconv_x3_elems": (ll, [ci, ci, ci]),
     "ign_clconv_pack_weights_x3": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "ign_clconv_fwd_x6": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ign_clconv_dgrad_x6": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),

@@ -83,8 +83,8 @@ class FcnBodyFn(torch.autograd.Function):
             part = torch.empty(nparts, 2, Co, **f32) if st.use_batch_stats else None
             want_wd = l > 0 and need_grad
             if x6:
-                wt = torch.empty(3, Co, k * int(L.ign_clconv_kpad(Ci)), device=dev, dtype=torch.bfloat16)
-                wd = torch.empty(3, Ci, k * int(L.ign_clconv_kpad(Co)), device=dev, dtype=torch.bfloat16) if want_wd else None
+                wt = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
+                wd = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, k)), device=dev, dtype=torch.bfloat16) if want_wd else None
                 _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt), _ptr(wd), Co, Ci, k, _stream()), "ign_clconv_pack_weights_x3")
                 _lib.check(L.ign_clconv_fwd_x6(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part), B, Tin, Ci, Co, k,
                                                _stream()), "ign_clconv_fwd_x6")

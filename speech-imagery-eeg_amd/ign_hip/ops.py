@@ -253,8 +253,8 @@ class LinearFn(torch.autograd.Function):
         w = w.contiguous()
         dev = x.device
         need_dx = ctx.needs_input_grad[0]
-        wt3 = torch.empty(3, Co, int(L.ign_clconv_kpad(Ci)), device=dev, dtype=torch.bfloat16)
-        wd3 = torch.empty(3, Ci, int(L.ign_clconv_kpad(Co)), device=dev, dtype=torch.bfloat16) if need_dx else None
+        wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, 1)), device=dev, dtype=torch.bfloat16)
+        wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, 1)), device=dev, dtype=torch.bfloat16) if need_dx else None
         _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt3), _ptr(wd3), Co, Ci, 1, _stream()), "ign_clconv_pack_weights_x3")
         y = torch.empty(M, Co, device=dev, dtype=torch.float32)
         _lib.check(L.ign_clconv_fwd_x6(_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, 1, M, Ci, Co, 1, _stream()),

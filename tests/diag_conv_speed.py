@@ -26,8 +26,8 @@ for (Tin, Ci, Co, k, pro) in [(1000, 122, 128, 8, False), (993, 128, 256, 5, Tru
     y = torch.empty(B, Tout, Co, device=dev); y6 = torch.empty_like(y)
     part = torch.empty(int(L.ign_clconv_x6_mtiles(B, Tout)), 2, Co, device=dev)
     wt = torch.empty(Co, k * Ci, device=dev); wd = torch.empty(Ci, k * Co, device=dev)
-    wt3 = torch.empty(3, Co, k * int(L.ign_clconv_kpad(Ci)), device=dev, dtype=torch.bfloat16)
-    wd3 = torch.empty(3, Ci, k * int(L.ign_clconv_kpad(Co)), device=dev, dtype=torch.bfloat16)
+    wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
+    wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, k)), device=dev, dtype=torch.bfloat16)
     _lib.check(L.ign_clconv_pack_weights(p(w), p(wt), p(wd), Co, Ci, k, s()), "pack")
     _lib.check(L.ign_clconv_pack_weights_x3(p(w), p(wt3), p(wd3), Co, Ci, k, s()), "pack3")
     flops = 2.0 * B * Tout * Co * Ci * k

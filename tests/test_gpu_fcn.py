@@ -69,7 +69,7 @@ def test_clconv_fwd_matches_conv1d(B, T, Ci, Co, k, pro, math):
         _lib.check(L.ign_clconv_pack_weights(_p(wd_), _p(wt), None, Co, Ci, k, _s()), "pack")
         _lib.check(L.ign_clconv_fwd(_p(xd), _p(wt), _p(bd), _p(pad), _p(pbd), _p(y), _p(part), B, T, Ci, Co, k, _s()), "fwd")
     else:       # split-bf16 product on the bf16 matrix cores: must be as accurate as the fp32 kernel
-        wt = torch.empty(3, Co, k * int(L.ign_clconv_kpad(Ci)), device=dev, dtype=torch.bfloat16)
+        wt = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
         _lib.check(L.ign_clconv_pack_weights_x3(_p(wd_), _p(wt), None, Co, Ci, k, _s()), "pack_x3")
         _lib.check(L.ign_clconv_fwd_x6(_p(xd), _p(wt), _p(bd), _p(pad), _p(pbd), _p(y), _p(part), B, T, Ci, Co, k, _s()), "fwd_x6")
     assert _rel(y, ref) < 3e-6, "fp32 rounding level (K <= 1280 terms)"
@@ -199,8 +199,8 @@ def test_clconv_dgrad_and_wgrad_kernels(B, Tin, Ci, Co, k, math):
         _lib.check(L.ign_clconv_dgrad(_p(dypd), _p(wdg), _p(yind), _p(ad), _p(bd), _p(md), _p(isd), _p(gin), _p(part),
                                       B, Tin, Ci, Co, k, _s()), "dgrad")
     else:
-        wt3 = torch.empty(3, Co, k * int(L.ign_clconv_kpad(Ci)), device=dev, dtype=torch.bfloat16)
-        wd3 = torch.empty(3, Ci, k * int(L.ign_clconv_kpad(Co)), device=dev, dtype=torch.bfloat16)
+        wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
+        wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, k)), device=dev, dtype=torch.bfloat16)
         _lib.check(L.ign_clconv_pack_weights_x3(_p(wd_), _p(wt3), _p(wd3), Co, Ci, k, _s()), "pack_x3")
         _lib.check(L.ign_clconv_dgrad_x6(_p(dypd), _p(wd3), _p(yind), _p(ad), _p(bd), _p(md), _p(isd), _p(gin), _p(part),
                                          B, Tin, Ci, Co, k, _s()), "dgrad_x6")
