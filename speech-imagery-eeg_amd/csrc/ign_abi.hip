@@ -220,7 +220,7 @@ static int plan_bwd(int B, int C, int T, int K, int L, int Tw, BwdPlan* p) {
     // LDS budget ~5 KB per wave keeps 7-8 waves per SIMD resident (the v_cmpx loop is latency-bound per wave):
     // stage the window axis in chunks of tc positions, equalised over ceil(Tw / tc_max) chunks.
     const size_t budget = std::max<size_t>(8 * 1024, (size_t)(p->threads / 64) * 5 * 1024);
-    const long fixed = (long)p->cpk * JJ + 8 * p->kb + 8;                      // floats besides the tc-proportional part
+    const long fixed = (long)p->cpk * JJ + 16 * p->kb + 8;                      // floats besides the tc-proportional part
     long tc_max = ((long)(budget / 4) - fixed) / (1 + p->kb);
     tc_max = std::max<long>(2 * JJ, (tc_max / (2 * JJ)) * (2 * JJ));
     const int nchunk = (int)((Tw + tc_max - 1) / tc_max);
@@ -228,7 +228,7 @@ static int plan_bwd(int B, int C, int T, int K, int L, int Tw, BwdPlan* p) {
     tc = ((tc + 2 * JJ - 1) / (2 * JJ)) * (2 * JJ);
     p->tc = tc;
     p->xs_len = (p->cpk * JJ + tc + 3) & ~3;
-    p->lds = ((size_t)p->xs_len + (size_t)p->kb * tc + 8 * (size_t)p->kb) * 4;
+    p->lds = ((size_t)p->xs_len + (size_t)p->kb * tc + 16 * (size_t)p->kb) * 4;      // x chunk, A, per-wave sums, scalars
     if (p->lds > 64 * 1024) return IGN_E_TOOBIG;
     // batch slices: two rows per block.  Many small blocks keep the last scheduling round of the 256 CUs short -- with
     // ~2000 blocks of 2-5 waves a third of the launch was tail (profiles/r1a); rows per block 4 -> 2 -> 1 measured

@@ -85,12 +85,13 @@ __device__ __forceinline__ void lds_load(float (&dst)[JJ], const float* p) {
 }
 
 template <int JJ, int DIST>
-__global__ void __launch_bounds__(512, 2) shp_bwd_kernel(const ShpBwdArgs a) {
+__global__ void __launch_bounds__(512, 8) shp_bwd_kernel(const ShpBwdArgs a) {
     static_assert(JJ % 4 == 0, "float4 LDS reads need 4-float alignment");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                        // [xs_len]      x[b,c,t0 + i]
     float* As = smem + a.xs_len;             // [kb][tc]      A[k][t0 + t]
     float* Sp = As + a.kb * a.tc;            // [kb][8]       per-wave partial sums of A (fixed order -> deterministic)
+    float* Par = Sp + a.kb * 8;              // [kb][8]       per-shapelet scalars of the current row (g, t*, 1/Z, mu, ...)
 
     const int c = blockIdx.x, bs = blockIdx.y;
     const int kbase = blockIdx.z * a.kb;
@@ -120,14 +121,32 @@ __global__ void __launch_bounds__(512, 2) shp_bwd_kernel(const ShpBwdArgs a) {
         const float* row = a.xn + ((size_t)b * a.C + c) * a.T;
         for (int t0 = 0; t0 < a.Tw; t0 += a.tc) {
             __syncthreads();                 // previous chunk fully consumed
-            for (int i = tid; i < a.xs_len; i += nthr) xs[i] = (t0 + i < a.T) ? row[t0 + i] : 0.f;
-            for (int k2 = 0; k2 < kcount; ++k2) {
-                const int k = kbase + k2;
+            // ---- staging, arranged so that global-memory latency is paid a few times per chunk, not once per element:
+            // s_memtime stamps showed 25k of a chunk's 60-135k cycles in this phase, almost all of it ~20 serialised
+            // load round trips (per shapelet: its scalars, then load -> exp -> store per window position).  Now the x
+            // chunk and the per-shapelet scalars are fetched together (one round trip), the scalars go through LDS, and
+            // the saved distances are loaded in batches of SB positions for SG shapelets before any of them is used.
+            constexpr int XB = 4;
+            for (int i0 = tid; i0 < a.xs_len; i0 += XB * nthr) {
+                float xv[XB];
+#pragma unroll
+                for (int u = 0; u < XB; ++u) {
+                    const int i = i0 + u * nthr;
+                    xv[u] = (i < a.xs_len && t0 + i < a.T) ? row[t0 + i] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < XB; ++u) {
+                    const int i = i0 + u * nthr;
+                    if (i < a.xs_len) xs[i] = xv[u];
+                }
+            }
+            if (tid < kcount) {
+                const int k = kbase + tid;
                 const size_t sidx = ((size_t)b * a.K + k) * a.C + c;
                 const size_t col = (size_t)b * a.ld + a.col0 + (size_t)k * a.C + c;
                 const float gv = a.g[col];
                 const int ts = a.tstar[sidx];
-                const float invZ = 1.f / a.zmu[2 * sidx];
+                const float z = a.zmu[2 * sidx];
                 const float mu = a.zmu[2 * sidx + 1];
                 float gm = 0.f, dmin = 0.f;
                 if (a.gate == GATE_LTS) {
@@ -135,49 +154,91 @@ __global__ void __launch_bounds__(512, 2) shp_bwd_kernel(const ShpBwdArgs a) {
                     gm = -gv * P * (1.f - P);       // dP/dm = -sigma'(thr - m)
                     dmin = a.dmin[col];
                 }
-                const float* drow = a.d + (((size_t)b * a.C + c) * a.K + k) * a.Tw;
+                float* pr = Par + tid * 8;
+                pr[0] = gv; pr[1] = __int_as_float(ts); pr[2] = 1.f / z; pr[3] = mu; pr[4] = gm; pr[5] = dmin;
+                pr[6] = (DIST >= DIST_COS) ? a.wnorm[(size_t)k * a.C + c] : 0.f;
+            }
+            __syncthreads();
+            {
+                constexpr int SG = 5, SB = 2;            // shapelets x window positions fetched together (10 loads in flight)
                 const float* xst = (DIST >= DIST_COS) ? a.xstat + ((size_t)b * a.C + c) * a.Tw : nullptr;
-                const float wn = (DIST >= DIST_COS) ? a.wnorm[(size_t)k * a.C + c] : 0.f;
-                float* Ak = As + k2 * a.tc;
-                float part = 0.f;
-                for (int tt = tid; tt < a.tc; tt += nthr) {
-                    const int t = t0 + tt;
-                    float A = 0.f;
-                    if (t < a.Tw) {
-                        const float dv = drow[t];
-                        float dldd;
-                        if (a.gate == GATE_RBF) {
-                            const float u = a.eps * dv;
-                            const float p = __expf(-(u * u));
-                            const float e = __expf(p);
-                            const float coef = gv * ((t == ts ? 1.f : 0.f) + e * invZ * (p - mu));
-                            dldd = coef * (-two_eps2 * dv * p);
-                        } else {
-                            const float s = __expf(dmin - dv) * invZ;
-                            dldd = gm * ((t == ts ? 1.f : 0.f) + s * (mu - dv));
+                const float* dbase = a.d + (((size_t)b * a.C + c) * a.K + kbase) * a.Tw;
+                for (int kg = 0; kg < kcount; kg += SG) {
+                    float part[SG];
+#pragma unroll
+                    for (int q = 0; q < SG; ++q) part[q] = 0.f;
+                    for (int tb = tid; tb < a.tc; tb += SB * nthr) {
+                        float dv[SG][SB], xsv[SB];
+#pragma unroll
+                        for (int q = 0; q < SG; ++q)
+#pragma unroll
+                            for (int u = 0; u < SB; ++u) {
+                                const int tt = tb + u * nthr, t = t0 + tt;
+                                dv[q][u] = (kg + q < kcount && tt < a.tc && t < a.Tw) ? dbase[(size_t)(kg + q) * a.Tw + t] : 0.f;
+                            }
+                        if (DIST >= DIST_COS) {
+#pragma unroll
+                            for (int u = 0; u < SB; ++u) {
+                                const int tt = tb + u * nthr, t = t0 + tt;
+                                xsv[u] = (tt < a.tc && t < a.Tw) ? xst[t] : 1.f;
+                            }
                         }
-                        if (DIST == DIST_L1) {
-                            A = -dldd * a.invL;
-                            part += A;
-                        } else if (DIST == DIST_MSE) {
-                            A = -2.f * dldd * a.invL;
-                        } else if (DIST == DIST_COS) {
-                            // d = 1 - <x,w>/(max(|x|,e) max(|w|,e)):  dd/dw_j = -x_j/den + cos * w_j / |w|^2
-                            A = -dldd / (fmaxf(xst[t], 1e-8f) * fmaxf(wn, 1e-8f));
-                            if (wn >= 1e-8f) part += dldd * (1.f - dv) / (wn * wn);
-                        } else {
-                            // d = 1 - <x,wc>/(sx sw + e):  dd/dwc_j = -x_j/den + rho * sx * wc_j / (sw den)
-                            const float den = xst[t] * wn + 1e-8f;
-                            A = -dldd / den;
-                            if (wn > 0.f) part += dldd * (1.f - dv) * xst[t] / (wn * den);
+#pragma unroll
+                        for (int q = 0; q < SG; ++q) {
+                            if (kg + q >= kcount) break;
+                            const float* pr = Par + (kg + q) * 8;
+                            const float gv = pr[0], invZ = pr[2], mu = pr[3], gm = pr[4], dmin = pr[5], wn = pr[6];
+                            const int ts = __float_as_int(pr[1]);
+                            float* Ak = As + (kg + q) * a.tc;
+#pragma unroll
+                            for (int u = 0; u < SB; ++u) {
+                                const int tt = tb + u * nthr, t = t0 + tt;
+                                if (tt >= a.tc) break;
+                                float A = 0.f;
+                                if (t < a.Tw) {
+                                    const float d1 = dv[q][u];
+                                    float dldd;
+                                    if (a.gate == GATE_RBF) {
+                                        const float uu = a.eps * d1;
+                                        const float pp = __expf(-(uu * uu));
+                                        const float e = __expf(pp);
+                                        const float coef = gv * ((t == ts ? 1.f : 0.f) + e * invZ * (pp - mu));
+                                        dldd = coef * (-two_eps2 * d1 * pp);
+                                    } else {
+                                        const float sft = __expf(dmin - d1) * invZ;
+                                        dldd = gm * ((t == ts ? 1.f : 0.f) + sft * (mu - d1));
+                                    }
+                                    if (DIST == DIST_L1) {
+                                        A = -dldd * a.invL;
+                                        part[q] += A;
+                                    } else if (DIST == DIST_MSE) {
+                                        A = -2.f * dldd * a.invL;
+                                    } else if (DIST == DIST_COS) {
+                                        // d = 1 - <x,w>/(max(|x|,e) max(|w|,e)):  dd/dw_j = -x_j/den + cos * w_j / |w|^2
+                                        A = -dldd / (fmaxf(xsv[u], 1e-8f) * fmaxf(wn, 1e-8f));
+                                        if (wn >= 1e-8f) part[q] += dldd * (1.f - d1) / (wn * wn);
+                                    } else {
+                                        // d = 1 - <x,wc>/(sx sw + e):  dd/dwc_j = -x_j/den + rho * sx * wc_j / (sw den)
+                                        const float den = xsv[u] * wn + 1e-8f;
+                                        A = -dldd / den;
+                                        if (wn > 0.f) part[q] += dldd * (1.f - d1) * xsv[u] / (wn * den);
+                                    }
+                                }
+                                Ak[tt] = A;
+                                __builtin_amdgcn_sched_barrier(0);   // one element at a time: keeps the register budget of the main loop
+                            }
                         }
                     }
-                    Ak[tt] = A;
-                }
-                if (DIST != DIST_MSE) {
+                    if (DIST != DIST_MSE) {
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-                    if (lane == 0) Sp[k2 * 8 + wave] = part;
+                        for (int q = 0; q < SG; ++q) {
+                            if (kg + q >= kcount) break;
+                            float pq = part[q];
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) pq += __shfl_xor(pq, o, 64);
+                            if (lane == 0) Sp[(kg + q) * 8 + wave] = pq;
+                        }
+                    }
                 }
             }
             __syncthreads();
