@@ -270,7 +270,15 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // index in (Co, k, Ci) order: coalesced reads
     if (i >= n) return;
     float s = 0.f;
-    for (int p = 0; p < nsplit; ++p) s += part[(long long)p * n + i];
+    int p = 0;
+    for (; p + 8 <= nsplit; p += 8) {            // 8 loads in flight, summed in ascending order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(long long)(p + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < nsplit; ++p) s += part[(long long)p * n + i];
     const int ci = (int)(i % Ci);
     const long long t = i / Ci;
     const int j = (int)(t % k);

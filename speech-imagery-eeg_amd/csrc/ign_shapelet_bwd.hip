@@ -50,9 +50,39 @@ __global__ void __launch_bounds__(256) reduce_parts_sliced_kernel(const float* _
     }
 }
 
+// Mid-size case (16 <= nparts <= 128, the shapelet backward's batch slices): 64 outputs x 4 slices of the partials per
+// block; each slice is summed in ascending order with 8 loads in flight, the 4 slice sums are combined in fixed order.
+__global__ void __launch_bounds__(256) reduce_parts_x4_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                              int nparts, size_t n) {
+    __shared__ float sm[4][64];
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + o;
+    const int per = (nparts + 3) / 4;
+    const int p0 = sl * per, p1 = min(nparts, p0 + per);
+    float s = 0.f;
+    if (i < n) {
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(p + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; p < p1; ++p) s += part[(size_t)p * n + i];
+    }
+    sm[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) out[i] = ((sm[0][o] + sm[1][o]) + sm[2][o]) + sm[3][o];
+}
+
 void ign_launch_reduce_parts(const float* part, float* out, int nparts, size_t n, hipStream_t s) {
     if (nparts > 128) {
         hipLaunchKernelGGL(reduce_parts_sliced_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, part, out, nparts, n);
+        return;
+    }
+    if (nparts >= 16) {
+        hipLaunchKernelGGL(reduce_parts_x4_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, out, nparts, n);
         return;
     }
     const unsigned blocks = (unsigned)((n + 255) / 256);
