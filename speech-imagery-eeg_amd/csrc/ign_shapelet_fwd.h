@@ -16,15 +16,43 @@
 
 template <int TT> struct FwdJ { static constexpr int J = (TT <= 8) ? 8 : 4; };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave reductions on the DPP path (pure VALU): two quad permutes, row_half_mirror, row_mirror, row_bcast:15, row_bcast:31.
+// After the four in-row steps every lane of a 16-lane row holds the row's result; the two broadcast steps leave the
+// 64-lane result in the last row, i.e. in LANE 63 -- the only lane that writes the row's outputs.  `__shfl_xor` compiles
+// to ds_bpermute_b32: the 30 dependent LDS round trips per shapelet it cost were ~20 % of the epilogue (s_memtime stamps).
+#define IGN_DPP(v, ctrl, rmask, ident) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(ident)), __builtin_bit_cast(int, (float)(v)), (ctrl), (rmask), 0xf, false))
+#define IGN_DPPI(v, ctrl, rmask, ident) __builtin_amdgcn_update_dpp((int)(ident), (int)(v), (ctrl), (rmask), 0xf, false)
+constexpr int DPP_QP_XOR1 = 0xB1, DPP_QP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_BCAST15 = 0x142,
+              DPP_BCAST31 = 0x143;
+
+__device__ __forceinline__ float wave_sum_l63(float v) {
+    v += IGN_DPP(v, DPP_QP_XOR1, 0xf, 0.f);
+    v += IGN_DPP(v, DPP_QP_XOR2, 0xf, 0.f);
+    v += IGN_DPP(v, DPP_HALF_MIRROR, 0xf, 0.f);
+    v += IGN_DPP(v, DPP_MIRROR, 0xf, 0.f);
+    v += IGN_DPP(v, DPP_BCAST15, 0xa, 0.f);
+    v += IGN_DPP(v, DPP_BCAST31, 0xc, 0.f);
+    return v;                                   // valid in lane 63
 }
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+__device__ __forceinline__ float wave_min_l63(float v) {
+    v = fminf(v, IGN_DPP(v, DPP_QP_XOR1, 0xf, INFINITY));
+    v = fminf(v, IGN_DPP(v, DPP_QP_XOR2, 0xf, INFINITY));
+    v = fminf(v, IGN_DPP(v, DPP_HALF_MIRROR, 0xf, INFINITY));
+    v = fminf(v, IGN_DPP(v, DPP_MIRROR, 0xf, INFINITY));
+    v = fminf(v, IGN_DPP(v, DPP_BCAST15, 0xa, INFINITY));
+    v = fminf(v, IGN_DPP(v, DPP_BCAST31, 0xc, INFINITY));
+    return v;                                   // valid in lane 63
+}
+// arg-max with "first index wins" on ties: (best, idx) <- better of (best, idx) and the DPP partner
+#define IGN_ARGMAX_STEP(ctrl, rmask)                                                        \
+    do {                                                                                    \
+        const float ob = IGN_DPP(best, ctrl, rmask, -INFINITY);                             \
+        const int oi = IGN_DPPI(idx, ctrl, rmask, 0x7fffffff);                              \
+        if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }                 \
+    } while (0)
+__device__ __forceinline__ float wave_bcast_l63(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 template <int TT, int KT, int DIST>
@@ -252,24 +280,25 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
                 park[(5 * k + 2) * blockDim.x] = rZ; park[(5 * k + 3) * blockDim.x] = rM;
                 park[(5 * k + 4) * blockDim.x] = __int_as_float(ri);
             } else {
-                // ---- merge the 64 lanes of the row
+                // ---- merge the 64 lanes of the row (results land in lane 63)
                 float best = rb;
                 int idx = ri;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ob = __shfl_xor(best, o, 64);
-                    const int oi = __shfl_xor(idx, o, 64);
-                    if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
-                }
-                const float dmin = wave_min(rd);
+                IGN_ARGMAX_STEP(DPP_QP_XOR1, 0xf);
+                IGN_ARGMAX_STEP(DPP_QP_XOR2, 0xf);
+                IGN_ARGMAX_STEP(DPP_HALF_MIRROR, 0xf);
+                IGN_ARGMAX_STEP(DPP_MIRROR, 0xf);
+                IGN_ARGMAX_STEP(DPP_BCAST15, 0xa);
+                IGN_ARGMAX_STEP(DPP_BCAST31, 0xc);
+                float dmin = wave_min_l63(rd);
                 float Z = rZ, M = rM;
                 if (a.gate == GATE_LTS) {
+                    dmin = wave_bcast_l63(dmin);                  // every lane rescales its partial sums to the row minimum
                     const float sc = (rd < INFINITY) ? __expf(dmin - rd) : 0.f;
                     Z *= sc; M *= sc;
                 }
-                Z = wave_sum(Z);
-                M = wave_sum(M);
-                if (lane == 0 && row_ok) {
+                Z = wave_sum_l63(Z);
+                M = wave_sum_l63(M);
+                if (lane == 63 && row_ok) {
                     const int kk = k0 + k;
                     const size_t col = (size_t)b * a.ld + a.col0 + (size_t)kk * a.C + c;
                     const size_t sidx = ((size_t)b * a.K + kk) * a.C + c;
