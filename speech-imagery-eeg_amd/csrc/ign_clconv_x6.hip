@@ -18,12 +18,52 @@ constexpr int X6_PITCH = KC + 8;             // bf16 per staged row: 48 B, 12*i 
 constexpr int X6_PLANE = TM * X6_PITCH;      // bf16 per plane per stage
 constexpr int X6_BLOCK = 3 * TN * KC;        // bf16 per packed weight block (one step of one n-tile): 3 planes x 128 rows x 16 k
 
+// The same split on pairs: f32x2 -> bf16x2 is ONE v_cvt_pk_bf16_f32 and the halves come out packed, so a pair costs
+// 3 conversions + 4 unpacks + 4 subtractions (5.5 VALU per element; the scalar form above compiles to ~10).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(f32x2 v, bf16x2& x0, bf16x2& x1, bf16x2& x2) {
+    x0 = __builtin_convertvector(v, bf16x2);
+    f32x2 r = v - __builtin_convertvector(x0, f32x2);
+    x1 = __builtin_convertvector(r, bf16x2);
+    r -= __builtin_convertvector(x1, f32x2);
+    x2 = __builtin_convertvector(r, bf16x2);
+}
+// split V consecutive values and write them to three LDS planes `plane` elements apart
+template <int V>
+__device__ __forceinline__ void split3_store(const float (&t)[V], __bf16* d, int plane);
+template <>
+__device__ __forceinline__ void split3_store<1>(const float (&t)[1], __bf16* d, int plane);
 __device__ __forceinline__ void split3(float v, __bf16& x0, __bf16& x1, __bf16& x2) {
     x0 = (__bf16)v;
     float r = v - (float)x0;
     x1 = (__bf16)r;
     r -= (float)x1;
     x2 = (__bf16)r;
+}
+template <>
+__device__ __forceinline__ void split3_store<1>(const float (&t)[1], __bf16* d, int plane) {
+    __bf16 x0, x1, x2;
+    split3(t[0], x0, x1, x2);
+    d[0] = x0; d[plane] = x1; d[2 * plane] = x2;
+}
+template <>
+__device__ __forceinline__ void split3_store<2>(const float (&t)[2], __bf16* d, int plane) {
+    bf16x2 x0, x1, x2;
+    split3_pair(f32x2{t[0], t[1]}, x0, x1, x2);
+    *reinterpret_cast<bf16x2*>(d) = x0;
+    *reinterpret_cast<bf16x2*>(d + plane) = x1;
+    *reinterpret_cast<bf16x2*>(d + 2 * plane) = x2;
+}
+template <>
+__device__ __forceinline__ void split3_store<4>(const float (&t)[4], __bf16* d, int plane) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x2 a0, a1, a2, b0, b1, b2;
+    split3_pair(f32x2{t[0], t[1]}, a0, a1, a2);
+    split3_pair(f32x2{t[2], t[3]}, b0, b1, b2);
+    *reinterpret_cast<bf16x4*>(d) = __builtin_shufflevector(a0, b0, 0, 1, 2, 3);
+    *reinterpret_cast<bf16x4*>(d + plane) = __builtin_shufflevector(a1, b1, 0, 1, 2, 3);
+    *reinterpret_cast<bf16x4*>(d + 2 * plane) = __builtin_shufflevector(a2, b2, 0, 1, 2, 3);
 }
 
 // ---- split-bf16 convolution with tap reuse.  The im2col rows of 128 consecutive output positions of one sample overlap:
@@ -110,16 +150,13 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
             const int idx = tid + p * 256;
             if (idx < nvec) {
                 const int row = idx / VPR, q = idx - row * VPR;
-                __bf16 x0[V], x1[V], x2[V];
+                float tv[V];
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
-                    float t = ra[p][v];
-                    if (PRO && a_ok) t = fmaxf(fmaf(pa[v], t, pb[v]), 0.f);
-                    split3(t, x0[v], x1[v], x2[v]);
+                    tv[v] = ra[p][v];
+                    if (PRO && a_ok) tv[v] = fmaxf(fmaf(pa[v], tv[v], pb[v]), 0.f);
                 }
-                __bf16* d = st + row * X6_PITCH + q * V;
-#pragma unroll
-                for (int v = 0; v < V; ++v) { d[v] = x0[v]; d[X6T_APLANE + v] = x1[v]; d[2 * X6T_APLANE + v] = x2[v]; }
+                split3_store<V>(tv, st + row * X6_PITCH + q * V, X6T_APLANE);
             }
         }
     };
@@ -324,28 +361,18 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Ar
         __bf16* P = smem + buf * STAGE;
         __bf16* Q = P + 3 * PPLANE;
 #pragma unroll
-        for (int p = 0; p < DPASS; ++p) {
-            __bf16* d = P + (dr + 16 * p) * WG_PITCH + dc;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                __bf16 x0, x1, x2;
-                split3(rd[p][v], x0, x1, x2);
-                d[v] = x0; d[PPLANE + v] = x1; d[2 * PPLANE + v] = x2;
-            }
-        }
+        for (int p = 0; p < DPASS; ++p) split3_store<4>(rd[p], P + (dr + 16 * p) * WG_PITCH + dc, PPLANE);
 #pragma unroll
         for (int p = 0; p < XPASS; ++p) {
             const int row = (tid + p * 256) / XVPR;
             if (row < SPAN) {
-                __bf16* d = Q + row * WG_PITCH + xq;
+                float tv[VX];
 #pragma unroll
                 for (int v = 0; v < VX; ++v) {
-                    float t = rx[p][v];
-                    if (PRO && x_ok) t = fmaxf(fmaf(pa[v], t, pb[v]), 0.f);
-                    __bf16 x0, x1, x2;
-                    split3(t, x0, x1, x2);
-                    d[v] = x0; d[QPLANE + v] = x1; d[2 * QPLANE + v] = x2;
+                    tv[v] = rx[p][v];
+                    if (PRO && x_ok) tv[v] = fmaxf(fmaf(pa[v], tv[v], pb[v]), 0.f);
                 }
+                split3_store<VX>(tv, Q + row * WG_PITCH + xq, QPLANE);
             }
         }
     };
