@@ -215,7 +215,8 @@ int ign_clconv_dgrad_x6(const float* dyp, const void* wt3_dgrad, const float* y_
                         int B, int Tin, int Ci, int Co, int k, void* stream);
 /* Weight gradient on the bf16 matrix cores (same split): operands staged row-major and read with the transposing LDS read
  * ds_read_b64_tr_b16; one staged input span serves all k taps.  k in {2, 3, 5, 8} (the FCN expert's kernels), Co % 4 == 0;
- * same arguments and result as ign_clconv_wgrad.                                                                        */
+ * k = 1 (a Linear layer over the B*Tin rows; needs Ci % 4 == 0, dy_pad == 0, no prologue) runs 128 x 128 tiles instead.
+ * Same arguments and result as ign_clconv_wgrad.                                                                        */
 size_t ign_clconv_wgrad_x6_workspace_bytes(int B, int Tin, int Ci, int Co, int k);
 int ign_clconv_wgrad_x6(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
                         float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream);

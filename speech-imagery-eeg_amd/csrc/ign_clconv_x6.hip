@@ -447,6 +447,123 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Ar
     }
 }
 
+// ---- the k = 1 case (a Linear layer: dW[co][ci] = sum_m dy[m][co] * x[m][ci]) has no taps to share a staged span, so the
+// tile grows instead: 128 co x 128 ci per workgroup, wave 64 x 64 = four accumulators, units of 16 rows, 24 MFMAs per wave and
+// barrier.  Same staging (row-major, one split per element), same transposing reads, same fixed-order reduction of the splits.
+constexpr int W1_PITCH = 128 + 32;            // bf16 per staged row: 320 B; rows 0..3 of a block start 16 banks apart
+constexpr int W1_PLANE = 16 * W1_PITCH;
+constexpr int W1_STAGE = 6 * W1_PLANE;        // three dy planes + three x planes
+constexpr size_t W1_LDS_BYTES = (size_t)2 * W1_STAGE * sizeof(unsigned short);
+
+struct Wgrad1Args {
+    const float* dy; const float* x; float* part;      // dy (M, Co), x (M, Ci), part (nsplit, Co, Ci)
+    long long M;
+    int Ci, Co, nunits, nsplit, citiles, ntiles;
+};
+
+__global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    __bf16* smem = reinterpret_cast<__bf16*>(smem16);
+    // Workgroups go round-robin over the 8 XCDs: XCD x takes the row ranges (splits) = x mod 8 and runs all tiles of a split
+    // back to back, so the dy / x rows a split shares between its tiles are fetched into ONE L2, once.
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int tile = seq % a.ntiles;
+    const int split = (seq / a.ntiles) * 8 + xcd;
+    if (split >= a.nsplit) return;
+    const int cot = tile / a.citiles, cit = tile - cot * a.citiles;
+    const int co0 = cot * 128, ci0 = cit * 128;
+    const int per = (a.nunits + a.nsplit - 1) / a.nsplit;
+    const int u_begin = split * per, u_end = min(a.nunits, u_begin + per);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wco = wave & 1, wci = wave >> 1;
+
+    const int sr = tid >> 5, sc = (tid & 31) * 4;             // staging: rows sr and sr + 8, four channels from sc
+    const bool d_ok = co0 + sc < a.Co, x_ok = ci0 + sc < a.Ci;        // Co % 4 == 0, Ci % 4 == 0
+    const float* dyp = a.dy + co0 + sc;
+    const float* xp = a.x + ci0 + sc;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float rd[2][4], rx[2][4];
+    auto gload = [&](int u) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const long long m = (long long)u * 16 + sr + 8 * p;
+            if (d_ok && m < a.M) vload<4>(rd[p], dyp + m * a.Co);
+            else { rd[p][0] = rd[p][1] = rd[p][2] = rd[p][3] = 0.f; }
+            if (x_ok && m < a.M) vload<4>(rx[p], xp + m * a.Ci);
+            else { rx[p][0] = rx[p][1] = rx[p][2] = rx[p][3] = 0.f; }
+        }
+    };
+    auto lstore = [&](int buf) {
+        __bf16* P = smem + buf * W1_STAGE;
+        __bf16* Q = P + 3 * W1_PLANE;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            split3_store<4>(rd[p], P + (sr + 8 * p) * W1_PITCH + sc, W1_PLANE);
+            split3_store<4>(rx[p], Q + (sr + 8 * p) * W1_PITCH + sc, W1_PLANE);
+        }
+    };
+
+    // transposed-read coordinates as in clconv_wgrad_x6_kernel
+    const int u16 = lane & 15, q4 = u16 >> 2, p4 = u16 & 3, G1 = (lane >> 4) & 1;
+    const int roff = (8 * h + q4) * W1_PITCH + 16 * G1 + 4 * p4;
+
+    if (u_begin < u_end) {
+        gload(u_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int u = u_begin; u < u_end; ++u, buf ^= 1) {
+        if (u + 1 < u_end) gload(u + 1);
+        const __bf16* P = smem + buf * W1_STAGE + roff + wco * 64;
+        const __bf16* Q = smem + buf * W1_STAGE + 3 * W1_PLANE + roff + wci * 64;
+        bf16x8 bf[2][3], af[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                bf[j][pl] = lds_tr8(Q + pl * W1_PLANE + 32 * j, Q + pl * W1_PLANE + 32 * j + 4 * W1_PITCH);
+                af[j][pl] = lds_tr8(P + pl * W1_PLANE + 32 * j, P + pl * W1_PLANE + 32 * j + 4 * W1_PITCH);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#define IGN_W1(pa_, pb_)                                                                                   \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[0][pb_], acc[0][0], 0, 0, 0);   \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[1][pb_], acc[0][1], 0, 0, 0);   \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[0][pb_], acc[1][0], 0, 0, 0);   \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[1][pb_], acc[1][1], 0, 0, 0);
+        IGN_W1(2, 0) IGN_W1(0, 2) IGN_W1(1, 1) IGN_W1(1, 0) IGN_W1(0, 1) IGN_W1(0, 0)
+#undef IGN_W1
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 1 < u_end) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = a.part + (long long)split * a.Co * a.Ci;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = ci0 + wci * 64 + 32 * j + l31;
+        if (ci < a.Ci) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wco * 64 + 32 * i + acc_row16(r, h);
+                    if (co < a.Co) out[(long long)co * a.Ci + ci] = acc[i][j][r];
+                }
+        }
+    }
+}
+
 // dW[co][ci][j] = sum_s part[s][co][j*Ci + ci]   (s ascending: bitwise reproducible); torch (Co, Ci, k) layout
 // ------------------------------------------------------------------------------------------------ C ABI
 template <int EPI>
@@ -520,7 +637,20 @@ static int wgrad_x6_splits(int nunits, int tiles) {
     return s < 1 ? 1 : s;
 }
 
+static int wgrad_x6_k1_splits(long long M, int Ci, int Co, int* nunits, int* tiles) {
+    *nunits = (int)((M + 15) / 16);
+    *tiles = ((Co + 127) / 128) * ((Ci + 127) / 128);
+    int s = (512 + *tiles - 1) / *tiles;                      // ~2 workgroups per CU
+    const int max_s = (*nunits + 31) / 32;                    // at least 32 units per split
+    if (s > max_s) s = max_s;
+    return s < 1 ? 1 : s;
+}
+
 extern "C" size_t ign_clconv_wgrad_x6_workspace_bytes(int B, int Tin, int Ci, int Co, int k) {
+    if (k == 1 && B > 0 && Tin > 0 && Ci > 0 && Co > 0) {
+        int nunits, tiles;
+        return (size_t)wgrad_x6_k1_splits((long long)B * Tin, Ci, Co, &nunits, &tiles) * Co * Ci * sizeof(float);
+    }
     const int Tout = Tin - k + 1, ru = wgrad_x6_rows_per_unit(k);
     if (B <= 0 || Tout <= 0 || Ci <= 0 || Co <= 0 || !ru) return 0;
     const int tiles = ((Co + 63) / 64) * ((Ci + 63) / 64);
@@ -537,8 +667,34 @@ extern "C" int ign_clconv_wgrad_x6(const float* dyp, int dy_pad, const float* x,
         ign_set_error("%s: bad argument (B=%d Tin=%d Ci=%d Co=%d k=%d pad=%d)", who, B, Tin, Ci, Co, k, dy_pad);
         return IGN_E_ARG;
     }
-    if (Co % 4 || !ru) { ign_set_error("%s: needs Co %% 4 == 0 and k in {2,3,5,8} (Co=%d k=%d)", who, Co, k); return IGN_E_UNSUP; }
     hipStream_t s = (hipStream_t)stream;
+    if (k == 1) {
+        // a Linear layer: rows of all samples are one (B*Tin, C) matrix (no padding rows, no prologue)
+        if (Co % 4 || Ci % 4 || dy_pad || pro_a) {
+            ign_set_error("%s: k = 1 needs Co %% 4 == 0, Ci %% 4 == 0, no padding, no prologue (Co=%d Ci=%d)", who, Co, Ci);
+            return IGN_E_UNSUP;
+        }
+        Wgrad1Args w{};
+        w.dy = dyp; w.x = x; w.part = (float*)workspace; w.M = (long long)B * Tin; w.Ci = Ci; w.Co = Co;
+        int tiles;
+        w.nsplit = wgrad_x6_k1_splits(w.M, Ci, Co, &w.nunits, &tiles);
+        w.citiles = (Ci + 127) / 128; w.ntiles = tiles;
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_wgrad_x6_k1_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)W1_LDS_BYTES);
+            once = true;
+        }
+        {
+            IgnScopedTimer tm("clconv_wgrad", s);
+            hipLaunchKernelGGL(clconv_wgrad_x6_k1_kernel, dim3((unsigned)(tiles * ((w.nsplit + 7) / 8 * 8))), dim3(256), W1_LDS_BYTES,
+                               s, w);
+        }
+        const int rc1 = ign_check_launch("clconv_wgrad_x6_k1_kernel");
+        if (rc1) return rc1;
+        return ign_clconv_launch_wgrad_reduce((const float*)workspace, dw_oik, w.nsplit, Co, Ci, 1, s);
+    }
+    if (Co % 4 || !ru) { ign_set_error("%s: needs Co %% 4 == 0 and k in {1,2,3,5,8} (Co=%d k=%d)", who, Co, k); return IGN_E_UNSUP; }
     WgradX6Args a{};
     a.dy = dyp; a.dy_sample_pitch = (long long)(Tout + 2 * dy_pad) * Co; a.dy_row0 = dy_pad;
     a.x = x; a.x_sample_pitch = (long long)Tin * Ci; a.pro_a = pro_a; a.pro_b = pro_b;

@@ -10,6 +10,7 @@ import os
 
 DIST_L1, DIST_MSE, DIST_COS, DIST_PEARSON = 0, 1, 2, 3
 LINEAR_IMPL = os.environ.get("IGN_LINEAR", "hip")      # "torch": route ops.linear to hipBLASLt (A/B measurements)
+LINEAR_WGRAD = os.environ.get("IGN_LINEAR_WGRAD", "bf16x6")   # "f32": weight gradient of ops.linear on the fp32-MFMA TN kernel
 GATE_RBF, GATE_LTS = 0x00, 0x10
 
 
@@ -241,7 +242,8 @@ class LinearFn(torch.autograd.Function):
     IGN/layers/Transformer_EncDec.py:33-48, nn.TransformerEncoderLayer in IGN/model/eegcnn.py:219-228) on the library's own
     GEMM kernels instead of hipBLASLt: a Linear layer is the k = 1 case of the channels-last convolution, so forward and the
     input gradient run on the split-bf16 kernel (fp32 accuracy on the bf16 matrix cores, ign_clconv_fwd_x6 with the weight
-    resp. its transpose), the weight gradient on the fp32-MFMA TN kernel (ign_clconv_wgrad)."""
+    resp. its transpose), and so does the weight gradient (ign_clconv_wgrad_x6, k = 1: 128 x 128 tiles, transposing LDS reads);
+    IGN_LINEAR_WGRAD=f32 keeps it on the fp32-MFMA TN kernel (ign_clconv_wgrad)."""
 
     @staticmethod
     def forward(ctx, x, w, bias):
@@ -277,10 +279,17 @@ class LinearFn(torch.autograd.Function):
                        "ign_clconv_fwd_x6(dx)")
             dx = dx.view(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            ws = torch.empty(int(L.ign_clconv_wgrad_workspace_bytes(1, M, Ci, Co, 1)) // 4, device=g2.device, dtype=torch.float32)
             dw = torch.empty(Co, Ci, device=g2.device, dtype=torch.float32)
-            _lib.check(L.ign_clconv_wgrad(_ptr(g2), 0, _ptr(x2), None, None, _ptr(dw), _ptr(ws), 1, M, Ci, Co, 1, _stream()),
-                       "ign_clconv_wgrad")
+            if Ci % 4 == 0 and LINEAR_WGRAD == "bf16x6":
+                ws = torch.empty(int(L.ign_clconv_wgrad_x6_workspace_bytes(1, M, Ci, Co, 1)) // 4, device=g2.device,
+                                 dtype=torch.float32)
+                _lib.check(L.ign_clconv_wgrad_x6(_ptr(g2), 0, _ptr(x2), None, None, _ptr(dw), _ptr(ws), 1, M, Ci, Co, 1, _stream()),
+                           "ign_clconv_wgrad_x6")
+            else:
+                ws = torch.empty(int(L.ign_clconv_wgrad_workspace_bytes(1, M, Ci, Co, 1)) // 4, device=g2.device,
+                                 dtype=torch.float32)
+                _lib.check(L.ign_clconv_wgrad(_ptr(g2), 0, _ptr(x2), None, None, _ptr(dw), _ptr(ws), 1, M, Ci, Co, 1, _stream()),
+                           "ign_clconv_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = g2.sum(dim=0)
         return dx, dw, db

@@ -223,11 +223,14 @@ def test_eegcnn_block_matches_reference_ops_in_eval_and_train():
 
 @pytest.mark.parametrize("shape,Co,bias", [((256, 100, 512), 256, True), ((3, 77, 64), 512, True), ((5, 130), 12, False),
                                            ((2, 1000, 512), 2048, True)])
-def test_linear_on_own_gemm_kernels(shape, Co, bias):
-    """ops.linear (split-bf16 forward / input gradient, fp32-MFMA weight gradient) against float64 torch."""
+@pytest.mark.parametrize("wgrad", ["bf16x6", "f32"])
+def test_linear_on_own_gemm_kernels(shape, Co, bias, wgrad, monkeypatch):
+    """ops.linear (split-bf16 forward / input gradient; weight gradient on the split-bf16 k = 1 kernel or the fp32-MFMA TN
+    kernel) against float64 torch."""
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
     from ign_hip import ops
+    monkeypatch.setattr(ops, "LINEAR_WGRAD", wgrad)
     g = torch.Generator().manual_seed(sum(shape) + Co)
     Ci = shape[-1]
     x = torch.randn(*shape, generator=g)
