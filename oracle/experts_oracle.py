@@ -1,0 +1,103 @@
+"""CPU oracle for the remaining deep experts (ResNet, PatchTST) -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/`` may import this module (same rule as ``oracle/ign_oracle.py``).  These are FUNCTIONAL restatements: a
+state dict (the reference's key names) and an input go in, logits come out; nothing is shared with the product modules in
+``speech-imagery-eeg_amd/models``.  Pinned by ``tests/golden/resnet_{bm,odd}.npz`` and ``tests/golden/patchtst_bm.npz`` --
+outputs of the reference itself (``tests/golden/make_golden.py``) -- in ``tests/test_oracle_golden.py``.
+
+Reference lines followed (``IGN/`` = InterpretGatedNetwork/):
+  ResNet stem / blocks / head     IGN/model/ResNet.py:44-58,66-83 ; BasicBlock :6-40
+  PatchTST classification         IGN/model/PatchTST.py:165-189 ; patching IGN/layers/Embed.py:165-190
+  encoder layer / stack           IGN/layers/Transformer_EncDec.py:27-80
+  attention layer / core          IGN/layers/SelfAttention_Family.py:179-213, 56-75
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+Tensors = Dict[str, torch.Tensor]
+
+
+def _bn(p: Tensors, pre: str, h: torch.Tensor, training: bool, stats_out: Tensors | None) -> torch.Tensor:
+    """BatchNorm1d over (B, C, T): batch statistics (biased variance) when training, running statistics otherwise.  When
+    ``stats_out`` is given, the running statistics torch would hold after this call (momentum 0.1, unbiased variance) are
+    written to it."""
+    w, b = p[pre + ".weight"], p[pre + ".bias"]
+    if training:
+        mean = h.mean(dim=(0, 2))
+        var = h.var(dim=(0, 2), unbiased=False)
+        if stats_out is not None:
+            n = h.shape[0] * h.shape[2]
+            stats_out[pre + ".running_mean"] = 0.9 * p[pre + ".running_mean"] + 0.1 * mean.detach()
+            stats_out[pre + ".running_var"] = 0.9 * p[pre + ".running_var"] + 0.1 * var.detach() * n / max(n - 1, 1)
+    else:
+        mean, var = p[pre + ".running_mean"], p[pre + ".running_var"]
+    return (h - mean[None, :, None]) / torch.sqrt(var[None, :, None] + 1e-5) * w[None, :, None] + b[None, :, None]
+
+
+def resnet_logits(p: Tensors, x_btc: torch.Tensor, training: bool, stats_out: Tensors | None = None) -> torch.Tensor:
+    h = x_btc.transpose(1, 2)                                                     # channels first for conv1d
+    h = F.conv1d(h, p["conv1.weight"], None, stride=2, padding=3)
+    h = F.relu(_bn(p, "bn1", h, training, stats_out))
+    h = F.max_pool1d(h, kernel_size=3, stride=2, padding=1)
+    for name in ("layer1.0", "layer2.0", "layer3.0"):
+        skip = h
+        if name + ".shortcut.0.weight" in p:
+            skip = _bn(p, name + ".shortcut.1", F.conv1d(h, p[name + ".shortcut.0.weight"]), training, stats_out)
+        u = F.relu(_bn(p, name + ".bn1", F.conv1d(h, p[name + ".conv1.weight"], padding=1), training, stats_out))
+        u = _bn(p, name + ".bn2", F.conv1d(u, p[name + ".conv2.weight"], padding=1), training, stats_out)
+        h = F.relu(u + skip)
+    return h.mean(dim=2) @ p["fc.weight"].t() + p["fc.bias"]
+
+
+def _sincos_table(n: int, d: int, like: torch.Tensor) -> torch.Tensor:
+    pos = torch.arange(n, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * (-math.log(10000.0) / d))
+    pe = torch.zeros(n, d)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.to(like)
+
+
+def _layer_norm(p: Tensors, pre: str, h: torch.Tensor) -> torch.Tensor:
+    return F.layer_norm(h, h.shape[-1:], p[pre + ".weight"], p[pre + ".bias"], 1e-5)
+
+
+def _encoder(p: Tensors, pre: str, h: torch.Tensor, n_layers: int, n_heads: int, gelu: bool) -> torch.Tensor:
+    N, P, D = h.shape
+    E = D // n_heads
+    for i in range(n_layers):
+        lp = f"{pre}.attn_layers.{i}"
+        q = (h @ p[lp + ".attention.query_projection.weight"].t() + p[lp + ".attention.query_projection.bias"]).view(N, P, n_heads, E)
+        k = (h @ p[lp + ".attention.key_projection.weight"].t() + p[lp + ".attention.key_projection.bias"]).view(N, P, n_heads, E)
+        v = (h @ p[lp + ".attention.value_projection.weight"].t() + p[lp + ".attention.value_projection.bias"]).view(N, P, n_heads, E)
+        a = torch.softmax(torch.einsum("nlhe,nshe->nhls", q, k) / math.sqrt(E), dim=-1)
+        o = torch.einsum("nhls,nshe->nlhe", a, v).reshape(N, P, D)
+        o = o @ p[lp + ".attention.out_projection.weight"].t() + p[lp + ".attention.out_projection.bias"]
+        h = _layer_norm(p, lp + ".norm1", h + o)
+        y = h @ p[lp + ".conv1.weight"].squeeze(-1).t() + p[lp + ".conv1.bias"]
+        y = F.gelu(y) if gelu else F.relu(y)
+        y = y @ p[lp + ".conv2.weight"].squeeze(-1).t() + p[lp + ".conv2.bias"]
+        h = _layer_norm(p, lp + ".norm2", h + y)
+    return _layer_norm(p, pre + ".norm", h)
+
+
+def patchtst_logits(p: Tensors, x_btc: torch.Tensor, n_layers: int, n_heads: int, patch_len: int = 16, stride: int = 8,
+                    gelu: bool = True) -> torch.Tensor:
+    B, T, C = x_btc.shape
+    x = x_btc - x_btc.mean(dim=1, keepdim=True)
+    x = x / torch.sqrt(x.var(dim=1, keepdim=True, unbiased=False) + 1e-5)
+    x = x.transpose(1, 2)                                                         # (B, C, T)
+    x = torch.cat([x, x[:, :, -1:].expand(B, C, stride)], dim=2)                  # replicate the right edge
+    n_patch = (T + stride - patch_len) // stride + 1
+    idx = torch.arange(n_patch)[:, None] * stride + torch.arange(patch_len)[None, :]
+    patches = x[:, :, idx].reshape(B * C, n_patch, patch_len)
+    w = p["patch_embedding.value_embedding.weight"]
+    h = patches @ w.t() + _sincos_table(n_patch, w.shape[0], w)[None]
+    h = _encoder(p, "encoder", h, n_layers, n_heads, gelu)                        # (B*C, P, D)
+    flat = h.view(B, C, n_patch, -1).transpose(2, 3).reshape(B, -1)               # (B, C*D*P)
+    return flat @ p["projection.weight"].t() + p["projection.bias"]

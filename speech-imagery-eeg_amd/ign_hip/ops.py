@@ -305,6 +305,67 @@ def linear(x, w, bias=None):
     return LinearFn.apply(x, w, bias)
 
 
+class ConvCLFn(torch.autograd.Function):
+    """Valid, stride-1 Conv1d on a CHANNELS-LAST tensor: x (B, Tin, Ci), w (Co, Ci, k) -> y (B, Tin-k+1, Co).
+
+    The general-purpose door to the implicit-GEMM kernels of the FCN expert (csrc/ign_clconv_x6.hip) for the other deep
+    experts and embeddings (IGN/model/ResNet.py:11-22,46; IGN/layers/Embed.py:32-36): padding is materialised by the caller
+    (zero rows, circular rows), a strided convolution is a stride-1 one over a space-to-depth view.  Forward and input
+    gradient run on ign_clconv_fwd_x6 (the latter on dy zero-padded by k-1 rows with the tap-reversed transposed weights),
+    the weight gradient on ign_clconv_wgrad_x6 where its tap count is instantiated (k in 1,2,3,5,8), else ign_clconv_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        L = _lib.lib()
+        _need_gpu("conv1d_cl", x, w)
+        B, Tin, Ci = x.shape
+        Co, Ci2, k = w.shape
+        if Ci2 != Ci or Tin < k or Co % 4:
+            raise _lib.IgnError(f"conv1d_cl: x {tuple(x.shape)} / w {tuple(w.shape)}: needs matching channels, Tin >= k, Co % 4 == 0")
+        x = x.contiguous()
+        w = w.contiguous()
+        dev = x.device
+        need_dx = ctx.needs_input_grad[0]
+        wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
+        wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, k)), device=dev, dtype=torch.bfloat16) if need_dx else None
+        _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt3), _ptr(wd3), Co, Ci, k, _stream()), "ign_clconv_pack_weights_x3")
+        y = torch.empty(B, Tin - k + 1, Co, device=dev, dtype=torch.float32)
+        _lib.check(L.ign_clconv_fwd_x6(_ptr(x), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, B, Tin, Ci, Co, k, _stream()),
+                   "ign_clconv_fwd_x6")
+        ctx.save_for_backward(x)
+        ctx.wd3, ctx.dims, ctx.has_bias = wd3, (B, Tin, Ci, Co, k), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        (x,) = ctx.saved_tensors
+        B, Tin, Ci, Co, k = ctx.dims
+        Tout = Tin - k + 1
+        dx = dw = db = None
+        # dy zero-padded by k-1 rows per side: the operand of the input gradient, and the layout the weight gradient reads
+        gyp = torch.nn.functional.pad(gy, (0, 0, k - 1, k - 1)) if k > 1 else gy.contiguous()
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(B, Tin, Ci, device=gy.device, dtype=torch.float32)
+            _lib.check(L.ign_clconv_fwd_x6(_ptr(gyp), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, B, Tout + 2 * (k - 1), Co, Ci, k,
+                                           _stream()), "ign_clconv_fwd_x6(dx)")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(Co, Ci, k, device=gy.device, dtype=torch.float32)
+            x6 = k in (2, 3, 5, 8) and LINEAR_WGRAD == "bf16x6"
+            wsb, fn, name = ((L.ign_clconv_wgrad_x6_workspace_bytes, L.ign_clconv_wgrad_x6, "ign_clconv_wgrad_x6") if x6 else
+                             (L.ign_clconv_wgrad_workspace_bytes, L.ign_clconv_wgrad, "ign_clconv_wgrad"))
+            ws = torch.empty(max(1, int(wsb(B, Tin, Ci, Co, k)) // 4), device=gy.device, dtype=torch.float32)
+            _lib.check(fn(_ptr(gyp), k - 1, _ptr(x), None, None, _ptr(dw), _ptr(ws), B, Tin, Ci, Co, k, _stream()), name)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = gy.sum(dim=(0, 1))
+        return dx, dw, db
+
+
+def conv1d_cl(x_btc, w_oik, bias=None):
+    """Valid stride-1 Conv1d over (B, T, C) channels-last input on the hand-written kernels (see ConvCLFn)."""
+    return ConvCLFn.apply(x_btc, w_oik, bias)
+
+
 class GiniGateFn(torch.autograd.Function):
     """(sbm_out, dnn_out) -> (mixture, eta); IGN/model/InterpGN.py:44-52."""
 

@@ -31,6 +31,10 @@ class TokenEmbedding(nn.Module):
         nn.init.kaiming_normal_(self.tokenConv.weight, mode='fan_in', nonlinearity='leaky_relu')
 
     def forward(self, x):                       # (B,T,C) -> (B,T,d)
+        if x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and self.tokenConv.out_channels % 4 == 0:
+            # circular padding = one wrapped row per side; then a valid channels-last convolution on the implicit-GEMM kernels
+            from ign_hip import ops
+            return ops.conv1d_cl(torch.cat([x[:, -1:], x, x[:, :1]], dim=1), self.tokenConv.weight)
         return self.tokenConv(x.permute(0, 2, 1)).transpose(1, 2)
 
 
@@ -61,3 +65,27 @@ class DataEmbedding(nn.Module):
         if x_mark is not None:
             out = out + self.temporal_embedding(x_mark)
         return self.dropout(out)
+
+
+class PatchEmbedding(nn.Module):
+    """Patching + value projection + positional table of PatchTST (IGN/layers/Embed.py:165-190): (B, C, T) ->
+    (B*C, patch_num, d_model).  The right edge is replicated `padding` steps, patches of `patch_len` are taken every `stride`
+    steps; the projection Linear(patch_len -> d_model, no bias) runs on ``ops.linear``."""
+
+    def __init__(self, d_model, patch_len, stride, padding, dropout):
+        super().__init__()
+        self.patch_len = patch_len
+        self.stride = stride
+        self.padding_patch_layer = nn.ReplicationPad1d((0, padding))
+        self.value_embedding = nn.Linear(patch_len, d_model, bias=False)
+        self.position_embedding = PositionalEmbedding(d_model)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        from ign_hip import ops
+        n_vars = x.shape[1]
+        x = self.padding_patch_layer(x)
+        x = x.unfold(dimension=-1, size=self.patch_len, step=self.stride)
+        x = torch.reshape(x, (x.shape[0] * x.shape[1], x.shape[2], x.shape[3]))
+        x = ops.linear(x, self.value_embedding.weight) + self.position_embedding(x)
+        return self.dropout(x), n_vars

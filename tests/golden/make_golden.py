@@ -295,7 +295,51 @@ def case_eegcnn(R):
          **sd0, **gr, **sd_after)
 
 
-CASES = dict(shapelet_modes=case_shapelet_modes, shapelet_bm=case_shapelet_bm, sbm=case_sbm, ign=case_ign,
+def case_resnet(R):
+    """ResNet deep expert (model/ResNet.py): BasicMotions shape in train mode (+ running statistics after the step, + eval
+    output), and an odd-length / odd-channel case (T=61, C=3: stem and max-pool edge handling)."""
+    import importlib
+    RN = importlib.import_module("model.ResNet")
+    for tag, (B, T, C, N) in (("bm", (8, 100, 6, 4)), ("odd", (3, 61, 3, 2))):
+        c = cfg(enc_in=C, seq_len=T, num_class=N)
+        torch.manual_seed(0)
+        m = RN.Model(c)
+        sd0 = sd_np(m)
+        g = torch.Generator().manual_seed(91 + T)
+        x = torch.randn(B, T, C, generator=g)
+        y = torch.arange(B) % N
+        m.train()
+        out = m(x)
+        loss = torch.nn.functional.cross_entropy(out, y)
+        loss.backward()
+        sd_after = {k: v for k, v in sd_np(m, "sd_after.").items() if "running" in k}
+        m.eval()
+        with torch.no_grad():
+            out_e = m(x)
+        save("resnet_" + tag, x=npy(x), y=npy(y), out=npy(out), loss=npy(loss), eval_out=npy(out_e), **sd0, **grads_np(m),
+             **sd_after)
+
+
+def case_patchtst(R):
+    """PatchTST deep expert, classification head (model/PatchTST.py): d_model 64, 4 heads, d_ff 128, 2 layers, BM shape."""
+    import importlib
+    PT = importlib.import_module("model.PatchTST")
+    B = 4
+    c = cfg()
+    torch.manual_seed(0)
+    m = PT.Model(c)
+    sd0 = {k: v for k, v in sd_np(m).items() if not k.endswith("position_embedding.pe")}      # deterministic sin/cos table
+    g = torch.Generator().manual_seed(101)
+    x = torch.randn(B, 100, 6, generator=g)
+    y = torch.arange(B) % 4
+    m.train()
+    out = m(x.clone(), None, None, None)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    save("patchtst_bm", x=npy(x), y=npy(y), out=npy(out), loss=npy(loss), **sd0, **grads_np(m))
+
+
+CASES = dict(resnet=case_resnet, patchtst=case_patchtst, shapelet_modes=case_shapelet_modes, shapelet_bm=case_shapelet_bm, sbm=case_sbm, ign=case_ign,
              ign_ch=case_ign_ch, train_steps=case_train_steps, transformer=case_transformer, eegcnn=case_eegcnn)
 
 def case_run_flags(R=None):

@@ -248,3 +248,102 @@ def test_linear_on_own_gemm_kernels(shape, Co, bias, wgrad, monkeypatch):
     assert _rel(xg.grad, xd.grad) < 3e-6 and _rel(wg.grad, wd.grad) < 1e-5
     if bias:
         assert _rel(bg.grad, bd.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- remaining deep experts
+@pytest.mark.parametrize("B,Tin,Ci,Co,k,bias", [(3, 40, 6, 64, 3, False), (2, 130, 12, 64, 4, True), (4, 27, 64, 128, 3, False),
+                                                (2, 300, 122, 512, 3, False), (1, 17, 5, 8, 7, True), (2, 64, 128, 128, 1, True),
+                                                (3, 33, 7, 12, 11, False)])
+def test_conv1d_cl_against_float64(B, Tin, Ci, Co, k, bias):
+    """ops.conv1d_cl (valid, stride 1, channels-last) forward / input gradient / weight gradient against float64 torch."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    g = torch.Generator().manual_seed(B * 1000 + Tin + Ci + Co + k)
+    x = torch.randn(B, Tin, Ci, generator=g)
+    w = torch.randn(Co, Ci, k, generator=g) / (Ci * k) ** 0.5
+    b = torch.randn(Co, generator=g) if bias else None
+    gy = torch.randn(B, Tin - k + 1, Co, generator=g)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True) if bias else None
+    yd = F.conv1d(xd.permute(0, 2, 1), wd, bd).permute(0, 2, 1)
+    (yd * gy.double()).sum().backward()
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    bg = b.to(dev).requires_grad_(True) if bias else None
+    y = ops.conv1d_cl(xg, wg, bg)
+    (y * gy.to(dev)).sum().backward()
+    assert _rel(y, yd) < 3e-6
+    assert _rel(xg.grad, xd.grad) < 3e-6 and _rel(wg.grad, wd.grad) < 1e-5
+    if bias:
+        assert _rel(bg.grad, bd.grad) < 1e-5
+
+
+def _check_expert_golden(m, g, out, loss, tol_out=2e-4, tol_grad=5e-4):
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=tol_out, atol=tol_out)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    gmax = max(float(np.abs(g[k]).max()) for k in g if k.startswith("grad."))
+    for n, p in m.named_parameters():
+        ref = g["grad." + n]
+        scale = max(float(np.abs(ref).max()), 1e-3 * gmax)
+        err = float(np.abs(p.grad.cpu().numpy() - ref).max())
+        assert err <= tol_grad * scale + 1e-8, f"{n}: {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("tag,C,T,N", [("bm", 6, 100, 4), ("odd", 3, 61, 2)])
+def test_resnet_expert_golden(tag, C, T, N):
+    """ResNet deep expert on the channels-last implicit-GEMM kernels against the reference's outputs (tests/golden/resnet_*.npz):
+    logits, loss, every parameter gradient, BatchNorm running statistics after one training forward, eval-mode logits."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models.ResNet import Model
+    g = golden("resnet_" + tag)
+    m = Model(make_cfg(enc_in=C, seq_len=T, num_class=N))
+    assert set(m.state_dict().keys()) == {k[3:] for k in g if k.startswith("sd.")}
+    m.load_state_dict(sd_from(g))
+    m.to(dev).train()
+    x, y = _t(g["x"], dev), _t(g["y"], dev)
+    out = m(x)
+    loss = F.cross_entropy(out, y)
+    loss.backward()
+    _check_expert_golden(m, g, out, loss)
+    sd = m.state_dict()
+    for k in g:
+        if k.startswith("sd_after."):
+            np.testing.assert_allclose(sd[k[9:]].cpu().numpy(), g[k], rtol=2e-4, atol=2e-5, err_msg=k)
+    m.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(m(x).cpu().numpy(), g["eval_out"], rtol=2e-4, atol=2e-4)
+
+
+def test_patchtst_expert_golden():
+    """PatchTST deep expert (patching, the shared encoder on ign_attn_* / ops.linear, streaming class head) against the
+    reference's outputs (tests/golden/patchtst_bm.npz)."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models.PatchTST import Model
+    g = golden("patchtst_bm")
+    m = Model(make_cfg())
+    want = {k[3:] for k in g if k.startswith("sd.")}
+    assert {k for k in m.state_dict() if not k.endswith("position_embedding.pe")} == want
+    m.load_state_dict(sd_from(g), strict=False)
+    m.to(dev).train()
+    x, y = _t(g["x"], dev), _t(g["y"], dev)
+    out = m(x, None, None, None)
+    loss = F.cross_entropy(out, y)
+    loss.backward()
+    _check_expert_golden(m, g, out, loss)
+
+
+def test_ign_with_resnet_expert_runs_and_matches_parts():
+    """InterpGN with dnn_type='ResNet': the mixture is the gate applied to the two experts' own outputs."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models.InterpGN import InterpGN, gini_gate
+    torch.manual_seed(0)
+    m = InterpGN(make_cfg(dnn_type="ResNet")).to(dev).train()
+    x = torch.randn(8, 100, 6, device=dev)
+    out, info = m(x, torch.ones(8, 100, device=dev), None, None)
+    ref, eta = gini_gate(info.shapelet_preds, info.dnn_preds)
+    assert _rel(out, ref) < 1e-5 and _rel(info.eta, eta) < 1e-5
+    out.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.deep_model.parameters())

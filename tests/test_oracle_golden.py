@@ -164,3 +164,55 @@ def test_three_adam_steps(tag, posw):
     for k, v in m.state_dict().items():
         # Adam divides by sqrt(v)+eps: tiny grad differences are amplified on near-zero grads
         np.testing.assert_allclose(v.numpy(), g["sd3." + k], rtol=2e-3, atol=2e-4, err_msg=k)
+
+
+# ----------------------------------------------------------------------------- remaining deep experts
+def _leaf_params(g):
+    p = {}
+    for k, v in sd_from(g).items():
+        p[k] = v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()
+    return p
+
+
+def _check_grads(p, g, tol=2e-4):
+    gmax = max(float(np.abs(g[k]).max()) for k in g if k.startswith("grad."))
+    for k in g:
+        if k.startswith("grad."):
+            ref = g[k]
+            err = float(np.abs(p[k[5:]].grad.numpy() - ref).max())
+            assert err <= tol * max(float(np.abs(ref).max()), 1e-3 * gmax) + 1e-8, f"{k}: {err:.3e}"
+
+
+@pytest.mark.parametrize("tag", ["bm", "odd"])
+def test_resnet_oracle(tag):
+    from oracle import experts_oracle as X
+    g = golden("resnet_" + tag)
+    p = _leaf_params(g)
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    after = {}
+    out = X.resnet_logits(p, x, training=True, stats_out=after)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    _check_grads(p, g)
+    for k in g:
+        if k.startswith("sd_after.") and "num_batches" not in k:
+            np.testing.assert_allclose(after[k[9:]].numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
+    with torch.no_grad():
+        q = dict(p)
+        q.update(after)
+        np.testing.assert_allclose(X.resnet_logits(q, x, training=False).numpy(), g["eval_out"], rtol=1e-4, atol=1e-5)
+
+
+def test_patchtst_oracle():
+    from oracle import experts_oracle as X
+    g = golden("patchtst_bm")
+    p = _leaf_params(g)
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    out = X.patchtst_logits(p, x, n_layers=2, n_heads=4)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    _check_grads(p, g)
