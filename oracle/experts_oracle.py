@@ -101,3 +101,50 @@ def patchtst_logits(p: Tensors, x_btc: torch.Tensor, n_layers: int, n_heads: int
     h = _encoder(p, "encoder", h, n_layers, n_heads, gelu)                        # (B*C, P, D)
     flat = h.view(B, C, n_patch, -1).transpose(2, 3).reshape(B, -1)               # (B, C*D*P)
     return flat @ p["projection.weight"].t() + p["projection.bias"]
+
+
+# ------------------------------------------------------------------------------------------------------------ TimesNet
+# Reference lines followed: IGN/model/TimesNet.py:9-18 (period detection), :21-69 (TimesBlock), :185-202 (classification);
+# IGN/layers/Conv_Blocks.py:5-33 (inception = mean of same-padded Conv2d's, kernels 1,3,..); IGN/layers/Embed.py:29-42,109-126.
+def _token_embedding(p: Tensors, pre: str, x_btc: torch.Tensor) -> torch.Tensor:
+    w = p[pre + ".value_embedding.tokenConv.weight"]                              # (d, C, 3), circular padding 1, no bias
+    xc = x_btc.transpose(1, 2)
+    xc = torch.cat([xc[:, :, -1:], xc, xc[:, :, :1]], dim=2)
+    return F.conv1d(xc, w).transpose(1, 2) + _sincos_table(x_btc.shape[1], w.shape[0], w)[None]
+
+
+def _inception(p: Tensors, pre: str, img: torch.Tensor, n_kernels: int) -> torch.Tensor:
+    acc = 0.
+    for i in range(n_kernels):
+        acc = acc + F.conv2d(img, p[f"{pre}.kernels.{i}.weight"], p[f"{pre}.kernels.{i}.bias"], padding=i)
+    return acc / n_kernels
+
+
+def timesnet_periods(h: torch.Tensor, k: int):
+    amp = torch.fft.rfft(h, dim=1).abs()
+    freq = amp.mean(0).mean(-1).clone()
+    freq[0] = 0
+    top = torch.topk(freq, k).indices
+    return [h.shape[1] // int(t) for t in top], amp.mean(-1)[:, top]
+
+
+def timesnet_logits(p: Tensors, x_btc: torch.Tensor, pad_mask: torch.Tensor, n_layers: int, top_k: int, n_kernels: int,
+                    periods_out: list | None = None) -> torch.Tensor:
+    B, T, _ = x_btc.shape
+    h = _token_embedding(p, "enc_embedding", x_btc)
+    D = h.shape[-1]
+    for i in range(n_layers):
+        periods, weight = timesnet_periods(h, top_k)
+        if periods_out is not None:
+            periods_out.append(periods)
+        branches = []
+        for per in periods:
+            length = T if T % per == 0 else (T // per + 1) * per
+            u = h if length == T else torch.cat([h, h.new_zeros(B, length - T, D)], dim=1)
+            img = u.view(B, length // per, per, D).permute(0, 3, 1, 2)
+            img = _inception(p, f"model.{i}.conv.2", F.gelu(_inception(p, f"model.{i}.conv.0", img, n_kernels)), n_kernels)
+            branches.append(img.permute(0, 2, 3, 1).reshape(B, length, D)[:, :T])
+        mix = torch.softmax(weight, dim=1)                                        # (B, k)
+        h = _layer_norm(p, "layer_norm", sum(b * mix[:, j, None, None] for j, b in enumerate(branches)) + h)
+    out = F.gelu(h) * pad_mask[:, :, None]
+    return out.reshape(B, -1) @ p["projection.weight"].t() + p["projection.bias"]

@@ -339,7 +339,39 @@ def case_patchtst(R):
     save("patchtst_bm", x=npy(x), y=npy(y), out=npy(out), loss=npy(loss), **sd0, **grads_np(m))
 
 
-CASES = dict(resnet=case_resnet, patchtst=case_patchtst, shapelet_modes=case_shapelet_modes, shapelet_bm=case_shapelet_bm, sbm=case_sbm, ign=case_ign,
+def case_timesnet(R):
+    """TimesNet deep expert, classification head (model/TimesNet.py): d_model 16, d_ff 16, 6 inception kernels, top-3 periods,
+    2 blocks, T=96.  The input is a sum of three sinusoids of distinct amplitudes (periods 24, 12, 8) plus noise, so the
+    top-k period selection is far from ties; the chosen periods are stored so a consumer can verify it took the same branch."""
+    import importlib
+    TN = importlib.import_module("model.TimesNet")
+    B, T, C = 4, 96, 6
+    c = cfg(seq_len=T, d_model=16, d_ff=16, top_k=3, num_kernels=6)
+    torch.manual_seed(0)
+    m = TN.Model(c)
+    sd0 = {k: v for k, v in sd_np(m).items() if not k.endswith("position_embedding.pe")}
+    g = torch.Generator().manual_seed(111)
+    t = torch.arange(T, dtype=torch.float32)[None, :, None]
+    x = (2.0 * torch.sin(2 * np.pi * t / 24 + torch.rand(B, 1, C, generator=g)) + 1.2 * torch.sin(2 * np.pi * t / 12)
+         + 0.7 * torch.sin(2 * np.pi * t / 8) + 0.1 * torch.randn(B, T, C, generator=g))
+    mask = torch.ones(B, T)
+    mask[2, 90:] = 0.
+    y = torch.arange(B) % 4
+    m.train()
+    periods = []
+    with torch.no_grad():
+        h = m.enc_embedding(x, None)
+        for blk in m.model:
+            periods.append(TN.FFT_for_Period(h, 3)[0])
+            h = m.layer_norm(blk(h))
+    out = m(x, mask, None, None)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    save("timesnet_t96", x=npy(x), mask=npy(mask), y=npy(y), out=npy(out), loss=npy(loss), periods=np.array(periods),
+         **sd0, **grads_np(m))
+
+
+CASES = dict(timesnet=case_timesnet, resnet=case_resnet, patchtst=case_patchtst, shapelet_modes=case_shapelet_modes, shapelet_bm=case_shapelet_bm, sbm=case_sbm, ign=case_ign,
              ign_ch=case_ign_ch, train_steps=case_train_steps, transformer=case_transformer, eegcnn=case_eegcnn)
 
 def case_run_flags(R=None):

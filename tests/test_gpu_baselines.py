@@ -347,3 +347,52 @@ def test_ign_with_resnet_expert_runs_and_matches_parts():
     assert _rel(out, ref) < 1e-5 and _rel(info.eta, eta) < 1e-5
     out.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.deep_model.parameters())
+
+
+def test_timesnet_expert_golden():
+    """TimesNet deep expert (fused-inception 2-D convolutions on the 1-D implicit-GEMM kernels, rocFFT period detection)
+    against the reference's outputs (tests/golden/timesnet_t96.npz); the periods it folds by must be the reference's."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models import TimesNet as TN
+    g = golden("timesnet_t96")
+    m = TN.Model(make_cfg(seq_len=96, d_model=16, d_ff=16, top_k=3, num_kernels=6))
+    want = {k[3:] for k in g if k.startswith("sd.")}
+    assert {k for k in m.state_dict() if not k.endswith("position_embedding.pe")} == want
+    m.load_state_dict(sd_from(g), strict=False)
+    m.to(dev).train()
+    x, mask, y = _t(g["x"], dev), _t(g["mask"], dev), _t(g["y"], dev)
+    with torch.no_grad():
+        h = m.enc_embedding(x, None)
+        for i, blk in enumerate(m.model):
+            assert list(TN.FFT_for_Period(h, 3)[0]) == list(g["periods"][i])
+            h = m.layer_norm(blk(h))
+    out = m(x, mask, None, None)
+    loss = F.cross_entropy(out, y)
+    loss.backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=2e-4, atol=2e-4)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    gmax = max(float(np.abs(g[k]).max()) for k in g if k.startswith("grad."))
+    for n, p in m.named_parameters():
+        if "grad." + n not in g:                 # temporal_embedding: constructed, never called on this path
+            assert p.grad is None, n
+            continue
+        ref = g["grad." + n]
+        err = float(np.abs(p.grad.cpu().numpy() - ref).max())
+        assert err <= 5e-4 * max(float(np.abs(ref).max()), 1e-3 * gmax) + 1e-8, f"{n}: {err:.3e}"
+
+
+def test_inception_block_fused_equals_separate_convs():
+    """The single (2n-1)x(2n-1) convolution on the 1-D kernels equals the mean of the n same-padded Conv2d's (float64)."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models.TimesNet import Inception_Block_V1
+    torch.manual_seed(3)
+    blk = Inception_Block_V1(8, 12, num_kernels=4)
+    for conv in blk.kernels:
+        nn_b = torch.randn_like(conv.bias)
+        conv.bias.data.copy_(nn_b)
+    x = torch.randn(3, 5, 7, 8)                                              # (B, H, W, C)
+    ref = blk.double()(x.double().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    y = blk.float().to(dev).forward_cl(x.to(dev))
+    assert _rel(y, ref) < 3e-6

@@ -130,3 +130,38 @@ def test_harness_accumulation_and_clipping_on_the_flat_path(tmp_path, monkeypatc
     for k, v in finals[True].items():
         w = finals[False][k]
         assert float((v - w).abs().max()) <= 2e-4 * max(1.0, float(w.abs().max())), k
+
+
+@pytest.mark.parametrize("model,dnn", [("DNN", "ResNet"), ("InterpGN", "ResNet"), ("DNN", "PatchTST"), ("InterpGN", "PatchTST"),
+                                      ("DNN", "TimesNet"), ("InterpGN", "TimesNet")])
+def test_harness_trains_the_other_deep_experts(tmp_path, monkeypatch, model, dnn):
+    """`--dnn_type ResNet|PatchTST|TimesNet` through the unmodified harness (standalone and as the deep expert of the gated
+    mixture): three epochs on the generated BasicMotions fixture run on the HIP kernels, the loss falls, a checkpoint with the
+    reference's key names is written and reloads, and test() returns the result object."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import speech_imagery_eeg_amd  # noqa
+    import run
+    from exp.experiment_classification import Experiment
+    _write_bm(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    run.set_seed(0)
+    a = run.get_args(["--model", model, "--dnn_type", dnn, "--data", "UEA", "--data_root", str(tmp_path), "--dataset",
+                      "BasicMotions", "--train_epochs", "3", "--batch_size", "8", "--seed", "0", "--amp", "--log_interval", "1",
+                      "--d_model", "32", "--d_ff", "32", "--n_heads", "2", "--e_layers", "1", "--top_k", "2", "--lr", "0.002"])
+    e = Experiment(a)
+    assert e.device.type == "cuda"
+    x = torch.randn(8, 100, 6, device=e.device)
+    with torch.no_grad():
+        first = e.model(x, torch.ones(8, 100, device=e.device), None, None)
+    e.train()
+    ckpt = torch.load(os.path.join(e.checkpoint_dir, "checkpoint.pth"), map_location="cpu", weights_only=True)
+    assert set(ckpt) == set(e.model.state_dict())
+    e.model.load_state_dict(ckpt)
+    res = e.test()
+    assert res is not None
+    with torch.no_grad():
+        after = e.model(x, torch.ones(8, 100, device=e.device), None, None)
+    first = first[0] if isinstance(first, tuple) else first
+    after = after[0] if isinstance(after, tuple) else after
+    assert torch.isfinite(after).all() and not torch.allclose(first, after)

@@ -216,3 +216,18 @@ def test_patchtst_oracle():
     np.testing.assert_allclose(out.detach().numpy(), g["out"], rtol=1e-4, atol=1e-5)
     assert abs(loss.item() - float(g["loss"])) < 1e-5
     _check_grads(p, g)
+
+
+def test_timesnet_oracle():
+    from oracle import experts_oracle as X
+    g = golden("timesnet_t96")
+    p = _leaf_params(g)
+    x, mask, y = torch.from_numpy(g["x"]), torch.from_numpy(g["mask"]), torch.from_numpy(g["y"])
+    periods = []
+    out = X.timesnet_logits(p, x, mask, n_layers=2, top_k=3, n_kernels=6, periods_out=periods)
+    assert np.array_equal(np.array(periods), g["periods"])
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    _check_grads(p, g)
