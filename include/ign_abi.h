@@ -220,6 +220,16 @@ int ign_clconv_dgrad_x6(const float* dyp, const void* wt3_dgrad, const float* y_
 size_t ign_clconv_wgrad_x6_workspace_bytes(int B, int Tin, int Ci, int Co, int k);
 int ign_clconv_wgrad_x6(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
                         float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream);
+/* The three split-bf16 GEMMs with ONE product per step: operands rounded to bf16 (round-to-nearest-even), products and sums in
+ * fp32 -- the arithmetic of the reference's default bf16-autocast mode (IGN/exp/experiment_classification.py:319; `--amp`
+ * switches it OFF).  Same packed weights (plane 0 is read), same arguments, same workspace as the *_x6 entry points.        */
+int ign_clconv_fwd_bf16(const float* x, const void* wt3_fwd, const float* bias, const float* pro_a, const float* pro_b,
+                        float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream);
+int ign_clconv_dgrad_bf16(const float* dyp, const void* wt3_dgrad, const float* y_in, const float* a_in, const float* b_in,
+                          const float* mean_in, const float* invstd_in, float* g_in, float* stat_part,
+                          int B, int Tin, int Ci, int Co, int k, void* stream);
+int ign_clconv_wgrad_bf16(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
+                          float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream);
 size_t ign_clconv_wgrad_workspace_bytes(int B, int Tin, int Ci, int Co, int k);
 int ign_clconv_wgrad(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
                      float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream);

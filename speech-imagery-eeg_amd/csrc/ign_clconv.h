@@ -146,6 +146,7 @@ struct ConvX6Args {
     int cin, cp, k;               // input channels, padded channels, taps
     int trows;                    // valid output rows per sample
     int tps;                      // m-tiles per sample
+    int nprod;                    // 6: three-way split, six partial products (fp32 accuracy); 1: operands rounded to bf16
 };
 
 inline int ign_vec_width(int c) { return (c % 4 == 0) ? 4 : (c % 2 == 0) ? 2 : 1; }

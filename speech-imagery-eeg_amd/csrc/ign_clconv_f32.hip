@@ -326,7 +326,8 @@ extern "C" int ign_clconv_pack_weights(const float* w_oik, float* wt_fwd, float*
     return ign_check_launch("pack_weights_kernel");
 }
 
-static int clconv_fwd_impl(const char* who, bool x6, const float* x, const void* wt, const float* bias, const float* pro_a,
+// x6: 0 = fp32 MFMA, 6 = split bf16 (six products), 1 = operands rounded to bf16 (one product)
+static int clconv_fwd_impl(const char* who, int x6, const float* x, const void* wt, const float* bias, const float* pro_a,
                            const float* pro_b, float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream) {
     const int Tout = Tin - k + 1;
     if (!x || !wt || !y || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || ((pro_a == nullptr) != (pro_b == nullptr))) {
@@ -348,7 +349,7 @@ static int clconv_fwd_impl(const char* who, bool x6, const float* x, const void*
         c.g = a;
         c.cin = Ci; c.cp = (Ci + 15) / 16 * 16; c.k = k; c.g.Kp = k * c.cp;
         c.sample_pitch = (long long)Tin * Ci; c.rows_in = Tin; c.trows = Tout; c.tps = (Tout + TM - 1) / TM;
-        c.g.mtiles = B * c.tps;
+        c.g.mtiles = B * c.tps; c.nprod = x6;
         return ign_clconv_launch_x6t(c, EPI_BIAS_STATS, ign_vec_width(Ci), pro_a != nullptr, (hipStream_t)stream);
     }
     return launch_nt<EPI_BIAS_STATS>(a, ign_vec_width(Ci), pro_a != nullptr, (hipStream_t)stream);
@@ -356,15 +357,20 @@ static int clconv_fwd_impl(const char* who, bool x6, const float* x, const void*
 
 extern "C" int ign_clconv_fwd(const float* x, const float* wt, const float* bias, const float* pro_a, const float* pro_b,
                               float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream) {
-    return clconv_fwd_impl("ign_clconv_fwd", false, x, wt, bias, pro_a, pro_b, y, stat_part, B, Tin, Ci, Co, k, stream);
+    return clconv_fwd_impl("ign_clconv_fwd", 0, x, wt, bias, pro_a, pro_b, y, stat_part, B, Tin, Ci, Co, k, stream);
 }
 
 extern "C" int ign_clconv_fwd_x6(const float* x, const void* wt3, const float* bias, const float* pro_a, const float* pro_b,
                                  float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream) {
-    return clconv_fwd_impl("ign_clconv_fwd_x6", true, x, wt3, bias, pro_a, pro_b, y, stat_part, B, Tin, Ci, Co, k, stream);
+    return clconv_fwd_impl("ign_clconv_fwd_x6", 6, x, wt3, bias, pro_a, pro_b, y, stat_part, B, Tin, Ci, Co, k, stream);
 }
 
-static int clconv_dgrad_impl(const char* who, bool x6, const float* dyp, const void* wt_dgrad, const float* y_in, const float* a_in,
+extern "C" int ign_clconv_fwd_bf16(const float* x, const void* wt3, const float* bias, const float* pro_a, const float* pro_b,
+                                   float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream) {
+    return clconv_fwd_impl("ign_clconv_fwd_bf16", 1, x, wt3, bias, pro_a, pro_b, y, stat_part, B, Tin, Ci, Co, k, stream);
+}
+
+static int clconv_dgrad_impl(const char* who, int x6, const float* dyp, const void* wt_dgrad, const float* y_in, const float* a_in,
                              const float* b_in, const float* mean_in, const float* invstd_in, float* g_in, float* stat_part, int B,
                              int Tin, int Ci, int Co, int k, void* stream) {
     const int Tout = Tin - k + 1;
@@ -389,7 +395,7 @@ static int clconv_dgrad_impl(const char* who, bool x6, const float* dyp, const v
         c.g = a;
         c.cin = Co; c.cp = (Co + 15) / 16 * 16; c.k = k; c.g.Kp = k * c.cp;
         c.sample_pitch = (long long)(Tout + 2 * (k - 1)) * Co; c.rows_in = Tout + 2 * (k - 1); c.trows = Tin; c.tps = (Tin + TM - 1) / TM;
-        c.g.mtiles = B * c.tps;
+        c.g.mtiles = B * c.tps; c.nprod = x6;
         return ign_clconv_launch_x6t(c, EPI_MASK_STATS, ign_vec_width(Co), false, (hipStream_t)stream);
     }
     return launch_nt<EPI_MASK_STATS>(a, ign_vec_width(Co), false, (hipStream_t)stream);
@@ -398,14 +404,21 @@ static int clconv_dgrad_impl(const char* who, bool x6, const float* dyp, const v
 extern "C" int ign_clconv_dgrad(const float* dyp, const float* wt_dgrad, const float* y_in, const float* a_in, const float* b_in,
                                 const float* mean_in, const float* invstd_in, float* g_in, float* stat_part, int B, int Tin,
                                 int Ci, int Co, int k, void* stream) {
-    return clconv_dgrad_impl("ign_clconv_dgrad", false, dyp, wt_dgrad, y_in, a_in, b_in, mean_in, invstd_in, g_in, stat_part, B, Tin,
+    return clconv_dgrad_impl("ign_clconv_dgrad", 0, dyp, wt_dgrad, y_in, a_in, b_in, mean_in, invstd_in, g_in, stat_part, B, Tin,
                              Ci, Co, k, stream);
 }
 
 extern "C" int ign_clconv_dgrad_x6(const float* dyp, const void* wt3_dgrad, const float* y_in, const float* a_in, const float* b_in,
                                    const float* mean_in, const float* invstd_in, float* g_in, float* stat_part, int B, int Tin,
                                    int Ci, int Co, int k, void* stream) {
-    return clconv_dgrad_impl("ign_clconv_dgrad_x6", true, dyp, wt3_dgrad, y_in, a_in, b_in, mean_in, invstd_in, g_in, stat_part, B,
+    return clconv_dgrad_impl("ign_clconv_dgrad_x6", 6, dyp, wt3_dgrad, y_in, a_in, b_in, mean_in, invstd_in, g_in, stat_part, B,
+                             Tin, Ci, Co, k, stream);
+}
+
+extern "C" int ign_clconv_dgrad_bf16(const float* dyp, const void* wt3_dgrad, const float* y_in, const float* a_in, const float* b_in,
+                                     const float* mean_in, const float* invstd_in, float* g_in, float* stat_part, int B, int Tin,
+                                     int Ci, int Co, int k, void* stream) {
+    return clconv_dgrad_impl("ign_clconv_dgrad_bf16", 1, dyp, wt3_dgrad, y_in, a_in, b_in, mean_in, invstd_in, g_in, stat_part, B,
                              Tin, Ci, Co, k, stream);
 }
 

@@ -66,6 +66,23 @@ __device__ __forceinline__ void split3_store<4>(const float (&t)[4], __bf16* d, 
     *reinterpret_cast<bf16x4*>(d + 2 * plane) = __builtin_shufflevector(a2, b2, 0, 1, 2, 3);
 }
 
+// NP = number of bf16 planes an operand is split into: 3 (six partial products, fp32 accuracy) or 1 (the operand rounded to
+// bf16, one product: the arithmetic of the reference's default bf16-autocast mode, fp32 accumulation).
+template <int V, int NP>
+__device__ __forceinline__ void split_store(const float (&t)[V], __bf16* d, int plane) {
+    if constexpr (NP == 3) {
+        split3_store<V>(t, d, plane);
+    } else if constexpr (V == 1) {
+        d[0] = (__bf16)t[0];
+    } else if constexpr (V == 2) {
+        *reinterpret_cast<bf16x2*>(d) = __builtin_convertvector(f32x2{t[0], t[1]}, bf16x2);
+    } else {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        const bf16x2 a = __builtin_convertvector(f32x2{t[0], t[1]}, bf16x2), b = __builtin_convertvector(f32x2{t[2], t[3]}, bf16x2);
+        *reinterpret_cast<bf16x4*>(d) = __builtin_shufflevector(a, b, 0, 1, 2, 3);
+    }
+}
+
 // ---- split-bf16 convolution with tap reuse.  The im2col rows of 128 consecutive output positions of one sample overlap:
 // together they are the (128 + k - 1)-row span of the input.  Per 16-channel chunk that span is loaded, passed through the
 // prologue and split ONCE, and all k taps run from it with the MFMA row operand shifted by one LDS row per tap -- the plain
@@ -78,7 +95,7 @@ constexpr int X6T_ABUF = 3 * X6T_APLANE;
 constexpr int X6T_BBUF = 3 * X6_PLANE;
 constexpr size_t X6T_LDS_BYTES = (size_t)2 * (X6T_ABUF + X6T_BBUF) * sizeof(unsigned short);
 
-template <int V, bool PRO, int EPI>
+template <int V, bool PRO, int EPI, int NP>
 __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca) {
     const GemmNTArgs& a = ca.g;
     constexpr int VPR = KC / V;                               // vectors per span row
@@ -124,7 +141,7 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
     bool a_ok = false;
     // Weight prefetch registers: two sets of three planes (scalars, not arrays: arrays captured by the lambdas below end
     // up in scratch).  The loads for step s+2 are issued at the top of step s, so they have two steps to land.
-    uint4 rb00, rb01, rb02, rb10, rb11, rb12;
+    uint4 rb00, rb01 = {}, rb02 = {}, rb10, rb11 = {}, rb12 = {};
     const int ncc = ca.cp / KC;
     const int nstep = ncc * ca.k;
 
@@ -156,7 +173,7 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
                     tv[v] = ra[p][v];
                     if (PRO && a_ok) tv[v] = fmaxf(fmaf(pa[v], tv[v], pb[v]), 0.f);
                 }
-                split3_store<V>(tv, st + row * X6_PITCH + q * V, X6T_APLANE);
+                split_store<V, NP>(tv, st + row * X6_PITCH + q * V, X6T_APLANE);
             }
         }
     };
@@ -169,15 +186,19 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
     auto bstore = [&](int buf, const uint4& r0, const uint4& r1, const uint4& r2) {
         __bf16* st = Bbuf + buf * X6T_BBUF + brw * X6_PITCH + 8 * bh;
         *reinterpret_cast<uint4*>(st) = r0;
-        *reinterpret_cast<uint4*>(st + X6_PLANE) = r1;
-        *reinterpret_cast<uint4*>(st + 2 * X6_PLANE) = r2;
+        if constexpr (NP == 3) {
+            *reinterpret_cast<uint4*>(st + X6_PLANE) = r1;
+            *reinterpret_cast<uint4*>(st + 2 * X6_PLANE) = r2;
+        }
     };
 #define IGN_BLOAD(r0, r1, r2, st)                                                       \
     do {                                                                                \
         const size_t off_ = boff(st);                                                   \
         r0 = *reinterpret_cast<const uint4*>(bsrc + off_);                              \
-        r1 = *reinterpret_cast<const uint4*>(bsrc + bplane + off_);                     \
-        r2 = *reinterpret_cast<const uint4*>(bsrc + 2 * bplane + off_);                 \
+        if constexpr (NP == 3) {                                                        \
+            r1 = *reinterpret_cast<const uint4*>(bsrc + bplane + off_);                 \
+            r2 = *reinterpret_cast<const uint4*>(bsrc + 2 * bplane + off_);             \
+        }                                                                               \
     } while (0)
 
     aload(0);
@@ -196,11 +217,11 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
         if (j == 0 && next_span) aload(cc + 1);             // k steps ahead of its use
         const __bf16* As = Abuf + (cc & 1) * X6T_ABUF + (wm * 64 + l31 + j) * X6_PITCH + 8 * h;
         const __bf16* Bs = Bbuf + (step & 1) * X6T_BBUF + (wn * 64 + l31) * X6_PITCH + 8 * h;
-        bf16x8 af[2][3], bf[2][3];
+        bf16x8 af[2][NP], bf[2][NP];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NP; ++pl) {
                 af[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * X6T_APLANE + i * 32 * X6_PITCH);
                 bf[i][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * X6_PLANE + i * 32 * X6_PITCH);
             }
@@ -213,7 +234,8 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[1][pb_], acc[0][1], 0, 0, 0);   \
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[0][pb_], acc[1][0], 0, 0, 0);   \
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[1][pb_], acc[1][1], 0, 0, 0);
-        IGN_X6(2, 0) IGN_X6(0, 2) IGN_X6(1, 1) IGN_X6(1, 0) IGN_X6(0, 1) IGN_X6(0, 0)
+        if constexpr (NP == 3) { IGN_X6(2, 0) IGN_X6(0, 2) IGN_X6(1, 1) IGN_X6(1, 0) IGN_X6(0, 1) }
+        IGN_X6(0, 0)
 #undef IGN_X6
         __builtin_amdgcn_sched_barrier(0);
         // step + 1 goes to LDS from the OTHER register set (loaded during step - 1)
@@ -299,7 +321,7 @@ __device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int KT, int NR, int VX, bool PRO>
+template <int KT, int NR, int VX, bool PRO, int NP>
 __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Args a) {
     constexpr int RU = 16 * NR;                     // output rows per unit
     constexpr int SPAN = RU + KT - 1;               // input rows per unit
@@ -361,7 +383,7 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Ar
         __bf16* P = smem + buf * STAGE;
         __bf16* Q = P + 3 * PPLANE;
 #pragma unroll
-        for (int p = 0; p < DPASS; ++p) split3_store<4>(rd[p], P + (dr + 16 * p) * WG_PITCH + dc, PPLANE);
+        for (int p = 0; p < DPASS; ++p) split_store<4, NP>(rd[p], P + (dr + 16 * p) * WG_PITCH + dc, PPLANE);
 #pragma unroll
         for (int p = 0; p < XPASS; ++p) {
             const int row = (tid + p * 256) / XVPR;
@@ -372,7 +394,7 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Ar
                     tv[v] = rx[p][v];
                     if (PRO && x_ok) tv[v] = fmaxf(fmaf(pa[v], tv[v], pb[v]), 0.f);
                 }
-                split3_store<VX>(tv, Q + row * WG_PITCH + xq, QPLANE);
+                split_store<VX, NP>(tv, Q + row * WG_PITCH + xq, QPLANE);
             }
         }
     };
@@ -397,16 +419,16 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Ar
         const __bf16* Q = P + 3 * PPLANE;
 #pragma unroll
         for (int s = 0; s < NR; ++s) {
-            bf16x8 af[3];
+            bf16x8 af[NP];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NP; ++pl) {
                 const __bf16* base = P + pl * PPLANE + (16 * s + row_lo) * WG_PITCH + acol;
                 af[pl] = lds_tr8(base, base + 4 * WG_PITCH);
             }
             // software pipeline over the taps: the transposed reads of tap j+1 are in flight while tap j's six MFMAs run
-            bf16x8 bf[2][3];
+            bf16x8 bf[2][NP];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NP; ++pl) {
                 const __bf16* base = Q + pl * QPLANE + (16 * s + row_lo) * WG_PITCH + bcol;
                 bf[0][pl] = lds_tr8(base, base + 4 * WG_PITCH);
             }
@@ -414,18 +436,20 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Ar
             for (int j = 0; j < KT; ++j) {
                 if (j + 1 < KT) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
+                    for (int pl = 0; pl < NP; ++pl) {
                         const __bf16* base = Q + pl * QPLANE + (16 * s + row_lo + j + 1) * WG_PITCH + bcol;
                         bf[(j + 1) & 1][pl] = lds_tr8(base, base + 4 * WG_PITCH);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const bf16x8(&b)[3] = bf[j & 1];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[1], acc[j], 0, 0, 0);
+                const bf16x8(&b)[NP] = bf[j & 1];
+                if constexpr (NP == 3) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[1], acc[j], 0, 0, 0);
+                }
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[0], acc[j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -461,6 +485,7 @@ struct Wgrad1Args {
     int Ci, Co, nunits, nsplit, citiles, ntiles;
 };
 
+template <int NP>
 __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     __bf16* smem = reinterpret_cast<__bf16*>(smem16);
@@ -508,8 +533,8 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1
         __bf16* Q = P + 3 * W1_PLANE;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            split3_store<4>(rd[p], P + (sr + 8 * p) * W1_PITCH + sc, W1_PLANE);
-            split3_store<4>(rx[p], Q + (sr + 8 * p) * W1_PITCH + sc, W1_PLANE);
+            split_store<4, NP>(rd[p], P + (sr + 8 * p) * W1_PITCH + sc, W1_PLANE);
+            split_store<4, NP>(rx[p], Q + (sr + 8 * p) * W1_PITCH + sc, W1_PLANE);
         }
     };
 
@@ -527,11 +552,11 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1
         if (u + 1 < u_end) gload(u + 1);
         const __bf16* P = smem + buf * W1_STAGE + roff + wco * 64;
         const __bf16* Q = smem + buf * W1_STAGE + 3 * W1_PLANE + roff + wci * 64;
-        bf16x8 bf[2][3], af[2][3];
+        bf16x8 bf[2][NP], af[2][NP];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NP; ++pl) {
                 bf[j][pl] = lds_tr8(Q + pl * W1_PLANE + 32 * j, Q + pl * W1_PLANE + 32 * j + 4 * W1_PITCH);
                 af[j][pl] = lds_tr8(P + pl * W1_PLANE + 32 * j, P + pl * W1_PLANE + 32 * j + 4 * W1_PITCH);
             }
@@ -541,7 +566,8 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[1][pb_], acc[0][1], 0, 0, 0);   \
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[0][pb_], acc[1][0], 0, 0, 0);   \
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[1][pb_], acc[1][1], 0, 0, 0);
-        IGN_W1(2, 0) IGN_W1(0, 2) IGN_W1(1, 1) IGN_W1(1, 0) IGN_W1(0, 1) IGN_W1(0, 0)
+        if constexpr (NP == 3) { IGN_W1(2, 0) IGN_W1(0, 2) IGN_W1(1, 1) IGN_W1(1, 0) IGN_W1(0, 1) }
+        IGN_W1(0, 0)
 #undef IGN_W1
         __builtin_amdgcn_sched_barrier(0);
         if (u + 1 < u_end) lstore(buf ^ 1);
@@ -566,18 +592,18 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1
 
 // dW[co][ci][j] = sum_s part[s][co][j*Ci + ci]   (s ascending: bitwise reproducible); torch (Co, Ci, k) layout
 // ------------------------------------------------------------------------------------------------ C ABI
-template <int EPI>
+template <int EPI, int NP>
 static int launch_x6t(const ConvX6Args& a, int V, bool pro, hipStream_t s) {
     const dim3 grid((unsigned)(a.g.mtiles * a.g.ntiles)), block(256);
 #define IGN_X6T(VV, PP)                                                                                                      \
     do {                                                                                                                     \
         static bool once = false;                                                                                            \
         if (!once) {                                                                                                         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_x6t_kernel<VV, PP, EPI>),                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_x6t_kernel<VV, PP, EPI, NP>),                     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6T_LDS_BYTES);                       \
             once = true;                                                                                                     \
         }                                                                                                                    \
-        hipLaunchKernelGGL((clconv_x6t_kernel<VV, PP, EPI>), grid, block, X6T_LDS_BYTES, s, a);                               \
+        hipLaunchKernelGGL((clconv_x6t_kernel<VV, PP, EPI, NP>), grid, block, X6T_LDS_BYTES, s, a);                           \
     } while (0)
     if (V == 4) { if (pro) IGN_X6T(4, true); else IGN_X6T(4, false); }
     else if (V == 2) { if (pro) IGN_X6T(2, true); else IGN_X6T(2, false); }
@@ -587,7 +613,9 @@ static int launch_x6t(const ConvX6Args& a, int V, bool pro, hipStream_t s) {
 }
 
 int ign_clconv_launch_x6t(const ConvX6Args& a, int epi, int V, bool pro, hipStream_t s) {
-    return epi == EPI_BIAS_STATS ? launch_x6t<EPI_BIAS_STATS>(a, V, pro, s) : launch_x6t<EPI_MASK_STATS>(a, V, pro, s);
+    if (a.nprod == 1)
+        return epi == EPI_BIAS_STATS ? launch_x6t<EPI_BIAS_STATS, 1>(a, V, pro, s) : launch_x6t<EPI_MASK_STATS, 1>(a, V, pro, s);
+    return epi == EPI_BIAS_STATS ? launch_x6t<EPI_BIAS_STATS, 3>(a, V, pro, s) : launch_x6t<EPI_MASK_STATS, 3>(a, V, pro, s);
 }
 
 extern "C" int ign_clconv_kpad(int C) { return (C + 15) / 16 * 16; }
@@ -609,18 +637,18 @@ extern "C" int ign_clconv_pack_weights_x3(const float* w_oik, void* wt3_fwd, voi
     return ign_check_launch("pack_weights_x3t_kernel");
 }
 
-template <int KT, int NR>
+template <int KT, int NR, int NP>
 static int launch_wgrad_x6(const WgradX6Args& a, int V, bool pro, dim3 grid, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 3 * ((16 * NR) + (16 * NR + KT - 1)) * WG_PITCH * sizeof(unsigned short);
 #define IGN_WG(VV, PP)                                                                                                       \
     do {                                                                                                                     \
         static bool once = false;                                                                                            \
         if (!once) {                                                                                                         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_wgrad_x6_kernel<KT, NR, VV, PP>),                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_wgrad_x6_kernel<KT, NR, VV, PP, NP>),             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
             once = true;                                                                                                     \
         }                                                                                                                    \
-        hipLaunchKernelGGL((clconv_wgrad_x6_kernel<KT, NR, VV, PP>), grid, dim3(256), lds, s, a);                             \
+        hipLaunchKernelGGL((clconv_wgrad_x6_kernel<KT, NR, VV, PP, NP>), grid, dim3(256), lds, s, a);                         \
     } while (0)
     if (V == 4) { if (pro) IGN_WG(4, true); else IGN_WG(4, false); }
     else if (V == 2) { if (pro) IGN_WG(2, true); else IGN_WG(2, false); }
@@ -658,9 +686,9 @@ extern "C" size_t ign_clconv_wgrad_x6_workspace_bytes(int B, int Tin, int Ci, in
     return (size_t)wgrad_x6_splits(nunits, tiles) * Co * k * Ci * sizeof(float);
 }
 
-extern "C" int ign_clconv_wgrad_x6(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
-                                   float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream) {
-    static const char* who = "ign_clconv_wgrad_x6";
+template <int NP>
+static int wgrad_x6_impl(const char* who, const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
+                         float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream) {
     const int Tout = Tin - k + 1, ru = wgrad_x6_rows_per_unit(k);
     if (!dyp || !x || !dw_oik || !workspace || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || dy_pad < 0 ||
         ((pro_a == nullptr) != (pro_b == nullptr))) {
@@ -681,13 +709,13 @@ extern "C" int ign_clconv_wgrad_x6(const float* dyp, int dy_pad, const float* x,
         w.citiles = (Ci + 127) / 128; w.ntiles = tiles;
         static bool once = false;
         if (!once) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_wgrad_x6_k1_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_wgrad_x6_k1_kernel<NP>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W1_LDS_BYTES);
             once = true;
         }
         {
             IgnScopedTimer tm("clconv_wgrad", s);
-            hipLaunchKernelGGL(clconv_wgrad_x6_k1_kernel, dim3((unsigned)(tiles * ((w.nsplit + 7) / 8 * 8))), dim3(256), W1_LDS_BYTES,
+            hipLaunchKernelGGL(clconv_wgrad_x6_k1_kernel<NP>, dim3((unsigned)(tiles * ((w.nsplit + 7) / 8 * 8))), dim3(256), W1_LDS_BYTES,
                                s, w);
         }
         const int rc1 = ign_check_launch("clconv_wgrad_x6_k1_kernel");
@@ -709,12 +737,24 @@ extern "C" int ign_clconv_wgrad_x6(const float* dyp, int dy_pad, const float* x,
     int rc;
     {
         IgnScopedTimer tm("clconv_wgrad", s);
-        if (k == 8) rc = launch_wgrad_x6<8, 1>(a, V, pro, grid, s);
-        else if (k == 5) rc = launch_wgrad_x6<5, 1>(a, V, pro, grid, s);
-        else if (k == 3) rc = launch_wgrad_x6<3, 2>(a, V, pro, grid, s);
-        else rc = launch_wgrad_x6<2, 2>(a, V, pro, grid, s);
+        if (k == 8) rc = launch_wgrad_x6<8, 1, NP>(a, V, pro, grid, s);
+        else if (k == 5) rc = launch_wgrad_x6<5, 1, NP>(a, V, pro, grid, s);
+        else if (k == 3) rc = launch_wgrad_x6<3, 2, NP>(a, V, pro, grid, s);
+        else rc = launch_wgrad_x6<2, 2, NP>(a, V, pro, grid, s);
     }
     if (rc) return rc;
     return ign_clconv_launch_wgrad_reduce((const float*)workspace, dw_oik, a.nsplit, Co, Ci, k, s);
 }
 
+
+extern "C" int ign_clconv_wgrad_x6(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
+                                   float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream) {
+    return wgrad_x6_impl<3>("ign_clconv_wgrad_x6", dyp, dy_pad, x, pro_a, pro_b, dw_oik, workspace, B, Tin, Ci, Co, k, stream);
+}
+
+// The same kernel with ONE product per MFMA step (operands rounded to bf16, fp32 accumulation): the arithmetic of the
+// reference's default bf16-autocast mode.  Workspace as for ign_clconv_wgrad_x6.
+extern "C" int ign_clconv_wgrad_bf16(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
+                                     float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream) {
+    return wgrad_x6_impl<1>("ign_clconv_wgrad_bf16", dyp, dy_pad, x, pro_a, pro_b, dw_oik, workspace, B, Tin, Ci, Co, k, stream);
+}

@@ -20,7 +20,9 @@ from . import _lib
 # Arithmetic of the forward / data-gradient GEMMs (the weight gradient is fp32 MFMA in both):
 #   "bf16x6": exact 3-way bf16 split of every fp32 operand, six partial products accumulated in fp32 on the bf16 matrix
 #             cores -- error vs float64 at the fp32 kernel's level (<= 3e-6 of max; tests/test_gpu_fcn.py), 1.6x its speed;
-#   "f32":    v_mfma_f32_32x32x2_f32 (runs at the fp32 VECTOR rate on gfx950).
+#   "f32":    v_mfma_f32_32x32x2_f32 (runs at the fp32 VECTOR rate on gfx950);
+#   "bf16":   operands rounded to bf16, ONE product, fp32 accumulation -- what torch.autocast(bfloat16) computes for a
+#             convolution; selected automatically inside an autocast region (the reference's default mode, `--amp` not passed).
 CONV_MATH = os.environ.get("IGN_CONV_MATH", "bf16x6")
 DEBUG = None       # set to a dict to capture the backward intermediates (tests/diag_fcn.py)
 
@@ -56,8 +58,9 @@ class FcnBodyFn(torch.autograd.Function):
     """forward(x (B,T,C), states, w1, b1, gamma1, beta1, w2, ..., beta3) -> pooled (B, C3)."""
 
     @staticmethod
-    def forward(ctx, x, states, *params):
+    def forward(ctx, x, states_math, *params):
         L = _lib.lib()
+        states, math = states_math
         if not x.is_cuda or x.dtype != torch.float32:
             raise _lib.IgnError(f"fcn_body: needs a float32 GPU tensor, got {x.dtype} on {x.device} (no CPU fallback)")
         x = x.contiguous()
@@ -66,7 +69,8 @@ class FcnBodyFn(torch.autograd.Function):
         dev = x.device
         f32 = dict(device=dev, dtype=torch.float32)
         need_grad = any(ctx.needs_input_grad[2:])
-        x6 = CONV_MATH == "bf16x6"
+        x6 = math in ("bf16x6", "bf16")
+        conv_fwd = L.ign_clconv_fwd_bf16 if math == "bf16" else L.ign_clconv_fwd_x6
         inputs, affine, wds, shapes = [x], [], [], []
         pa = pb = None
         for l in range(nl):
@@ -86,8 +90,8 @@ class FcnBodyFn(torch.autograd.Function):
                 wt = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
                 wd = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, k)), device=dev, dtype=torch.bfloat16) if want_wd else None
                 _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt), _ptr(wd), Co, Ci, k, _stream()), "ign_clconv_pack_weights_x3")
-                _lib.check(L.ign_clconv_fwd_x6(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part), B, Tin, Ci, Co, k,
-                                               _stream()), "ign_clconv_fwd_x6")
+                _lib.check(conv_fwd(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part), B, Tin, Ci, Co, k, _stream()),
+                           "ign_clconv_fwd_x6")
             else:
                 wt = torch.empty(Co, k * Ci, **f32)
                 wd = torch.empty(Ci, k * Co, **f32) if want_wd else None
@@ -113,7 +117,7 @@ class FcnBodyFn(torch.autograd.Function):
         pooled = torch.empty(B, Cl, **f32)
         _lib.check(L.ign_bn_relu_pool_fwd(_ptr(y_last), _ptr(pa), _ptr(pb), _ptr(pooled), B, Tl, Cl, _stream()),
                    "ign_bn_relu_pool_fwd")
-        ctx.saved = (inputs, affine, wds, shapes, [st.use_batch_stats for st in states], x6) if need_grad else None
+        ctx.saved = (inputs, affine, wds, shapes, [st.use_batch_stats for st in states], math) if need_grad else None
         return pooled
 
     @staticmethod
@@ -123,7 +127,8 @@ class FcnBodyFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise _lib.IgnError("fcn_body: gradient w.r.t. the input series is not implemented (inputs are data)")
         L = _lib.lib()
-        inputs, affine, wds, shapes, batch_stats, x6 = ctx.saved
+        inputs, affine, wds, shapes, batch_stats, math = ctx.saved
+        x6 = math in ("bf16x6", "bf16")
         nl = len(shapes)
         B = inputs[0].shape[0]
         dev = gpool.device
@@ -160,7 +165,7 @@ class FcnBodyFn(torch.autograd.Function):
             ws_bytes = (L.ign_clconv_wgrad_x6_workspace_bytes if wx6 else L.ign_clconv_wgrad_workspace_bytes)(B, Tin, Ci, Co, k)
             ws = torch.empty(int(ws_bytes) // 4, **f32)
             dw = torch.empty(Co, Ci, k, **f32)
-            wgrad = L.ign_clconv_wgrad_x6 if wx6 else L.ign_clconv_wgrad
+            wgrad = (L.ign_clconv_wgrad_bf16 if math == "bf16" else L.ign_clconv_wgrad_x6) if wx6 else L.ign_clconv_wgrad
             _lib.check(wgrad(_ptr(dyp), pad, _ptr(inputs[l]), _ptr(pa), _ptr(pb), _ptr(dw), _ptr(ws), B, Tin, Ci, Co, k,
                              _stream()), "ign_clconv_wgrad")
             del ws
@@ -175,7 +180,7 @@ class FcnBodyFn(torch.autograd.Function):
                 g = torch.empty(B, Tin, Ci, **f32)
                 nparts = int(L.ign_clconv_x6_mtiles(B, Tin) if x6 else L.ign_clconv_mtiles(B * Tin))
                 part = torch.empty(nparts, 2, Ci, **f32)
-                dgrad = L.ign_clconv_dgrad_x6 if x6 else L.ign_clconv_dgrad
+                dgrad = (L.ign_clconv_dgrad_bf16 if math == "bf16" else L.ign_clconv_dgrad_x6) if x6 else L.ign_clconv_dgrad
                 _lib.check(dgrad(_ptr(dyp), _ptr(wds[l]), _ptr(inputs[l]), _ptr(pa_), _ptr(pb_), _ptr(pm_), _ptr(pi_),
                                               _ptr(g), _ptr(part), B, Tin, Ci, Co, k, _stream()), "ign_clconv_dgrad")
             del dyp
@@ -183,8 +188,11 @@ class FcnBodyFn(torch.autograd.Function):
         return (None, None, *grads)
 
 
-def fcn_body(x, blocks):
-    """x (B,T,C) float32 on the GPU; blocks = [(conv1d, batchnorm1d), ...] -> pooled (B, C_last)."""
+def fcn_body(x, blocks, math=None):
+    """x (B,T,C) float32 on the GPU; blocks = [(conv1d, batchnorm1d), ...] -> pooled (B, C_last).
+    `math`: arithmetic of the GEMMs (see CONV_MATH); default = "bf16" inside an autocast region, else CONV_MATH."""
+    if math is None:
+        math = "bf16" if torch.is_autocast_enabled() else CONV_MATH
     states = [BnState(bn) for _, bn in blocks]
     params = []
     for conv, bn in blocks:
@@ -193,4 +201,4 @@ def fcn_body(x, blocks):
         if conv.stride != (1,) or conv.padding != (0,) or conv.dilation != (1,) or conv.groups != 1:
             raise _lib.IgnError("fcn_body: only stride-1, unpadded, undilated, ungrouped Conv1d is implemented")
         params += [conv.weight, conv.bias, bn.weight, bn.bias]
-    return FcnBodyFn.apply(x, states, *params)
+    return FcnBodyFn.apply(x, (states, math), *params)

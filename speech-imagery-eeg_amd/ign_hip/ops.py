@@ -237,6 +237,13 @@ def head_linear(x, w, bias=None):
     return HeadLinearFn.apply(x, w, bias)
 
 
+def _gemm(L, bf16):
+    """(forward / input-gradient GEMM, weight-gradient GEMM) entry points: the split-bf16 kernels (fp32 accuracy), or inside a
+    torch.autocast(bfloat16) region -- the reference's default mode -- the same kernels with their operands rounded to bf16 and
+    ONE product per MFMA step (what autocast computes for a matmul; accumulation and outputs stay fp32)."""
+    return (L.ign_clconv_fwd_bf16, L.ign_clconv_wgrad_bf16) if bf16 else (L.ign_clconv_fwd_x6, L.ign_clconv_wgrad_x6)
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b for the dense layers of the two encoder baselines (IGN/layers/SelfAttention_Family.py:195-211,
     IGN/layers/Transformer_EncDec.py:33-48, nn.TransformerEncoderLayer in IGN/model/eegcnn.py:219-228) on the library's own
@@ -259,7 +266,8 @@ class LinearFn(torch.autograd.Function):
         wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, 1)), device=dev, dtype=torch.bfloat16) if need_dx else None
         _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt3), _ptr(wd3), Co, Ci, 1, _stream()), "ign_clconv_pack_weights_x3")
         y = torch.empty(M, Co, device=dev, dtype=torch.float32)
-        _lib.check(L.ign_clconv_fwd_x6(_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, 1, M, Ci, Co, 1, _stream()),
+        ctx.bf16 = torch.is_autocast_enabled()          # autocast region: operands rounded to bf16, one product (see _gemm)
+        _lib.check(_gemm(L, ctx.bf16)[0](_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, 1, M, Ci, Co, 1, _stream()),
                    "ign_clconv_fwd_x6")
         ctx.save_for_backward(x2)
         ctx.wd3, ctx.dims, ctx.has_bias, ctx.xshape = wd3, (M, Ci, Co), bias is not None, x.shape
@@ -275,7 +283,7 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, Ci, device=g2.device, dtype=torch.float32)
-            _lib.check(L.ign_clconv_fwd_x6(_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, 1, M, Co, Ci, 1, _stream()),
+            _lib.check(_gemm(L, ctx.bf16)[0](_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, 1, M, Co, Ci, 1, _stream()),
                        "ign_clconv_fwd_x6(dx)")
             dx = dx.view(ctx.xshape)
         if ctx.needs_input_grad[1]:
@@ -283,7 +291,7 @@ class LinearFn(torch.autograd.Function):
             if Ci % 4 == 0 and LINEAR_WGRAD == "bf16x6":
                 ws = torch.empty(int(L.ign_clconv_wgrad_x6_workspace_bytes(1, M, Ci, Co, 1)) // 4, device=g2.device,
                                  dtype=torch.float32)
-                _lib.check(L.ign_clconv_wgrad_x6(_ptr(g2), 0, _ptr(x2), None, None, _ptr(dw), _ptr(ws), 1, M, Ci, Co, 1, _stream()),
+                _lib.check(_gemm(L, ctx.bf16)[1](_ptr(g2), 0, _ptr(x2), None, None, _ptr(dw), _ptr(ws), 1, M, Ci, Co, 1, _stream()),
                            "ign_clconv_wgrad_x6")
             else:
                 ws = torch.empty(int(L.ign_clconv_wgrad_workspace_bytes(1, M, Ci, Co, 1)) // 4, device=g2.device,
@@ -296,9 +304,9 @@ class LinearFn(torch.autograd.Function):
 
 
 def linear(x, w, bias=None):
-    """nn.Linear / 1x1 Conv1d on the hand-written GEMM kernels; shapes they do not cover (and autocast, and CPU tensors of
-    the reference-side tests) go to torch's GEMM."""
-    if (not x.is_cuda or x.dtype != torch.float32 or w.dtype != torch.float32 or torch.is_autocast_enabled()
+    """nn.Linear / 1x1 Conv1d on the hand-written GEMM kernels (inside an autocast region: their single-product bf16 form);
+    shapes they do not cover (and non-fp32 tensors) go to torch's GEMM."""
+    if (not x.is_cuda or x.dtype != torch.float32 or w.dtype != torch.float32
             or w.shape[0] % 4 or x.numel() == 0 or x.shape[-1] != w.shape[1]
             or x.numel() // x.shape[-1] >= (1 << 30) or LINEAR_IMPL != "hip"):
         return torch.nn.functional.linear(x, w, bias)
@@ -330,7 +338,8 @@ class ConvCLFn(torch.autograd.Function):
         wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, k)), device=dev, dtype=torch.bfloat16) if need_dx else None
         _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt3), _ptr(wd3), Co, Ci, k, _stream()), "ign_clconv_pack_weights_x3")
         y = torch.empty(B, Tin - k + 1, Co, device=dev, dtype=torch.float32)
-        _lib.check(L.ign_clconv_fwd_x6(_ptr(x), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, B, Tin, Ci, Co, k, _stream()),
+        ctx.bf16 = torch.is_autocast_enabled()
+        _lib.check(_gemm(L, ctx.bf16)[0](_ptr(x), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, B, Tin, Ci, Co, k, _stream()),
                    "ign_clconv_fwd_x6")
         ctx.save_for_backward(x)
         ctx.wd3, ctx.dims, ctx.has_bias = wd3, (B, Tin, Ci, Co, k), bias is not None
@@ -347,12 +356,12 @@ class ConvCLFn(torch.autograd.Function):
         gyp = torch.nn.functional.pad(gy, (0, 0, k - 1, k - 1)) if k > 1 else gy.contiguous()
         if ctx.needs_input_grad[0]:
             dx = torch.empty(B, Tin, Ci, device=gy.device, dtype=torch.float32)
-            _lib.check(L.ign_clconv_fwd_x6(_ptr(gyp), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, B, Tout + 2 * (k - 1), Co, Ci, k,
-                                           _stream()), "ign_clconv_fwd_x6(dx)")
+            _lib.check(_gemm(L, ctx.bf16)[0](_ptr(gyp), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, B, Tout + 2 * (k - 1), Co, Ci,
+                                             k, _stream()), "ign_clconv_fwd_x6(dx)")
         if ctx.needs_input_grad[1]:
             dw = torch.empty(Co, Ci, k, device=gy.device, dtype=torch.float32)
             x6 = k in (2, 3, 5, 8) and LINEAR_WGRAD == "bf16x6"
-            wsb, fn, name = ((L.ign_clconv_wgrad_x6_workspace_bytes, L.ign_clconv_wgrad_x6, "ign_clconv_wgrad_x6") if x6 else
+            wsb, fn, name = ((L.ign_clconv_wgrad_x6_workspace_bytes, _gemm(L, ctx.bf16)[1], "ign_clconv_wgrad_x6") if x6 else
                              (L.ign_clconv_wgrad_workspace_bytes, L.ign_clconv_wgrad, "ign_clconv_wgrad"))
             ws = torch.empty(max(1, int(wsb(B, Tin, Ci, Co, k)) // 4), device=gy.device, dtype=torch.float32)
             _lib.check(fn(_ptr(gyp), k - 1, _ptr(x), None, None, _ptr(dw), _ptr(ws), B, Tin, Ci, Co, k, _stream()), name)

@@ -4,6 +4,8 @@ State-dict keys match the reference (``block{1,2,3}.{0,1}.*``, ``fc.*``).  On th
 one autograd node over the hand-written channels-last implicit-GEMM kernels (ign_hip/fcn.py, csrc/ign_clconv_{f32,x6}.hip, ign_bn.hip): the
 loader's (B, T, C) batch IS the GEMM operand (the im2col row of (b, t) is x[b, t:t+k, :], contiguous), BatchNorm statistics
 come out of the GEMM epilogue and BatchNorm's affine + ReLU are applied while the next GEMM stages its operand.
+Inside a ``torch.autocast(bfloat16)`` region (the reference's default mode: ``--amp`` switches it OFF) the same kernels run with
+their operands rounded to bf16 and ONE product per MFMA step (``fcn.CONV_MATH`` "bf16"), activations and BatchNorm stay fp32.
 ``IGN_FCN_MIOPEN=1`` routes the convolutions through torch's MIOpen backend instead (A/B measurements only).
 """
 import os
@@ -39,7 +41,7 @@ class FullyConvNetwork(nn.Module):
         return F.relu(h)
 
     def forward(self, x, x_mark_enc=None, x_dec=None, x_mark_dec=None, mask=None, x_bct=None):
-        if x.is_cuda and not torch.is_autocast_enabled():
+        if x.is_cuda and x.dtype == torch.float32:
             if _USE_CLCONV:
                 # x (B,T,C) is already the channels-last operand of the implicit GEMM: no transpose, no im2col
                 pooled = fcn.fcn_body(x, [(b[0], b[1]) for b in (self.block1, self.block2, self.block3)])

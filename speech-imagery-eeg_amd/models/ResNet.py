@@ -7,8 +7,8 @@ the loader's (B, T, C) batch is the operand as it is, the k=3 / padding=1 convol
 stride-2 stem is a stride-1 k=4 convolution over the (B, T/2, 2C) space-to-depth VIEW of the padded input (weights
 interleaved to match; no gather), the 1x1 shortcut is ``ops.linear``.  BatchNorm runs on the (B*T, C) view (same statistics as
 BatchNorm1d over (B, C, T)); BatchNorm / ReLU / max-pool / residual add are torch element-wise ops on tensors of <= 33 MB.
-Under autocast (the reference's bf16 mode) the reference formulation on (B, C, T) runs through torch on the GPU; CPU tensors
-are refused (no CPU fallback).
+Inside a torch.autocast(bfloat16) region (the reference's default mode) the same kernels run in their single-product bf16 form
+(``ops._gemm``); BatchNorm and the activations stay fp32.  CPU tensors are refused (no CPU fallback).
 """
 import torch
 import torch.nn as nn
@@ -45,14 +45,10 @@ class BasicBlock(nn.Module):
             self.shortcut = nn.Sequential(nn.Conv1d(in_channels, out_channels, kernel_size=1, stride=stride, bias=False),
                                           nn.BatchNorm1d(out_channels))
 
-    def forward(self, x):                        # (B, C, T): the reference formulation
-        identity = self.shortcut(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        out = out + identity
-        return self.relu(out)
+    def forward(self, h):                        # nn.Sequential entry point
+        return self.forward_cl(h)
 
-    def forward_cl(self, h):                     # (B, T, C) on the hand-written kernels
+    def forward_cl(self, h):                     # (B, T, C) channels-last on the hand-written kernels
         if self.stride != 1:
             raise NotImplementedError("the reference builds every BasicBlock with stride 1 (ResNet.py:52-54)")
         if isinstance(self.shortcut, nn.Identity):
@@ -108,16 +104,10 @@ class Model(nn.Module):
     def forward(self, x, x_mark_enc=None, x_dec=None, x_mark_dec=None, mask=None):
         if not x.is_cuda:
             raise IgnError(f"ResNet expert: tensor on {x.device}; the deep experts run on the MI355X only (no CPU fallback)")
-        if not torch.is_autocast_enabled():
-            h = F.relu(_bn_cl(self.bn1, self._stem_cl(x)))
-            h = self._maxpool_cl(h)
-            for layer in (self.layer1, self.layer2, self.layer3):
-                for blk in layer:
-                    h = blk.forward_cl(h)
-            pooled = h.mean(dim=1)
-        else:
-            h = x.permute(0, 2, 1)                                             # ResNet.py:67 ('b c t -> b t c' on (B,T,C))
-            h = self.maxpool(self.relu(self.bn1(self.conv1(h))))
-            h = self.layer3(self.layer2(self.layer1(h)))
-            pooled = torch.flatten(self.avgpool(h), 1)
+        h = F.relu(_bn_cl(self.bn1, self._stem_cl(x.float())))
+        h = self._maxpool_cl(h)
+        for layer in (self.layer1, self.layer2, self.layer3):
+            for blk in layer:
+                h = blk.forward_cl(h)
+        pooled = h.mean(dim=1)
         return ops.head_linear(pooled, self.fc.weight, self.fc.bias)

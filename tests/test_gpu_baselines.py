@@ -396,3 +396,45 @@ def test_inception_block_fused_equals_separate_convs():
     ref = blk.double()(x.double().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
     y = blk.float().to(dev).forward_cl(x.to(dev))
     assert _rel(y, ref) < 3e-6
+
+
+@pytest.mark.parametrize("name,kw", [("ResNet", {}), ("PatchTST", {}), ("Transformer", {}),
+                                     ("TimesNet", dict(seq_len=96, d_model=16, d_ff=16, top_k=3, num_kernels=6))])
+def test_deep_experts_inside_autocast_use_the_bf16_kernels(name, kw, monkeypatch):
+    """The reference's default mode (bf16 autocast): the deep experts stay on the hand-written kernels, in their single-product
+    bf16 form -- logits within bf16 distance of the fp32-accurate run but not equal to it, finite gradients everywhere."""
+    dev = _dev()
+    import importlib
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import _lib
+    L = _lib.lib()
+    calls = {"bf16": 0}
+    real = L.ign_clconv_fwd_bf16
+
+    class Spy:
+        def __getattr__(self, n):
+            if n == "ign_clconv_fwd_bf16":
+                def f(*a):
+                    calls["bf16"] += 1
+                    return real(*a)
+                return f
+            return getattr(L, n)
+
+    monkeypatch.setattr(_lib, "lib", lambda: Spy())
+    cfg = make_cfg(**kw)
+    torch.manual_seed(0)
+    m = importlib.import_module("models." + name).Model(cfg).to(dev).train()
+    T = cfg.seq_len
+    g = torch.Generator().manual_seed(9)
+    t = torch.arange(T, dtype=torch.float32)[None, :, None]
+    x = (torch.sin(2 * math.pi * t / 24) * 2 + torch.sin(2 * math.pi * t / 8) + 0.2 * torch.randn(4, T, 6, generator=g)).to(dev)
+    mask = torch.ones(4, T, device=dev)
+    ref = m(x, mask, None, None)
+    assert calls["bf16"] == 0
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        out = m(x, mask, None, None)
+    assert calls["bf16"] > 0
+    out.float().sum().backward()
+    d = _rel(out.float(), ref.float())
+    assert 1e-6 < d < 8e-2, d
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)

@@ -165,3 +165,35 @@ def test_harness_trains_the_other_deep_experts(tmp_path, monkeypatch, model, dnn
     first = first[0] if isinstance(first, tuple) else first
     after = after[0] if isinstance(after, tuple) else after
     assert torch.isfinite(after).all() and not torch.allclose(first, after)
+
+
+def test_harness_default_bf16_autocast_mode_trains(tmp_path, monkeypatch):
+    """The reference's DEFAULT mode: `--amp` NOT passed = bf16 autocast on (run.py:100, exp:319).  IGN + FCN through the
+    harness inside the autocast region: the shapelet path stays on the fp32 kernels, the FCN body runs the single-product bf16
+    kernels (fcn.CONV_MATH "bf16"), training makes progress and the checkpoint reloads."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import speech_imagery_eeg_amd  # noqa
+    import run
+    from exp.experiment_classification import Experiment
+    from ign_hip import fcn
+    _write_bm(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    run.set_seed(0)
+    a = run.get_args(["--model", "InterpGN", "--dnn_type", "FCN", "--data", "UEA", "--data_root", str(tmp_path), "--dataset",
+                      "BasicMotions", "--train_epochs", "3", "--batch_size", "8", "--seed", "0", "--log_interval", "1"])
+    assert a.amp is True
+    seen = []
+    orig = fcn.FcnBodyFn.forward
+
+    def spy(ctx, x, states_math, *params):
+        seen.append(states_math[1])
+        return orig(ctx, x, states_math, *params)
+
+    monkeypatch.setattr(fcn.FcnBodyFn, "forward", staticmethod(spy))
+    e = Experiment(a)
+    e.train()
+    assert seen and set(seen) == {"bf16"}
+    ckpt = torch.load(os.path.join(e.checkpoint_dir, "checkpoint.pth"), map_location="cpu", weights_only=True)
+    e.model.load_state_dict(ckpt)
+    assert e.test() is not None

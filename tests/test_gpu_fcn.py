@@ -274,3 +274,103 @@ def test_fcn_model_refuses_nothing_it_supports_and_matches_miopen_path():
     for k in res[True][2]:
         if "running" in k:
             assert _rel(res[True][2][k], res[False][2][k]) < TOL, k
+
+
+# --------------------------------------------------------------------------------- bf16-autocast mode
+def _bf16r(t):
+    return t.float().bfloat16().double()
+
+
+@pytest.mark.parametrize("B,Tin,Ci,Co,k", [(3, 50, 6, 128, 8), (2, 140, 128, 256, 5), (2, 77, 256, 128, 3), (4, 33, 10, 64, 2),
+                                           (2, 300, 64, 64, 1)])
+def test_bf16_single_product_kernels_equal_rounded_operand_products(B, Tin, Ci, Co, k):
+    """ign_clconv_{fwd,wgrad}_bf16 and the input gradient through ops: one product per MFMA step on operands rounded to bf16,
+    fp32 accumulation == float64 convolution of the ROUNDED operands (bf16 x bf16 products are exact in fp32)."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B + Tin + Ci + Co + k)
+    x = torch.randn(B, Tin, Ci, generator=g)
+    w = torch.randn(Co, Ci, k, generator=g) / (Ci * k) ** 0.5
+    b = torch.randn(Co, generator=g)
+    Tout = Tin - k + 1
+    gy = torch.randn(B, Tout, Co, generator=g)
+    xg, wg, bg, gyg = (t.to(dev).contiguous() for t in (x, w, b, gy))
+    wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
+    wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, k)), device=dev, dtype=torch.bfloat16)
+    _lib.check(L.ign_clconv_pack_weights_x3(_p(wg), _p(wt3), _p(wd3), Co, Ci, k, _s()), "pack")
+    y = torch.empty(B, Tout, Co, device=dev)
+    _lib.check(L.ign_clconv_fwd_bf16(_p(xg), _p(wt3), _p(bg), None, None, _p(y), None, B, Tin, Ci, Co, k, _s()), "fwd_bf16")
+    ref = F.conv1d(_bf16r(x).permute(0, 2, 1), _bf16r(w), b.double()).permute(0, 2, 1)
+    assert _rel(y, ref) < 3e-6
+    # input gradient = the same forward kernel on the zero-padded dy with the tap-reversed transposed weights
+    gyp = F.pad(gyg, (0, 0, k - 1, k - 1)).contiguous()
+    dx = torch.empty(B, Tin, Ci, device=dev)
+    _lib.check(L.ign_clconv_fwd_bf16(_p(gyp), _p(wd3), None, None, None, _p(dx), None, B, Tout + 2 * (k - 1), Co, Ci, k, _s()), "dx")
+    dref = F.conv_transpose1d(_bf16r(gy).permute(0, 2, 1), _bf16r(w)).permute(0, 2, 1)
+    assert _rel(dx, dref) < 3e-6
+    if k in (1, 2, 3, 5, 8) and Ci % 4 == 0 or k in (2, 3, 5, 8):
+        ws = torch.empty(int(L.ign_clconv_wgrad_x6_workspace_bytes(B, Tin, Ci, Co, k)) // 4, device=dev)
+        dw = torch.empty(Co, Ci, k, device=dev)
+        _lib.check(L.ign_clconv_wgrad_bf16(_p(gyp), k - 1, _p(xg), None, None, _p(dw), _p(ws), B, Tin, Ci, Co, k, _s()), "wgrad_bf16")
+        xr, gr = _bf16r(x), _bf16r(gy)
+        wref = torch.stack([torch.einsum("bto,bti->oi", gr, xr[:, j:j + Tout]) for j in range(k)], dim=2)
+        assert _rel(dw, wref) < 1e-5
+
+
+class _RoundedConv(torch.autograd.Function):
+    """float64 model of the single-product kernels: every GEMM operand (input, weight, upstream gradient) is rounded to bf16
+    where the kernel stages it; products and sums are exact / float64."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xr, wr = _bf16r(x), _bf16r(w)
+        ctx.save_for_backward(xr, wr)
+        return F.conv1d(xr, wr, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xr, wr = ctx.saved_tensors
+        gr = _bf16r(gy)
+        return (F.conv_transpose1d(gr, wr), torch.nn.grad.conv1d_weight(xr, wr.shape, gr), gy.sum(dim=(0, 2)))
+
+
+def test_fcn_body_inside_autocast_runs_the_bf16_kernels(monkeypatch):
+    """Inside torch.autocast(bfloat16) the FCN body runs the single-product kernels: it matches a float64 model that rounds
+    every GEMM operand to bf16 where the kernels do (tight bound), is NOT the fp32-accurate result, and stays within bf16-level
+    distance of it; the output stays float32."""
+    dev = _dev()
+    import copy
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import fcn
+    ref = _ref_blocks(6, (128, 256, 128), (8, 5, 3), seed=5).train()
+    m32, m16 = copy.deepcopy(ref).to(dev), copy.deepcopy(ref).to(dev)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(8, 100, 6, generator=g)
+    gp = torch.randn(8, 128, generator=g)
+    p32 = fcn.fcn_body(x.to(dev), [(b[0], b[1]) for b in m32])
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        p16 = fcn.fcn_body(x.to(dev), [(b[0], b[1]) for b in m16])
+    assert p16.dtype == torch.float32
+    (p16 * gp.to(dev)).sum().backward()
+    assert 1e-5 < _rel(p16, p32) < 2e-2
+    # float64 model with the kernels' rounding points
+    md = copy.deepcopy(ref).double()
+    h = x.double().permute(0, 2, 1)
+    near = 0
+    for blk in md:
+        y = _RoundedConv.apply(h, blk[0].weight, blk[0].bias)
+        n = F.batch_norm(y, None, None, blk[1].weight, blk[1].bias, True, 0.1, blk[1].eps)
+        near += int((n.abs() < 1e-5).sum())
+        h = F.relu(n)
+    pd = h.mean(-1)
+    (pd * gp.double()).sum().backward()
+    # an fp32 activation within rounding of a bf16 tie rounds the other way than its float64 twin (2^-9 on that element):
+    # the bound is a few 1e-4, two orders below the distance to the unrounded result
+    assert _rel(p16, pd) < 3e-4
+    if near == 0:
+        for (n_, a), (_, b) in zip(m16.named_parameters(), md.named_parameters()):
+            if n_.endswith("0.bias"):
+                continue
+            assert _rel(a.grad, b.grad) < 1e-2, n_

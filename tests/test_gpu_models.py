@@ -336,3 +336,38 @@ def test_graphed_train_step_equals_eager():
         w = finals["graph"][1][k]
         if v.dtype.is_floating_point:
             assert float((v - w).abs().max()) <= 1e-6 * max(1.0, float(v.abs().max())), k
+
+
+def test_ign_in_autocast_mode_tracks_the_oracle_in_autocast_mode():
+    """The reference's DEFAULT mode (bf16 autocast; `--amp` switches it off): the product model inside
+    torch.autocast(cuda, bfloat16) against the CPU oracle inside torch.autocast(cpu, bfloat16), same weights and batch.
+    bf16 rounding points differ in detail (the product keeps activations fp32), so the bound is bf16-level."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models.InterpGN import InterpGN
+    from oracle import ign_oracle as O
+    cfg = make_cfg()
+    torch.manual_seed(0)
+    orc = O.OracleIGN(cfg).train()
+    m = InterpGN(cfg)
+    m.load_state_dict(orc.state_dict())
+    m.to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 100, 6, generator=g)
+    y = torch.arange(8) % 4
+    with torch.autocast(device_type="cpu", dtype=torch.bfloat16):
+        out_o, info_o = orc(x)
+        loss_o = F.cross_entropy(out_o.float(), y)
+    loss_o.backward()
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        out, info = m(x.to(dev), torch.ones(8, 100, device=dev), None, None)
+        loss = F.cross_entropy(out.float(), y.to(dev))
+    loss.backward()
+    assert float((out.float().cpu() - out_o.float()).abs().max()) < 5e-2 * max(1.0, float(out_o.float().abs().max()))
+    assert abs(loss.item() - loss_o.item()) < 3e-2
+    go = dict(orc.named_parameters())
+    for n, p in m.named_parameters():
+        if p.grad is None or n.endswith("0.bias"):
+            continue
+        ref = go[n].grad.float()
+        assert float((p.grad.float().cpu() - ref).norm()) < 0.1 * float(ref.norm()) + 1e-4, n
