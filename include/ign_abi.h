@@ -99,6 +99,12 @@ int ign_attn_fwd(const float* q, const float* k, const float* v, float* out, flo
                  float scale, void* stream);
 /* Backward: gq (B,L,H,E), gk/gv (B,S,H,E) contiguous outputs (overwritten); gout (B,L,H,E) contiguous;
  * delta_ws: B*H*L floats of workspace.  dQ recomputes the scores instead of using float atomics: deterministic.  */
+/* The forward on the bf16 matrix cores at fp32 accuracy (split-bf16 products as in ign_clconv_*_x6; K / V tiles are split while
+ * they are staged, Q and P in registers).  Same arguments, outputs and saved statistics as ign_attn_fwd, so ign_attn_bwd follows
+ * either.                                                                                                                   */
+int ign_attn_fwd_x6(const float* q, const float* k, const float* v, float* out, float* lse, int B, int L, int S, int H, int E,
+                    long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl,
+                    float scale, void* stream);
 int ign_attn_bwd(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* gout,
                  float* gq, float* gk, float* gv, float* delta_ws,
                  int B, int L, int S, int H, int E,

@@ -1,0 +1,281 @@
+// Attention core  softmax(scale * Q K^T) V  on the bf16 matrix cores at fp32 accuracy (forward).
+//
+// Same maths and interface as attn_fwd_kernel (ign_attention.hip; IGN/layers/SelfAttention_Family.py:56-75), but both
+// products run as split-bf16 GEMMs (csrc/ign_clconv_x6.hip): every fp32 operand is split exactly into three bf16 terms and the
+// six partial products of weight >= 2^-16 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -- 24 MFMAs of 32 cycles per
+// 32x32 score tile and product instead of 32 fp32 MFMAs of 64 cycles, error at the fp32 kernel's level.
+//   * K and V tiles are split while they are staged (fp32 global -> registers -> three bf16 LDS planes): the L/128 workgroups
+//     of a (batch, head) repeat that split, but it is 5.5 VALU per element against 96 MFMAs per tile and wave, it reads 4 bytes
+//     per element instead of the 6 of pre-split planes, and needs no workspace or pre-pass (a pre-split pass cost 0.7 of 4.2 ms).
+//     The next tile's loads are issued before the current tile's MFMAs and land in registers behind them.  Q rows are split in
+//     registers by the wave that owns them, scale folded in first.
+//   * S^T = K Q^T as before (keys in the accumulator registers, the query on the lane): the online softmax is unchanged.
+//   * P^T is split in registers.  Accumulator register r of lane half h holds key (r&3) + 8(r>>2) + 4h, so registers 8s..8s+7
+//     are the 16-key slab s with k-slot i <-> key 16s + 4h + (i&3) + 8(i>>2): exactly two groups of 4 CONSECUTIVE keys, which is
+//     what gfx950's transposing LDS read ds_read_b64_tr_b16 delivers for the A operand V^T (lane = feature column, 4 rows per
+//     read) from a V tile staged row-major.  No LDS round trip for P, no transposed copy of V.
+#include "ign_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct AttnX6Args {
+    const float *q, *k, *v;                  // (B,L,H,E) / (B,S,H,E) with element strides sb (batch), sl (sequence); head stride E
+    float *out, *lse_out;
+    long long q_sb, q_sl, k_sb, k_sl, v_sb, v_sl;
+    int B, L, S, H, E;
+    float scale;
+};
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// x = x0 + x1 + x2 (bf16, round to nearest; the residuals are exact fp32 subtractions) for a pair of values
+__device__ __forceinline__ void split3_pair(f32x2 v, bf16x2& x0, bf16x2& x1, bf16x2& x2) {
+    x0 = __builtin_convertvector(v, bf16x2);
+    f32x2 r = v - __builtin_convertvector(x0, f32x2);
+    x1 = __builtin_convertvector(r, bf16x2);
+    r -= __builtin_convertvector(x1, f32x2);
+    x2 = __builtin_convertvector(r, bf16x2);
+}
+// eight values -> one bf16x8 MFMA operand per plane
+__device__ __forceinline__ void split3_x8(const float (&t)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    bf16x2 a[4], b[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split3_pair(f32x2{t[2 * i], t[2 * i + 1]}, a[i], b[i], c[i]);
+    p0 = __builtin_shufflevector(__builtin_shufflevector(a[0], a[1], 0, 1, 2, 3), __builtin_shufflevector(a[2], a[3], 0, 1, 2, 3),
+                                 0, 1, 2, 3, 4, 5, 6, 7);
+    p1 = __builtin_shufflevector(__builtin_shufflevector(b[0], b[1], 0, 1, 2, 3), __builtin_shufflevector(b[2], b[3], 0, 1, 2, 3),
+                                 0, 1, 2, 3, 4, 5, 6, 7);
+    p2 = __builtin_shufflevector(__builtin_shufflevector(c[0], c[1], 0, 1, 2, 3), __builtin_shufflevector(c[2], c[3], 0, 1, 2, 3),
+                                 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p1));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// four values -> three LDS planes `plane` elements apart (8-byte stores)
+__device__ __forceinline__ void split3_store4(const float4 t, __bf16* d, int plane) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x2 a0, a1, a2, b0, b1, b2;
+    split3_pair(f32x2{t.x, t.y}, a0, a1, a2);
+    split3_pair(f32x2{t.z, t.w}, b0, b1, b2);
+    *reinterpret_cast<bf16x4*>(d) = __builtin_shufflevector(a0, b0, 0, 1, 2, 3);
+    *reinterpret_cast<bf16x4*>(d + plane) = __builtin_shufflevector(a1, b1, 0, 1, 2, 3);
+    *reinterpret_cast<bf16x4*>(d + 2 * plane) = __builtin_shufflevector(a2, b2, 0, 1, 2, 3);
+}
+
+template <int E> struct AxPitch {
+    static constexpr int KT = E == 16 ? 64 : 32;                  // keys staged per LDS tile (256 threads cover >= 1 pass)
+    static constexpr int K = E + 8;                               // 16-byte reads of 8 consecutive e: (E+8)*2 B = 16 * odd
+    static constexpr int V = E >= 64 ? E + 32 : E + E / 2;        // transposing reads: rows 0..3 of a block 16 banks apart
+};
+
+template <int E>
+__global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a) {
+    constexpr int NS = E / 16, ED = (E + 31) / 32, PK = AxPitch<E>::K, PV = AxPitch<E>::V, AX_KT = AxPitch<E>::KT;
+    constexpr int KPLANE = AX_KT * PK, VPLANE = AX_KT * PV;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    __bf16* Ks = reinterpret_cast<__bf16*>(smem16);
+    __bf16* Vs = Ks + 3 * KPLANE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int qi = blockIdx.x * 128 + wave * 32 + l31;
+    const bool q_ok = qi < a.L;
+
+    // Q^T operand: lane (query, h) holds e = 16s + 8h .. +7 of slab s, three planes, scale folded in before the split
+    bf16x8 Qf[3][NS];
+    {
+        const float* qp = a.q + b * a.q_sb + (long long)(q_ok ? qi : a.L - 1) * a.q_sl + head * E + 8 * h;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * s);
+            const float4 t1 = *reinterpret_cast<const float4*>(qp + 16 * s + 4);
+            const float t[8] = {t0.x * a.scale, t0.y * a.scale, t0.z * a.scale, t0.w * a.scale,
+                                t1.x * a.scale, t1.y * a.scale, t1.z * a.scale, t1.w * a.scale};
+            split3_x8(t, Qf[0][s], Qf[1][s], Qf[2][s]);
+        }
+    }
+    f32x16 O[ED];
+#pragma unroll
+    for (int d = 0; d < ED; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[d][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    // transposed-read coordinates of the V^T operand (see the header): lane supplies row q4 / columns 4*p4 of its 16-lane
+    // group's block and receives column 16*G1 + u16 = l31
+    const int u16 = lane & 15, q4 = u16 >> 2, p4 = u16 & 3, G1 = (lane >> 4) & 1;
+    const int voff = (4 * h + q4) * PV + 16 * G1 + 4 * p4;
+    const float* kbase = a.k + b * a.k_sb + head * E;
+    const float* vbase = a.v + b * a.v_sb + head * E;
+    // staging: thread -> float4 pieces (row sr + 16*p, columns sc..sc+3), p < NP4; 256 threads cover 16 rows x E/4... per pass
+    constexpr int V4 = E / 4, RPP = 256 / V4, NP4 = AX_KT / RPP;      // rows per pass, passes per tile
+    const int sr = threadIdx.x / V4, sc = (threadIdx.x - sr * V4) * 4;
+    float4 rk[NP4], rv[NP4];
+#define IGN_GLOAD(kt_)                                                                               \
+    _Pragma("unroll") for (int p = 0; p < NP4; ++p) {                                                \
+        const int r_ = (kt_) + sr + RPP * p;                                                         \
+        const int rc_ = min(r_, a.S - 1);                                                            \
+        float4 tk_ = *reinterpret_cast<const float4*>(kbase + (long long)rc_ * a.k_sl + sc);         \
+        float4 tv_ = *reinterpret_cast<const float4*>(vbase + (long long)rc_ * a.v_sl + sc);         \
+        if (r_ >= a.S) tk_ = tv_ = make_float4(0.f, 0.f, 0.f, 0.f);                                  \
+        rk[p] = tk_; rv[p] = tv_;                                                                    \
+    }
+    IGN_GLOAD(0)
+    for (int kt0 = 0; kt0 < a.S; kt0 += AX_KT) {
+        __syncthreads();                                           // every wave is done with the previous tile
+#pragma unroll
+        for (int p = 0; p < NP4; ++p) {
+            split3_store4(rk[p], Ks + (sr + RPP * p) * PK + sc, KPLANE);
+            split3_store4(rv[p], Vs + (sr + RPP * p) * PV + sc, VPLANE);
+        }
+        __syncthreads();
+        if (kt0 + AX_KT < a.S) { IGN_GLOAD(kt0 + AX_KT) }          // lands behind this tile's MFMAs
+#pragma unroll
+        for (int sub = 0; sub < AX_KT / 32; ++sub) {
+            const int kb = sub * 32;
+            if (kt0 + kb < a.S) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const __bf16* kr = Ks + (kb + l31) * PK + 8 * h;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kr + 16 * s);
+                    const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kr + KPLANE + 16 * s);
+                    const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(kr + 2 * KPLANE + 16 * s);
+                    acc = MFMA16(k2, Qf[0][s], acc);
+                    acc = MFMA16(k0, Qf[2][s], acc);
+                    acc = MFMA16(k1, Qf[1][s], acc);
+                    acc = MFMA16(k1, Qf[0][s], acc);
+                    acc = MFMA16(k0, Qf[1][s], acc);
+                    acc = MFMA16(k0, Qf[0][s], acc);
+                }
+                // online softmax over this lane's 16 keys + the partner half's 16 keys
+                float mloc = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (kt0 + kb + acc_row(r, h) >= a.S) acc[r] = -INFINITY;
+                    mloc = fmaxf(mloc, acc[r]);
+                }
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                const float mnew = fmaxf(m, mloc);
+                const float alpha = __expf(m - mnew);
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[r] = __expf(acc[r] - mnew);
+                    psum += acc[r];
+                }
+                psum += __shfl_xor(psum, 32, 64);
+                l = l * alpha + psum;
+                m = mnew;
+                // P^T operand: registers 8*s2 .. 8*s2+7 are the 16-key slab s2
+                bf16x8 Pf[3][2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const float t[8] = {acc[8 * s2], acc[8 * s2 + 1], acc[8 * s2 + 2], acc[8 * s2 + 3],
+                                        acc[8 * s2 + 4], acc[8 * s2 + 5], acc[8 * s2 + 6], acc[8 * s2 + 7]};
+                    split3_x8(t, Pf[0][s2], Pf[1][s2], Pf[2][s2]);
+                }
+#pragma unroll
+                for (int d = 0; d < ED; ++d) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const __bf16* vp = Vs + (kb + 16 * s2) * PV + voff + d * 32;
+                        const bf16x8 v0 = lds_tr8(vp, vp + 8 * PV);
+                        const bf16x8 v1 = lds_tr8(vp + VPLANE, vp + VPLANE + 8 * PV);
+                        const bf16x8 v2 = lds_tr8(vp + 2 * VPLANE, vp + 2 * VPLANE + 8 * PV);
+                        O[d] = MFMA16(v2, Pf[0][s2], O[d]);
+                        O[d] = MFMA16(v0, Pf[2][s2], O[d]);
+                        O[d] = MFMA16(v1, Pf[1][s2], O[d]);
+                        O[d] = MFMA16(v1, Pf[0][s2], O[d]);
+                        O[d] = MFMA16(v0, Pf[1][s2], O[d]);
+                        O[d] = MFMA16(v0, Pf[0][s2], O[d]);
+                    }
+                }
+            }
+        }
+    }
+    if (q_ok) {
+        const float inv = 1.f / l;
+        float* op = a.out + (((long long)b * a.L + qi) * a.H + head) * E;
+#pragma unroll
+        for (int d = 0; d < ED; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = d * 32 + 8 * g + 4 * h;
+                if (d0 < E)
+                    *reinterpret_cast<float4*>(op + d0) = make_float4(O[d][4 * g] * inv, O[d][4 * g + 1] * inv,
+                                                                      O[d][4 * g + 2] * inv, O[d][4 * g + 3] * inv);
+            }
+        if (h == 0) a.lse_out[((long long)b * a.H + head) * a.L + qi] = m + __logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" int ign_attn_fwd_x6(const float* q, const float* k, const float* v, float* out, float* lse, int B, int L, int S, int H,
+                               int E, long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb,
+                               long long v_sl, float scale, void* stream) {
+    static const char* who = "ign_attn_fwd_x6";
+    if (B <= 0 || L <= 0 || S <= 0 || H <= 0 || H > 65535 || B > 65535) {
+        ign_set_error("%s: bad dimensions B=%d L=%d S=%d H=%d", who, B, L, S, H);
+        return IGN_E_ARG;
+    }
+    if (E != 16 && E != 32 && E != 64 && E != 128) {
+        ign_set_error("%s: head dimension E=%d not instantiated (16, 32, 64, 128)", who, E);
+        return IGN_E_UNSUP;
+    }
+    const void* ptrs[5] = {q, k, v, out, lse};
+    for (int i = 0; i < 5; ++i)
+        if (!ptrs[i] || ((uintptr_t)ptrs[i] & 15)) {
+            ign_set_error("%s: pointer %d is null or not 16-byte aligned", who, i);
+            return IGN_E_ARG;
+        }
+    const long long st[6] = {q_sb, q_sl, k_sb, k_sl, v_sb, v_sl};
+    for (int i = 0; i < 6; ++i)
+        if (st[i] <= 0 || (st[i] & 3)) {
+            ign_set_error("%s: stride %d = %lld must be a positive multiple of 4 elements", who, i, st[i]);
+            return IGN_E_ARG;
+        }
+    hipStream_t s = (hipStream_t)stream;
+    AttnX6Args a = {};
+    a.q = q; a.k = k; a.v = v; a.out = out; a.lse_out = lse;
+    a.q_sb = q_sb; a.q_sl = q_sl; a.k_sb = k_sb; a.k_sl = k_sl; a.v_sb = v_sb; a.v_sl = v_sl;
+    a.B = B; a.L = L; a.S = S; a.H = H; a.E = E; a.scale = scale;
+    const dim3 grid((L + 127) / 128, H, B);
+    IgnScopedTimer tm("attn_fwd", s);
+#define IGN_AX(EE)                                                                                                            \
+    do {                                                                                                                      \
+        constexpr size_t lds = (size_t)3 * AxPitch<EE>::KT * (AxPitch<EE>::K + AxPitch<EE>::V) * sizeof(unsigned short) + 256; \
+        static bool once = false;                                                                                             \
+        if (!once) {                                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_x6_kernel<EE>),                                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
+            once = true;                                                                                                      \
+        }                                                                                                                     \
+        hipLaunchKernelGGL((attn_fwd_x6_kernel<EE>), grid, dim3(256), lds, s, a);                                             \
+    } while (0)
+    switch (E) {
+        case 16: IGN_AX(16); break;
+        case 32: IGN_AX(32); break;
+        case 64: IGN_AX(64); break;
+        default: IGN_AX(128); break;
+    }
+#undef IGN_AX
+    return ign_check_launch("attn_fwd_x6_kernel");
+}

@@ -24,6 +24,7 @@ SIGNATURES = {
     "ign_shapelet_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),
     "ign_shapelet_bwd_workspace_bytes": (sz, [ci, ci, ci, ci, ci, ci, ci]),
     "ign_attn_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
+    "ign_attn_fwd_x6": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
     "ign_attn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
     "ign_head_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ll, vp]),
     "ign_head_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]),

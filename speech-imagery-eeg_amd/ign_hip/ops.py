@@ -10,6 +10,7 @@ import os
 
 DIST_L1, DIST_MSE, DIST_COS, DIST_PEARSON = 0, 1, 2, 3
 LINEAR_IMPL = os.environ.get("IGN_LINEAR", "hip")      # "torch": route ops.linear to hipBLASLt (A/B measurements)
+ATTN_MATH = os.environ.get("IGN_ATTN_MATH", "bf16x6")          # "f32": attention forward on the fp32-MFMA kernel
 LINEAR_WGRAD = os.environ.get("IGN_LINEAR_WGRAD", "bf16x6")   # "f32": weight gradient of ops.linear on the fp32-MFMA TN kernel
 GATE_RBF, GATE_LTS = 0x00, 0x10
 
@@ -165,8 +166,11 @@ class AttentionFn(torch.autograd.Function):
         out = torch.empty(B, L, H, E, device=q.device, dtype=torch.float32)
         lse = torch.empty(B, H, L, device=q.device, dtype=torch.float32)
         (qb, ql), (kb, kl), (vb, vl) = _bl_strides(q, "q"), _bl_strides(k, "k"), _bl_strides(v, "v")
-        _lib.check(_lib.lib().ign_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, L, S, H, E,
-                                           qb, ql, kb, kl, vb, vl, float(scale), _stream()), "ign_attn_fwd")
+        L_ = _lib.lib()
+        # "bf16x6": split-bf16 products on the bf16 matrix cores (fp32 accuracy); "f32": the fp32-MFMA kernel
+        fwd = L_.ign_attn_fwd_x6 if ATTN_MATH == "bf16x6" else L_.ign_attn_fwd
+        _lib.check(fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, L, S, H, E, qb, ql, kb, kl, vb, vl, float(scale),
+                       _stream()), "ign_attn_fwd")
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.scale = float(scale)
         return out

@@ -35,10 +35,12 @@ def _attn_ref(q, k, v, scale):
     return torch.einsum("bhls,bshd->blhd", torch.softmax(scale * s, dim=-1), v)
 
 
-def test_attention_core_golden():
+@pytest.mark.parametrize("amath", ["bf16x6", "f32"])
+def test_attention_core_golden(amath, monkeypatch):
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
     from ign_hip import ops
+    monkeypatch.setattr(ops, "ATTN_MATH", amath)
     g = golden("attention_core")
     q, k, v = (_t(g[n], dev).requires_grad_(True) for n in ("q", "k", "v"))
     o = ops.attention(q, k, v, 1.0 / math.sqrt(q.shape[-1]))
@@ -49,10 +51,12 @@ def test_attention_core_golden():
 
 @pytest.mark.parametrize("B,L,S,H,E", [(2, 1000, 1000, 8, 64), (3, 100, 100, 8, 64), (2, 130, 75, 2, 32),
                                        (1, 33, 257, 3, 16), (2, 64, 64, 1, 128)])
-def test_attention_vs_fp64_reference(B, L, S, H, E):
+@pytest.mark.parametrize("amath", ["bf16x6", "f32"])
+def test_attention_vs_fp64_reference(B, L, S, H, E, amath, monkeypatch):
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
     from ign_hip import ops
+    monkeypatch.setattr(ops, "ATTN_MATH", amath)
     g = torch.Generator().manual_seed(L * 7 + E)
     q = torch.randn(B, L, H, E, generator=g).to(dev).requires_grad_(True)
     k = torch.randn(B, S, H, E, generator=g).to(dev).requires_grad_(True)
