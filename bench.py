@@ -335,11 +335,11 @@ def main():
                     if x6:
                         return {"ms_per_step": ms, "achieved": tf_alg, "unit": "TFLOP/s fp32-equivalent (algorithmic)",
                                 "executed_bf16_tflops": 6.0 * tf_alg, "peak": 2500.0, "frac": 6.0 * tf_alg / 2500.0}
-                if _fcn.CONV_MATH == "bf16":
-                    # operands rounded to bf16, one product (the reference's autocast arithmetic): priced against the bf16 peak
-                    return {"ms_per_step": ms, "achieved": tf_alg, "unit": "TFLOP/s bf16 (one product, fp32 accumulate)",
-                            "peak": 2500.0, "frac": tf_alg / 2500.0}
-                return {"ms_per_step": ms, "achieved": tf_alg, "peak": 157.3, "frac": tf_alg / 157.3}
+                    if _fcn.CONV_MATH == "bf16":
+                        # operands rounded to bf16, one product (the reference's autocast arithmetic): priced against the bf16 peak
+                        return {"ms_per_step": ms, "achieved": tf_alg, "unit": "TFLOP/s bf16 (one product, fp32 accumulate)",
+                                "peak": 2500.0, "frac": tf_alg / 2500.0}
+                    return {"ms_per_step": ms, "achieved": tf_alg, "peak": 157.3, "frac": tf_alg / 157.3}
                 fcn_f = 2.0 * B * (993 * 128 * 976 + 989 * 256 * 640 + 987 * 128 * 768)
                 fcn_d = 2.0 * B * (993 * 128 * 1280 + 989 * 256 * 384)                          # data gradients of blocks 3, 2
                 # measured instruction-issue ceilings of the two inner loops in isolation (profiles/r1_valu_microbench.txt):
