@@ -152,19 +152,6 @@ extern "C" int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const f
     a.xstat = (dist >= DIST_COS) ? xstat_save : nullptr;
     a.B = B; a.C = C; a.T = T; a.K = K; a.L = L; a.Tw = Tw; a.stride = stride; a.ld = ld; a.col0 = col0;
     a.npass = npass; a.xs_len = xs_len; a.gate = gate; a.eps = eps; a.invL = 1.0f / (float)L;
-    {
-        // IGN_SHP_STAGGER="<percent of a row's estimated duration per slot>,<shift>" (experiment knob)
-        static int pct = -1, shift = 10;
-        if (pct < 0) {
-            const char* e = getenv("IGN_SHP_STAGGER");
-            pct = 0;
-            if (e) sscanf(e, "%d,%d", &pct, &shift);
-        }
-        // a row's distance loop: TT*L*K elements * 2 VALU per lane, ~2.5 cycles per wave-instruction at 4 waves per SIMD * 4
-        const double cyc = (double)TT * L * (K < 5 ? K : 5) * 2.0 * 2.5 * 4.0;
-        a.stagger = (int)(cyc * pct / 100.0 / (127.0 * 64.0));
-        a.stagger_shift = shift;
-    }
     const int nbg = (B + wpb - 1) / wpb;
     // shapelets in tiles of 5, then 2, then 1 (each tile shares the x registers across its shapelets)
     int k0 = 0;

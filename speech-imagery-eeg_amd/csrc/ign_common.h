@@ -38,7 +38,6 @@ struct ShpFwdArgs {
     int xs_len;           // floats of LDS per wave (multiple of 4)
     int gate;             // GATE_RBF / GATE_LTS
     float eps, invL;
-    int stagger, stagger_shift;   // first-round start offsets (see shp_fwd_kernel): sleeps per slot, slot = (block >> shift) & 3
 };
 
 // launchers generated per (DIST, TT, KT); defined in ign_shapelet_fwd_*.hip

@@ -69,14 +69,6 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
     if (!row_ok) b = a.B - 1;
     const int k0 = a.k0 + blockIdx.y * KT;
 
-    // All rows cost the same, so the waves a SIMD holds would run their (latency-bound) epilogues at the same moment and their
-    // (issue-bound) distance loops at the same moment.  The blocks of the first round start a quarter of a row apart; since
-    // every later block starts when an earlier one ends, the offset persists and epilogues hide under other waves' loops.
-    if (a.stagger > 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
-        const int slot = (blockIdx.x >> a.stagger_shift) & 3;
-        for (int i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-
     float* xs = smem + wave * a.xs_len;
     {
         // batches of 8 loads in flight before the first LDS store: one memory round trip per 512 samples instead of one
