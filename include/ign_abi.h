@@ -110,6 +110,14 @@ int ign_attn_bwd(const float* q, const float* k, const float* v, const float* ou
                  int B, int L, int S, int H, int E,
                  long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl,
                  float scale, void* stream);
+/* The backward in split-bf16 form: delta, then dV, dK (key blocks, each recomputing S) and dQ (query blocks) as three kernels;
+ * same arguments and results as ign_attn_bwd (gradients bitwise reproducible, no atomics).  E <= 64 runs without register
+ * spills; E = 128 is accepted but slower than ign_attn_bwd.                                                                */
+int ign_attn_bwd_x6(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* gout,
+                 float* gq, float* gk, float* gv, float* delta_ws,
+                 int B, int L, int S, int H, int E,
+                 long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl,
+                 float scale, void* stream);
 
 /* Skinny expert-head GEMM  out[b,n] = sum_f X[b,f] W[n,f] (+ bias[n]),  N <= 16 classes, F % 4 == 0, row pitch ldx.
  * Replaces nn.Linear at IGN/model/Shapelet.py:171,200 (SBM head), IGN/model/Transformer.py:72,109,

@@ -227,6 +227,295 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
     }
 }
 
+// ================================================================================================ backward
+// Same three-kernel structure as every split-bf16 GEMM here: operands that stay fixed for a wave live in registers as bf16x8
+// planes, streamed tiles are split while they are staged (32 rows x E, pitch E + 8: one layout serves both the row-wise
+// 16-byte operand reads and the transposing reads), probabilities / score gradients are split in registers and are already in
+// B-operand layout.  The fp32 backward keeps K^T and V^T (64 VGPRs) and both gradient accumulators in one kernel; in split
+// form that is 96 + 64 + 32 + 24 + fragments > 256 VGPRs at two waves per SIMD, so dK and dV are separate kernels that each
+// recompute S (MFMAs per 32x32 tile: dQ 72, dK 72, dV 48 of 32 cycles -- against 224 of 64 cycles in fp32).
+struct AttnX6BwdArgs {
+    const float *q, *k, *v, *go, *lse, *delta;     // go (B,L,H,E) contiguous; lse, delta (B,H,L)
+    float *gq, *gk, *gv;
+    long long q_sb, q_sl, k_sb, k_sl, v_sb, v_sl;
+    int B, L, S, H, E;
+    float scale;
+};
+
+constexpr int AB_T = 32;                                          // rows per staged tile
+template <int E> struct AbCfg {
+    static constexpr int P = E + 8;                               // bf16 per staged row
+    static constexpr int PLANE = AB_T * P;
+    static constexpr int V4 = E / 4;                              // float4 pieces per row
+    static constexpr int RPP = 256 / V4 < AB_T ? 256 / V4 : AB_T; // rows covered per pass by 256 threads
+    static constexpr int NP4 = AB_T / RPP;
+    static constexpr size_t LDS = (size_t)2 * 3 * PLANE * sizeof(unsigned short) + 2 * AB_T * sizeof(float) + 256;
+};
+
+// eight consecutive fp32 values (two float4) -> the three bf16x8 planes of an MFMA operand, optional scale
+__device__ __forceinline__ void load_split8(const float* p, float sc, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    const float4 t0 = *reinterpret_cast<const float4*>(p);
+    const float4 t1 = *reinterpret_cast<const float4*>(p + 4);
+    const float t[8] = {t0.x * sc, t0.y * sc, t0.z * sc, t0.w * sc, t1.x * sc, t1.y * sc, t1.z * sc, t1.w * sc};
+    split3_x8(t, p0, p1, p2);
+}
+
+#define IGN_X6_PRODUCTS(acc_, a0, a1, a2, b0, b1, b2)  \
+    acc_ = MFMA16(a2, b0, acc_);                       \
+    acc_ = MFMA16(a0, b2, acc_);                       \
+    acc_ = MFMA16(a1, b1, acc_);                       \
+    acc_ = MFMA16(a1, b0, acc_);                       \
+    acc_ = MFMA16(a0, b1, acc_);                       \
+    acc_ = MFMA16(a0, b0, acc_);
+
+// acc (rows = tile rows, column = lane) += T[32 rows][E] * F^T, T in LDS planes (row-wise reads), F this lane's register planes
+template <int E>
+__device__ __forceinline__ void x6_rows_times_regs(f32x16& acc, const __bf16* T, const bf16x8 (&F)[3][E / 16], int l31, int h) {
+    constexpr int P = AbCfg<E>::P, PLANE = AbCfg<E>::PLANE;
+    const __bf16* tr = T + l31 * P + 8 * h;
+#pragma unroll
+    for (int s = 0; s < E / 16; ++s) {
+        const bf16x8 t0 = *reinterpret_cast<const bf16x8*>(tr + 16 * s);
+        const bf16x8 t1 = *reinterpret_cast<const bf16x8*>(tr + PLANE + 16 * s);
+        const bf16x8 t2 = *reinterpret_cast<const bf16x8*>(tr + 2 * PLANE + 16 * s);
+        IGN_X6_PRODUCTS(acc, t0, t1, t2, F[0][s], F[1][s], F[2][s])
+    }
+}
+
+// G[d] (rows = feature d*32 + .., column = lane) += T^T * W, T in LDS planes (transposing reads), W = 16 register values of this
+// lane over the tile's 32 rows in accumulator order (split here)
+template <int E>
+__device__ __forceinline__ void x6_tileT_times_acc(f32x16 (&G)[(E + 31) / 32], const __bf16* T, const f32x16& w, int lane) {
+    constexpr int P = AbCfg<E>::P, PLANE = AbCfg<E>::PLANE, ED = (E + 31) / 32;
+    const int h = lane >> 5, u16 = lane & 15, q4 = u16 >> 2, p4 = u16 & 3, G1 = (lane >> 4) & 1;
+    const int off = (4 * h + q4) * P + 16 * G1 + 4 * p4;
+    bf16x8 W[3][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const float t[8] = {w[8 * s2], w[8 * s2 + 1], w[8 * s2 + 2], w[8 * s2 + 3], w[8 * s2 + 4], w[8 * s2 + 5], w[8 * s2 + 6],
+                            w[8 * s2 + 7]};
+        split3_x8(t, W[0][s2], W[1][s2], W[2][s2]);
+    }
+#pragma unroll
+    for (int d = 0; d < ED; ++d)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const __bf16* tp = T + (16 * s2) * P + off + d * 32;
+            const bf16x8 t0 = lds_tr8(tp, tp + 8 * P);
+            const bf16x8 t1 = lds_tr8(tp + PLANE, tp + PLANE + 8 * P);
+            const bf16x8 t2 = lds_tr8(tp + 2 * PLANE, tp + 2 * PLANE + 8 * P);
+            IGN_X6_PRODUCTS(G[d], t0, t1, t2, W[0][s2], W[1][s2], W[2][s2])
+        }
+}
+
+// rows t0 .. t0+31 of two (rows, H, E) fp32 tensors -> registers (zero past `nrows`); thread -> float4 piece (sr + RPP*p, sc)
+#define IGN_AB_GLOAD(t0_, nrows_, basea_, sla_, baseb_, slb_)                                        \
+    _Pragma("unroll") for (int p = 0; p < NP4; ++p) {                                                \
+        const int r_ = (t0_) + sr + RPP * p;                                                         \
+        const int rc_ = min(r_, (nrows_) - 1);                                                       \
+        float4 ta_ = *reinterpret_cast<const float4*>((basea_) + (long long)rc_ * (sla_) + sc);      \
+        float4 tb_ = *reinterpret_cast<const float4*>((baseb_) + (long long)rc_ * (slb_) + sc);      \
+        if (r_ >= (nrows_) || !stg) ta_ = tb_ = make_float4(0.f, 0.f, 0.f, 0.f);                     \
+        ra[p] = ta_; rb[p] = tb_;                                                                    \
+    }
+#define IGN_AB_STORE(Ta_, Tb_)                                                                       \
+    if (stg) {                                                                                       \
+        _Pragma("unroll") for (int p = 0; p < NP4; ++p) {                                            \
+            split3_store4(ra[p], (Ta_) + (sr + RPP * p) * P + sc, PLANE);                            \
+            split3_store4(rb[p], (Tb_) + (sr + RPP * p) * P + sc, PLANE);                            \
+        }                                                                                            \
+    }
+
+template <int E>
+__device__ __forceinline__ void store_grad_rows(float* dst, const f32x16 (&G)[(E + 31) / 32], float sc, int h) {
+#pragma unroll
+    for (int d = 0; d < (E + 31) / 32; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = d * 32 + 8 * g + 4 * h;
+            if (d0 < E)
+                *reinterpret_cast<float4*>(dst + d0) =
+                    make_float4(G[d][4 * g] * sc, G[d][4 * g + 1] * sc, G[d][4 * g + 2] * sc, G[d][4 * g + 3] * sc);
+        }
+}
+
+// ---- dQ: block = 4 waves x 32 queries (lanes); loops over key tiles.  S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta),
+// dQ^T += K^T dS^T, scaled once at the end.
+template <int E>
+__global__ void __launch_bounds__(256, 2) attn_bwd_dq_x6_kernel(const AttnX6BwdArgs a) {
+    constexpr int NS = E / 16, ED = (E + 31) / 32, P = AbCfg<E>::P, PLANE = AbCfg<E>::PLANE;
+    constexpr int V4 = AbCfg<E>::V4, RPP = AbCfg<E>::RPP, NP4 = AbCfg<E>::NP4;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    __bf16* Ks = reinterpret_cast<__bf16*>(smem16);
+    __bf16* Vs = Ks + 3 * PLANE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int qi = blockIdx.x * 128 + wave * 32 + l31;
+    const bool q_ok = qi < a.L;
+    const long long qrow = q_ok ? qi : a.L - 1;
+
+    bf16x8 Qf[3][NS], Gf[3][NS];
+    {
+        const float* qp = a.q + b * a.q_sb + qrow * a.q_sl + head * E + 8 * h;
+        const float* gp = a.go + (((long long)b * a.L + qrow) * a.H + head) * E + 8 * h;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            load_split8(qp + 16 * s, a.scale, Qf[0][s], Qf[1][s], Qf[2][s]);
+            load_split8(gp + 16 * s, 1.f, Gf[0][s], Gf[1][s], Gf[2][s]);
+        }
+    }
+    const float lse_q = a.lse[((long long)b * a.H + head) * a.L + qrow];
+    const float del_q = a.delta[((long long)b * a.H + head) * a.L + qrow];
+    f32x16 dQ[ED];
+#pragma unroll
+    for (int d = 0; d < ED; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dQ[d][r] = 0.f;
+
+    const float* kbase = a.k + b * a.k_sb + head * E;
+    const float* vbase = a.v + b * a.v_sb + head * E;
+    const int sr = threadIdx.x / V4, sc = (threadIdx.x - sr * V4) * 4;
+    const bool stg = sr < AB_T;
+    float4 ra[NP4], rb[NP4];
+    IGN_AB_GLOAD(0, a.S, kbase, a.k_sl, vbase, a.v_sl)
+    for (int kt0 = 0; kt0 < a.S; kt0 += AB_T) {
+        __syncthreads();
+        IGN_AB_STORE(Ks, Vs)
+        __syncthreads();
+        if (kt0 + AB_T < a.S) { IGN_AB_GLOAD(kt0 + AB_T, a.S, kbase, a.k_sl, vbase, a.v_sl) }
+        f32x16 st, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+        x6_rows_times_regs<E>(st, Ks, Qf, l31, h);
+        x6_rows_times_regs<E>(dp, Vs, Gf, l31, h);
+        // rows = keys kt0 + acc_row(r,h), column = this lane's query
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = (kt0 + acc_row(r, h) < a.S) ? __expf(st[r] - lse_q) : 0.f;
+            dp[r] = p * (dp[r] - del_q);
+        }
+        x6_tileT_times_acc<E>(dQ, Ks, dp, lane);
+    }
+    if (q_ok) store_grad_rows<E>(a.gq + (((long long)b * a.L + qi) * a.H + head) * E, dQ, a.scale, h);
+}
+
+// ---- dK / dV: block = 4 waves x 32 keys (lanes); loops over query tiles.  S = Q K^T (rows = queries), P = exp(S - lse);
+//   DV:  dV^T += dO^T P                                   (K^T in registers)
+//   !DV: dP = dO V^T, dS = P (dP - delta), dK^T += Q^T dS  (K^T and V^T in registers), scaled once at the end
+template <int E, bool DV>
+__global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6BwdArgs a) {
+    constexpr int NS = E / 16, ED = (E + 31) / 32, P = AbCfg<E>::P, PLANE = AbCfg<E>::PLANE;
+    constexpr int V4 = AbCfg<E>::V4, RPP = AbCfg<E>::RPP, NP4 = AbCfg<E>::NP4;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    __bf16* Qs = reinterpret_cast<__bf16*>(smem16);
+    __bf16* Gs = Qs + 3 * PLANE;
+    float* Ls = reinterpret_cast<float*>(Gs + 3 * PLANE);          // lse[32], delta[32] of the tile's queries
+    float* Ds = Ls + AB_T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int ki = blockIdx.x * 128 + wave * 32 + l31;
+    const bool k_ok = ki < a.S;
+    const long long krow = k_ok ? ki : a.S - 1;
+
+    bf16x8 Kf[3][NS], Vf[3][DV ? 1 : NS];
+    {
+        const float* kp = a.k + b * a.k_sb + krow * a.k_sl + head * E + 8 * h;
+        const float* vp = a.v + b * a.v_sb + krow * a.v_sl + head * E + 8 * h;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            load_split8(kp + 16 * s, a.scale, Kf[0][s], Kf[1][s], Kf[2][s]);
+            if constexpr (!DV) load_split8(vp + 16 * s, 1.f, Vf[0][s], Vf[1][s], Vf[2][s]);
+        }
+    }
+    f32x16 G[ED];
+#pragma unroll
+    for (int d = 0; d < ED; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) G[d][r] = 0.f;
+
+    const float* qbase = a.q + b * a.q_sb + head * E;
+    const float* gbase = a.go + (long long)b * a.L * a.H * E + head * E;
+    const long long g_sl = (long long)a.H * E;
+    const float* lse_b = a.lse + ((long long)b * a.H + head) * a.L;
+    const float* del_b = a.delta + ((long long)b * a.H + head) * a.L;
+    const int sr = threadIdx.x / V4, sc = (threadIdx.x - sr * V4) * 4;
+    const bool stg = sr < AB_T;
+    float4 ra[NP4], rb[NP4];
+    float rl = 0.f;
+    IGN_AB_GLOAD(0, a.L, qbase, a.q_sl, gbase, g_sl)
+    if (threadIdx.x < 2 * AB_T) {
+        const int q = threadIdx.x & (AB_T - 1);
+        rl = q < a.L ? (threadIdx.x < AB_T ? lse_b[q] : del_b[q]) : (threadIdx.x < AB_T ? INFINITY : 0.f);
+    }
+    for (int qt0 = 0; qt0 < a.L; qt0 += AB_T) {
+        __syncthreads();
+        IGN_AB_STORE(Qs, Gs)
+        if (threadIdx.x < 2 * AB_T) Ls[threadIdx.x] = rl;            // Ls and Ds are contiguous
+        __syncthreads();
+        if (qt0 + AB_T < a.L) {
+            IGN_AB_GLOAD(qt0 + AB_T, a.L, qbase, a.q_sl, gbase, g_sl)
+            if (threadIdx.x < 2 * AB_T) {
+                const int q = qt0 + AB_T + (threadIdx.x & (AB_T - 1));
+                rl = q < a.L ? (threadIdx.x < AB_T ? lse_b[q] : del_b[q]) : (threadIdx.x < AB_T ? INFINITY : 0.f);
+            }
+        }
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        x6_rows_times_regs<E>(s, Qs, Kf, l31, h);
+        // rows = queries qt0 + acc_row(r,h) (padded queries carry lse = inf: p = 0), column = this lane's key
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 lv = *reinterpret_cast<const float4*>(Ls + 8 * g + 4 * h);
+            s[4 * g] = k_ok ? __expf(s[4 * g] - lv.x) : 0.f;
+            s[4 * g + 1] = k_ok ? __expf(s[4 * g + 1] - lv.y) : 0.f;
+            s[4 * g + 2] = k_ok ? __expf(s[4 * g + 2] - lv.z) : 0.f;
+            s[4 * g + 3] = k_ok ? __expf(s[4 * g + 3] - lv.w) : 0.f;
+        }
+        if constexpr (DV) {
+            x6_tileT_times_acc<E>(G, Gs, s, lane);
+        } else {
+            f32x16 dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+            x6_rows_times_regs<E>(dp, Gs, Vf, l31, h);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 dv = *reinterpret_cast<const float4*>(Ds + 8 * g + 4 * h);
+                dp[4 * g] = s[4 * g] * (dp[4 * g] - dv.x);
+                dp[4 * g + 1] = s[4 * g + 1] * (dp[4 * g + 1] - dv.y);
+                dp[4 * g + 2] = s[4 * g + 2] * (dp[4 * g + 2] - dv.z);
+                dp[4 * g + 3] = s[4 * g + 3] * (dp[4 * g + 3] - dv.w);
+            }
+            x6_tileT_times_acc<E>(G, Qs, dp, lane);
+        }
+    }
+    if (k_ok) {
+        float* dst = (DV ? a.gv : a.gk) + (((long long)b * a.S + ki) * a.H + head) * E;
+        store_grad_rows<E>(dst, G, DV ? 1.f : a.scale, h);
+    }
+}
+
+// delta[b,h,l] = sum_e dO * O (same as attn_delta_kernel)
+__global__ void __launch_bounds__(256) attn_delta_x6_kernel(const float* __restrict__ o, const float* __restrict__ go,
+                                                            float* __restrict__ delta, int B, int L, int H, int E) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;      // over (b, l, h)
+    if (idx >= (long long)B * L * H) return;
+    const float* po = o + idx * E;
+    const float* pg = go + idx * E;
+    float s = 0.f;
+    for (int e = 0; e < E; e += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(po + e);
+        const float4 y = *reinterpret_cast<const float4*>(pg + e);
+        s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    const int hh = (int)(idx % H);
+    const long long bl = idx / H;
+    delta[((long long)(bl / L) * H + hh) * L + (int)(bl % L)] = s;
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" int ign_attn_fwd_x6(const float* q, const float* k, const float* v, float* out, float* lse, int B, int L, int S, int H,
                                int E, long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb,
@@ -278,4 +567,71 @@ extern "C" int ign_attn_fwd_x6(const float* q, const float* k, const float* v, f
     }
 #undef IGN_AX
     return ign_check_launch("attn_fwd_x6_kernel");
+}
+
+extern "C" int ign_attn_bwd_x6(const float* q, const float* k, const float* v, const float* out, const float* lse,
+                               const float* gout, float* gq, float* gk, float* gv, float* delta_ws, int B, int L, int S, int H,
+                               int E, long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb,
+                               long long v_sl, float scale, void* stream) {
+    static const char* who = "ign_attn_bwd_x6";
+    if (B <= 0 || L <= 0 || S <= 0 || H <= 0 || H > 65535 || B > 65535) {
+        ign_set_error("%s: bad dimensions B=%d L=%d S=%d H=%d", who, B, L, S, H);
+        return IGN_E_ARG;
+    }
+    if (E != 16 && E != 32 && E != 64 && E != 128) {
+        ign_set_error("%s: head dimension E=%d not instantiated (16, 32, 64, 128)", who, E);
+        return IGN_E_UNSUP;
+    }
+    const void* ptrs[10] = {q, k, v, out, lse, gout, gq, gk, gv, delta_ws};
+    for (int i = 0; i < 10; ++i)
+        if (!ptrs[i] || ((uintptr_t)ptrs[i] & 15)) {
+            ign_set_error("%s: pointer %d is null or not 16-byte aligned", who, i);
+            return IGN_E_ARG;
+        }
+    const long long st[6] = {q_sb, q_sl, k_sb, k_sl, v_sb, v_sl};
+    for (int i = 0; i < 6; ++i)
+        if (st[i] <= 0 || (st[i] & 3)) {
+            ign_set_error("%s: stride %d = %lld must be a positive multiple of 4 elements", who, i, st[i]);
+            return IGN_E_ARG;
+        }
+    hipStream_t s = (hipStream_t)stream;
+    AttnX6BwdArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.go = gout; a.lse = lse; a.delta = delta_ws; a.gq = gq; a.gk = gk; a.gv = gv;
+    a.q_sb = q_sb; a.q_sl = q_sl; a.k_sb = k_sb; a.k_sl = k_sl; a.v_sb = v_sb; a.v_sl = v_sl;
+    a.B = B; a.L = L; a.S = S; a.H = H; a.E = E; a.scale = scale;
+    int rc;
+    {
+        const long long n = (long long)B * L * H;
+        IgnScopedTimer tm("attn_delta", s);
+        hipLaunchKernelGGL(attn_delta_x6_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, gout, delta_ws, B, L, H, E);
+    }
+    if ((rc = ign_check_launch("attn_delta_x6_kernel"))) return rc;
+    const dim3 gk_grid((S + 127) / 128, H, B), gq_grid((L + 127) / 128, H, B);
+#define IGN_AB(EE, KERNEL, GRID)                                                                                              \
+    do {                                                                                                                      \
+        static bool once = false;                                                                                             \
+        if (!once) {                                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                      (int)AbCfg<EE>::LDS);                                                                   \
+            once = true;                                                                                                      \
+        }                                                                                                                     \
+        hipLaunchKernelGGL(KERNEL, GRID, dim3(256), AbCfg<EE>::LDS, s, a);                                                    \
+    } while (0)
+#define IGN_AB_ALL(EE)                                                                                                        \
+    do {                                                                                                                      \
+        { IgnScopedTimer tm("attn_bwd_dkdv", s);                                                                              \
+          IGN_AB(EE, (attn_bwd_dkv_x6_kernel<EE, true>), gk_grid);                                                            \
+          IGN_AB(EE, (attn_bwd_dkv_x6_kernel<EE, false>), gk_grid); }                                                         \
+        { IgnScopedTimer tm("attn_bwd_dq", s);                                                                                \
+          IGN_AB(EE, (attn_bwd_dq_x6_kernel<EE>), gq_grid); }                                                                 \
+    } while (0)
+    switch (E) {
+        case 16: IGN_AB_ALL(16); break;
+        case 32: IGN_AB_ALL(32); break;
+        case 64: IGN_AB_ALL(64); break;
+        default: IGN_AB_ALL(128); break;
+    }
+#undef IGN_AB_ALL
+#undef IGN_AB
+    return ign_check_launch("attn_bwd_x6 kernels");
 }

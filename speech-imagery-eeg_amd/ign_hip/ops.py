@@ -10,7 +10,7 @@ import os
 
 DIST_L1, DIST_MSE, DIST_COS, DIST_PEARSON = 0, 1, 2, 3
 LINEAR_IMPL = os.environ.get("IGN_LINEAR", "hip")      # "torch": route ops.linear to hipBLASLt (A/B measurements)
-ATTN_MATH = os.environ.get("IGN_ATTN_MATH", "bf16x6")          # "f32": attention forward on the fp32-MFMA kernel
+ATTN_MATH = os.environ.get("IGN_ATTN_MATH", "bf16x6")          # "f32": attention core on the fp32-MFMA kernels
 LINEAR_WGRAD = os.environ.get("IGN_LINEAR_WGRAD", "bf16x6")   # "f32": weight gradient of ops.linear on the fp32-MFMA TN kernel
 GATE_RBF, GATE_LTS = 0x00, 0x10
 
@@ -186,9 +186,10 @@ class AttentionFn(torch.autograd.Function):
         gv = torch.empty_like(gk)
         delta = torch.empty(B, H, L, device=q.device, dtype=torch.float32)
         (qb, ql), (kb, kl), (vb, vl) = _bl_strides(q, "q"), _bl_strides(k, "k"), _bl_strides(v, "v")
-        _lib.check(_lib.lib().ign_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(gout), _ptr(gq), _ptr(gk),
-                                           _ptr(gv), _ptr(delta), B, L, S, H, E, qb, ql, kb, kl, vb, vl, ctx.scale,
-                                           _stream()), "ign_attn_bwd")
+        # split-bf16 kernels up to E = 64 (E = 128 exceeds their register budget: the fp32-MFMA backward is faster there)
+        bwd = _lib.lib().ign_attn_bwd_x6 if (ATTN_MATH == "bf16x6" and E <= 64) else _lib.lib().ign_attn_bwd
+        _lib.check(bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(gout), _ptr(gq), _ptr(gk), _ptr(gv), _ptr(delta),
+                       B, L, S, H, E, qb, ql, kb, kl, vb, vl, ctx.scale, _stream()), "ign_attn_bwd")
         return gq, gk, gv, None
 
 

@@ -24,6 +24,14 @@ for (B, L, H, E) in [(256, 1000, 8, 64), (256, 100, 8, 64), (64, 1000, 4, 128), 
         with torch.no_grad():
             t = timeit(lambda: ops.attention(q, k, v, 1 / math.sqrt(E)))
             res[m] = (t, ops.attention(q, k, v, 1 / math.sqrt(E)))
+    for m in ("f32", "bf16x6"):
+        ops.ATTN_MATH = m
+        qg, kg, vg = (t.clone().requires_grad_(True) for t in (q, k, v))
+        o = ops.attention(qg, kg, vg, 1 / math.sqrt(E))
+        go = torch.randn_like(o)
+        tb = timeit(lambda: torch.autograd.grad(o, (qg, kg, vg), go, retain_graph=True))
+        res[m] = res[m] + (tb,)
+    print(f"   backward: f32 {res['f32'][2]:.3f} ms  bf16x6 {res['bf16x6'][2]:.3f} ms", flush=True)
     d = float((res["f32"][1] - res["bf16x6"][1]).abs().max() / res["f32"][1].abs().max())
     print(f"B={B} L={L} H={H} E={E}: f32 {res['f32'][0]:.3f} ms ({flops/res['f32'][0]/1e9:.0f} TFLOP/s)  "
           f"bf16x6 {res['bf16x6'][0]:.3f} ms ({flops/res['bf16x6'][0]/1e9:.0f} TFLOP/s-equiv)  max rel diff {d:.1e}", flush=True)
