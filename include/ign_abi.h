@@ -118,6 +118,16 @@ int ign_attn_bwd_x6(const float* q, const float* k, const float* v, const float*
                  int B, int L, int S, int H, int E,
                  long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl,
                  float scale, void* stream);
+/* Both with ONE product per MFMA step on operands rounded to bf16 (Q, K, V, P, dO, dS; fp32 accumulation and softmax): what the
+ * reference's default bf16-autocast mode computes for the two attention matmuls.  Same arguments and outputs.             */
+int ign_attn_fwd_bf16(const float* q, const float* k, const float* v, float* out, float* lse, int B, int L, int S, int H, int E,
+                    long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl,
+                    float scale, void* stream);
+int ign_attn_bwd_bf16(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* gout,
+                 float* gq, float* gk, float* gv, float* delta_ws,
+                 int B, int L, int S, int H, int E,
+                 long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl,
+                 float scale, void* stream);
 
 /* Skinny expert-head GEMM  out[b,n] = sum_f X[b,f] W[n,f] (+ bias[n]),  N <= 16 classes, F % 4 == 0, row pitch ldx.
  * Replaces nn.Linear at IGN/model/Shapelet.py:171,200 (SBM head), IGN/model/Transformer.py:72,109,

@@ -43,8 +43,19 @@ __device__ __forceinline__ void split3_pair(f32x2 v, bf16x2& x0, bf16x2& x1, bf1
     r -= __builtin_convertvector(x1, f32x2);
     x2 = __builtin_convertvector(r, bf16x2);
 }
-// eight values -> one bf16x8 MFMA operand per plane
-__device__ __forceinline__ void split3_x8(const float (&t)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+// eight values -> one bf16x8 MFMA operand per plane.  NP = 3: the exact three-way split (six products, fp32 accuracy);
+// NP = 1: the values rounded to bf16 (one product: the arithmetic of the reference's bf16-autocast mode); p1, p2 stay unused.
+template <int NP>
+__device__ __forceinline__ void splitN_x8(const float (&t)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    if constexpr (NP == 1) {
+        bf16x2 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = __builtin_convertvector(f32x2{t[2 * i], t[2 * i + 1]}, bf16x2);
+        p0 = __builtin_shufflevector(__builtin_shufflevector(a[0], a[1], 0, 1, 2, 3), __builtin_shufflevector(a[2], a[3], 0, 1, 2, 3),
+                                     0, 1, 2, 3, 4, 5, 6, 7);
+        p1 = p0; p2 = p0;
+        return;
+    }
     bf16x2 a[4], b[4], c[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) split3_pair(f32x2{t[2 * i], t[2 * i + 1]}, a[i], b[i], c[i]);
@@ -64,9 +75,15 @@ __device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// four values -> three LDS planes `plane` elements apart (8-byte stores)
-__device__ __forceinline__ void split3_store4(const float4 t, __bf16* d, int plane) {
+// four values -> NP LDS planes `plane` elements apart (8-byte stores)
+template <int NP>
+__device__ __forceinline__ void splitN_store4(const float4 t, __bf16* d, int plane) {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    if constexpr (NP == 1) {
+        const bf16x2 a = __builtin_convertvector(f32x2{t.x, t.y}, bf16x2), b = __builtin_convertvector(f32x2{t.z, t.w}, bf16x2);
+        *reinterpret_cast<bf16x4*>(d) = __builtin_shufflevector(a, b, 0, 1, 2, 3);
+        return;
+    }
     bf16x2 a0, a1, a2, b0, b1, b2;
     split3_pair(f32x2{t.x, t.y}, a0, a1, a2);
     split3_pair(f32x2{t.z, t.w}, b0, b1, b2);
@@ -81,7 +98,7 @@ template <int E> struct AxPitch {
     static constexpr int V = E >= 64 ? E + 32 : E + E / 2;        // transposing reads: rows 0..3 of a block 16 banks apart
 };
 
-template <int E>
+template <int E, int NP>
 __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a) {
     constexpr int NS = E / 16, ED = (E + 31) / 32, PK = AxPitch<E>::K, PV = AxPitch<E>::V, AX_KT = AxPitch<E>::KT;
     constexpr int KPLANE = AX_KT * PK, VPLANE = AX_KT * PV;
@@ -104,7 +121,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
             const float4 t1 = *reinterpret_cast<const float4*>(qp + 16 * s + 4);
             const float t[8] = {t0.x * a.scale, t0.y * a.scale, t0.z * a.scale, t0.w * a.scale,
                                 t1.x * a.scale, t1.y * a.scale, t1.z * a.scale, t1.w * a.scale};
-            split3_x8(t, Qf[0][s], Qf[1][s], Qf[2][s]);
+            splitN_x8<NP>(t, Qf[0][s], Qf[1][s], Qf[2][s]);
         }
     }
     f32x16 O[ED];
@@ -138,8 +155,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
         __syncthreads();                                           // every wave is done with the previous tile
 #pragma unroll
         for (int p = 0; p < NP4; ++p) {
-            split3_store4(rk[p], Ks + (sr + RPP * p) * PK + sc, KPLANE);
-            split3_store4(rv[p], Vs + (sr + RPP * p) * PV + sc, VPLANE);
+            splitN_store4<NP>(rk[p], Ks + (sr + RPP * p) * PK + sc, KPLANE);
+            splitN_store4<NP>(rv[p], Vs + (sr + RPP * p) * PV + sc, VPLANE);
         }
         __syncthreads();
         if (kt0 + AX_KT < a.S) { IGN_GLOAD(kt0 + AX_KT) }          // lands behind this tile's MFMAs
@@ -156,11 +173,13 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
                     const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kr + 16 * s);
                     const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kr + KPLANE + 16 * s);
                     const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(kr + 2 * KPLANE + 16 * s);
-                    acc = MFMA16(k2, Qf[0][s], acc);
-                    acc = MFMA16(k0, Qf[2][s], acc);
-                    acc = MFMA16(k1, Qf[1][s], acc);
-                    acc = MFMA16(k1, Qf[0][s], acc);
-                    acc = MFMA16(k0, Qf[1][s], acc);
+                    if constexpr (NP == 3) {
+                        acc = MFMA16(k2, Qf[0][s], acc);
+                        acc = MFMA16(k0, Qf[2][s], acc);
+                        acc = MFMA16(k1, Qf[1][s], acc);
+                        acc = MFMA16(k1, Qf[0][s], acc);
+                        acc = MFMA16(k0, Qf[1][s], acc);
+                    }
                     acc = MFMA16(k0, Qf[0][s], acc);
                 }
                 // online softmax over this lane's 16 keys + the partner half's 16 keys
@@ -188,7 +207,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const float t[8] = {acc[8 * s2], acc[8 * s2 + 1], acc[8 * s2 + 2], acc[8 * s2 + 3],
                                         acc[8 * s2 + 4], acc[8 * s2 + 5], acc[8 * s2 + 6], acc[8 * s2 + 7]};
-                    split3_x8(t, Pf[0][s2], Pf[1][s2], Pf[2][s2]);
+                    splitN_x8<NP>(t, Pf[0][s2], Pf[1][s2], Pf[2][s2]);
                 }
 #pragma unroll
                 for (int d = 0; d < ED; ++d) {
@@ -200,11 +219,13 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
                         const bf16x8 v0 = lds_tr8(vp, vp + 8 * PV);
                         const bf16x8 v1 = lds_tr8(vp + VPLANE, vp + VPLANE + 8 * PV);
                         const bf16x8 v2 = lds_tr8(vp + 2 * VPLANE, vp + 2 * VPLANE + 8 * PV);
-                        O[d] = MFMA16(v2, Pf[0][s2], O[d]);
-                        O[d] = MFMA16(v0, Pf[2][s2], O[d]);
-                        O[d] = MFMA16(v1, Pf[1][s2], O[d]);
-                        O[d] = MFMA16(v1, Pf[0][s2], O[d]);
-                        O[d] = MFMA16(v0, Pf[1][s2], O[d]);
+                        if constexpr (NP == 3) {
+                            O[d] = MFMA16(v2, Pf[0][s2], O[d]);
+                            O[d] = MFMA16(v0, Pf[2][s2], O[d]);
+                            O[d] = MFMA16(v1, Pf[1][s2], O[d]);
+                            O[d] = MFMA16(v1, Pf[0][s2], O[d]);
+                            O[d] = MFMA16(v0, Pf[1][s2], O[d]);
+                        }
                         O[d] = MFMA16(v0, Pf[0][s2], O[d]);
                     }
                 }
@@ -253,23 +274,26 @@ template <int E> struct AbCfg {
 };
 
 // eight consecutive fp32 values (two float4) -> the three bf16x8 planes of an MFMA operand, optional scale
+template <int NP>
 __device__ __forceinline__ void load_split8(const float* p, float sc, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
     const float4 t0 = *reinterpret_cast<const float4*>(p);
     const float4 t1 = *reinterpret_cast<const float4*>(p + 4);
     const float t[8] = {t0.x * sc, t0.y * sc, t0.z * sc, t0.w * sc, t1.x * sc, t1.y * sc, t1.z * sc, t1.w * sc};
-    split3_x8(t, p0, p1, p2);
+    splitN_x8<NP>(t, p0, p1, p2);
 }
 
 #define IGN_X6_PRODUCTS(acc_, a0, a1, a2, b0, b1, b2)  \
-    acc_ = MFMA16(a2, b0, acc_);                       \
-    acc_ = MFMA16(a0, b2, acc_);                       \
-    acc_ = MFMA16(a1, b1, acc_);                       \
-    acc_ = MFMA16(a1, b0, acc_);                       \
-    acc_ = MFMA16(a0, b1, acc_);                       \
+    if constexpr (NP == 3) {                           \
+        acc_ = MFMA16(a2, b0, acc_);                   \
+        acc_ = MFMA16(a0, b2, acc_);                   \
+        acc_ = MFMA16(a1, b1, acc_);                   \
+        acc_ = MFMA16(a1, b0, acc_);                   \
+        acc_ = MFMA16(a0, b1, acc_);                   \
+    }                                                  \
     acc_ = MFMA16(a0, b0, acc_);
 
 // acc (rows = tile rows, column = lane) += T[32 rows][E] * F^T, T in LDS planes (row-wise reads), F this lane's register planes
-template <int E>
+template <int E, int NP>
 __device__ __forceinline__ void x6_rows_times_regs(f32x16& acc, const __bf16* T, const bf16x8 (&F)[3][E / 16], int l31, int h) {
     constexpr int P = AbCfg<E>::P, PLANE = AbCfg<E>::PLANE;
     const __bf16* tr = T + l31 * P + 8 * h;
@@ -284,7 +308,7 @@ __device__ __forceinline__ void x6_rows_times_regs(f32x16& acc, const __bf16* T,
 
 // G[d] (rows = feature d*32 + .., column = lane) += T^T * W, T in LDS planes (transposing reads), W = 16 register values of this
 // lane over the tile's 32 rows in accumulator order (split here)
-template <int E>
+template <int E, int NP>
 __device__ __forceinline__ void x6_tileT_times_acc(f32x16 (&G)[(E + 31) / 32], const __bf16* T, const f32x16& w, int lane) {
     constexpr int P = AbCfg<E>::P, PLANE = AbCfg<E>::PLANE, ED = (E + 31) / 32;
     const int h = lane >> 5, u16 = lane & 15, q4 = u16 >> 2, p4 = u16 & 3, G1 = (lane >> 4) & 1;
@@ -294,7 +318,7 @@ __device__ __forceinline__ void x6_tileT_times_acc(f32x16 (&G)[(E + 31) / 32], c
     for (int s2 = 0; s2 < 2; ++s2) {
         const float t[8] = {w[8 * s2], w[8 * s2 + 1], w[8 * s2 + 2], w[8 * s2 + 3], w[8 * s2 + 4], w[8 * s2 + 5], w[8 * s2 + 6],
                             w[8 * s2 + 7]};
-        split3_x8(t, W[0][s2], W[1][s2], W[2][s2]);
+        splitN_x8<NP>(t, W[0][s2], W[1][s2], W[2][s2]);
     }
 #pragma unroll
     for (int d = 0; d < ED; ++d)
@@ -321,8 +345,8 @@ __device__ __forceinline__ void x6_tileT_times_acc(f32x16 (&G)[(E + 31) / 32], c
 #define IGN_AB_STORE(Ta_, Tb_)                                                                       \
     if (stg) {                                                                                       \
         _Pragma("unroll") for (int p = 0; p < NP4; ++p) {                                            \
-            split3_store4(ra[p], (Ta_) + (sr + RPP * p) * P + sc, PLANE);                            \
-            split3_store4(rb[p], (Tb_) + (sr + RPP * p) * P + sc, PLANE);                            \
+            splitN_store4<NP>(ra[p], (Ta_) + (sr + RPP * p) * P + sc, PLANE);                            \
+            splitN_store4<NP>(rb[p], (Tb_) + (sr + RPP * p) * P + sc, PLANE);                            \
         }                                                                                            \
     }
 
@@ -341,7 +365,7 @@ __device__ __forceinline__ void store_grad_rows(float* dst, const f32x16 (&G)[(E
 
 // ---- dQ: block = 4 waves x 32 queries (lanes); loops over key tiles.  S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta),
 // dQ^T += K^T dS^T, scaled once at the end.
-template <int E>
+template <int E, int NP>
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_x6_kernel(const AttnX6BwdArgs a) {
     constexpr int NS = E / 16, ED = (E + 31) / 32, P = AbCfg<E>::P, PLANE = AbCfg<E>::PLANE;
     constexpr int V4 = AbCfg<E>::V4, RPP = AbCfg<E>::RPP, NP4 = AbCfg<E>::NP4;
@@ -361,8 +385,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_x6_kernel(const AttnX6BwdA
         const float* gp = a.go + (((long long)b * a.L + qrow) * a.H + head) * E + 8 * h;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            load_split8(qp + 16 * s, a.scale, Qf[0][s], Qf[1][s], Qf[2][s]);
-            load_split8(gp + 16 * s, 1.f, Gf[0][s], Gf[1][s], Gf[2][s]);
+            load_split8<NP>(qp + 16 * s, a.scale, Qf[0][s], Qf[1][s], Qf[2][s]);
+            load_split8<NP>(gp + 16 * s, 1.f, Gf[0][s], Gf[1][s], Gf[2][s]);
         }
     }
     const float lse_q = a.lse[((long long)b * a.H + head) * a.L + qrow];
@@ -387,15 +411,15 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_x6_kernel(const AttnX6BwdA
         f32x16 st, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
-        x6_rows_times_regs<E>(st, Ks, Qf, l31, h);
-        x6_rows_times_regs<E>(dp, Vs, Gf, l31, h);
+        x6_rows_times_regs<E, NP>(st, Ks, Qf, l31, h);
+        x6_rows_times_regs<E, NP>(dp, Vs, Gf, l31, h);
         // rows = keys kt0 + acc_row(r,h), column = this lane's query
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float p = (kt0 + acc_row(r, h) < a.S) ? __expf(st[r] - lse_q) : 0.f;
             dp[r] = p * (dp[r] - del_q);
         }
-        x6_tileT_times_acc<E>(dQ, Ks, dp, lane);
+        x6_tileT_times_acc<E, NP>(dQ, Ks, dp, lane);
     }
     if (q_ok) store_grad_rows<E>(a.gq + (((long long)b * a.L + qi) * a.H + head) * E, dQ, a.scale, h);
 }
@@ -403,7 +427,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_x6_kernel(const AttnX6BwdA
 // ---- dK / dV: block = 4 waves x 32 keys (lanes); loops over query tiles.  S = Q K^T (rows = queries), P = exp(S - lse);
 //   DV:  dV^T += dO^T P                                   (K^T in registers)
 //   !DV: dP = dO V^T, dS = P (dP - delta), dK^T += Q^T dS  (K^T and V^T in registers), scaled once at the end
-template <int E, bool DV>
+template <int E, bool DV, int NP>
 __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6BwdArgs a) {
     constexpr int NS = E / 16, ED = (E + 31) / 32, P = AbCfg<E>::P, PLANE = AbCfg<E>::PLANE;
     constexpr int V4 = AbCfg<E>::V4, RPP = AbCfg<E>::RPP, NP4 = AbCfg<E>::NP4;
@@ -425,8 +449,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
         const float* vp = a.v + b * a.v_sb + krow * a.v_sl + head * E + 8 * h;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            load_split8(kp + 16 * s, a.scale, Kf[0][s], Kf[1][s], Kf[2][s]);
-            if constexpr (!DV) load_split8(vp + 16 * s, 1.f, Vf[0][s], Vf[1][s], Vf[2][s]);
+            load_split8<NP>(kp + 16 * s, a.scale, Kf[0][s], Kf[1][s], Kf[2][s]);
+            if constexpr (!DV) load_split8<NP>(vp + 16 * s, 1.f, Vf[0][s], Vf[1][s], Vf[2][s]);
         }
     }
     f32x16 G[ED];
@@ -464,7 +488,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        x6_rows_times_regs<E>(s, Qs, Kf, l31, h);
+        x6_rows_times_regs<E, NP>(s, Qs, Kf, l31, h);
         // rows = queries qt0 + acc_row(r,h) (padded queries carry lse = inf: p = 0), column = this lane's key
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -475,12 +499,12 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
             s[4 * g + 3] = k_ok ? __expf(s[4 * g + 3] - lv.w) : 0.f;
         }
         if constexpr (DV) {
-            x6_tileT_times_acc<E>(G, Gs, s, lane);
+            x6_tileT_times_acc<E, NP>(G, Gs, s, lane);
         } else {
             f32x16 dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dp[r] = 0.f;
-            x6_rows_times_regs<E>(dp, Gs, Vf, l31, h);
+            x6_rows_times_regs<E, NP>(dp, Gs, Vf, l31, h);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 dv = *reinterpret_cast<const float4*>(Ds + 8 * g + 4 * h);
@@ -489,7 +513,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
                 dp[4 * g + 2] = s[4 * g + 2] * (dp[4 * g + 2] - dv.z);
                 dp[4 * g + 3] = s[4 * g + 3] * (dp[4 * g + 3] - dv.w);
             }
-            x6_tileT_times_acc<E>(G, Qs, dp, lane);
+            x6_tileT_times_acc<E, NP>(G, Qs, dp, lane);
         }
     }
     if (k_ok) {
@@ -517,10 +541,10 @@ __global__ void __launch_bounds__(256) attn_delta_x6_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
-extern "C" int ign_attn_fwd_x6(const float* q, const float* k, const float* v, float* out, float* lse, int B, int L, int S, int H,
-                               int E, long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb,
-                               long long v_sl, float scale, void* stream) {
-    static const char* who = "ign_attn_fwd_x6";
+template <int NP>
+static int attn_fwd_x6_impl(const char* who, const float* q, const float* k, const float* v, float* out, float* lse, int B, int L,
+                            int S, int H, int E, long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb,
+                            long long v_sl, float scale, void* stream) {
     if (B <= 0 || L <= 0 || S <= 0 || H <= 0 || H > 65535 || B > 65535) {
         ign_set_error("%s: bad dimensions B=%d L=%d S=%d H=%d", who, B, L, S, H);
         return IGN_E_ARG;
@@ -553,11 +577,11 @@ extern "C" int ign_attn_fwd_x6(const float* q, const float* k, const float* v, f
         constexpr size_t lds = (size_t)3 * AxPitch<EE>::KT * (AxPitch<EE>::K + AxPitch<EE>::V) * sizeof(unsigned short) + 256; \
         static bool once = false;                                                                                             \
         if (!once) {                                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_x6_kernel<EE>),                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_x6_kernel<EE, NP>),                              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
             once = true;                                                                                                      \
         }                                                                                                                     \
-        hipLaunchKernelGGL((attn_fwd_x6_kernel<EE>), grid, dim3(256), lds, s, a);                                             \
+        hipLaunchKernelGGL((attn_fwd_x6_kernel<EE, NP>), grid, dim3(256), lds, s, a);                                         \
     } while (0)
     switch (E) {
         case 16: IGN_AX(16); break;
@@ -569,11 +593,11 @@ extern "C" int ign_attn_fwd_x6(const float* q, const float* k, const float* v, f
     return ign_check_launch("attn_fwd_x6_kernel");
 }
 
-extern "C" int ign_attn_bwd_x6(const float* q, const float* k, const float* v, const float* out, const float* lse,
-                               const float* gout, float* gq, float* gk, float* gv, float* delta_ws, int B, int L, int S, int H,
-                               int E, long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb,
-                               long long v_sl, float scale, void* stream) {
-    static const char* who = "ign_attn_bwd_x6";
+template <int NP>
+static int attn_bwd_x6_impl(const char* who, const float* q, const float* k, const float* v, const float* out, const float* lse,
+                            const float* gout, float* gq, float* gk, float* gv, float* delta_ws, int B, int L, int S, int H,
+                            int E, long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb,
+                            long long v_sl, float scale, void* stream) {
     if (B <= 0 || L <= 0 || S <= 0 || H <= 0 || H > 65535 || B > 65535) {
         ign_set_error("%s: bad dimensions B=%d L=%d S=%d H=%d", who, B, L, S, H);
         return IGN_E_ARG;
@@ -620,10 +644,10 @@ extern "C" int ign_attn_bwd_x6(const float* q, const float* k, const float* v, c
 #define IGN_AB_ALL(EE)                                                                                                        \
     do {                                                                                                                      \
         { IgnScopedTimer tm("attn_bwd_dkdv", s);                                                                              \
-          IGN_AB(EE, (attn_bwd_dkv_x6_kernel<EE, true>), gk_grid);                                                            \
-          IGN_AB(EE, (attn_bwd_dkv_x6_kernel<EE, false>), gk_grid); }                                                         \
+          IGN_AB(EE, (attn_bwd_dkv_x6_kernel<EE, true, NP>), gk_grid);                                                        \
+          IGN_AB(EE, (attn_bwd_dkv_x6_kernel<EE, false, NP>), gk_grid); }                                                     \
         { IgnScopedTimer tm("attn_bwd_dq", s);                                                                                \
-          IGN_AB(EE, (attn_bwd_dq_x6_kernel<EE>), gq_grid); }                                                                 \
+          IGN_AB(EE, (attn_bwd_dq_x6_kernel<EE, NP>), gq_grid); }                                                             \
     } while (0)
     switch (E) {
         case 16: IGN_AB_ALL(16); break;
@@ -634,4 +658,26 @@ extern "C" int ign_attn_bwd_x6(const float* q, const float* k, const float* v, c
 #undef IGN_AB_ALL
 #undef IGN_AB
     return ign_check_launch("attn_bwd_x6 kernels");
+}
+
+#define IGN_ATTN_FWD_ARGS const float* q, const float* k, const float* v, float* out, float* lse, int B, int L, int S, int H, int E, \
+    long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl, float scale, void* stream
+#define IGN_ATTN_BWD_ARGS const float* q, const float* k, const float* v, const float* out, const float* lse, const float* gout, \
+    float* gq, float* gk, float* gv, float* delta_ws, int B, int L, int S, int H, int E, long long q_sb, long long q_sl,          \
+    long long k_sb, long long k_sl, long long v_sb, long long v_sl, float scale, void* stream
+extern "C" int ign_attn_fwd_x6(IGN_ATTN_FWD_ARGS) {
+    return attn_fwd_x6_impl<3>("ign_attn_fwd_x6", q, k, v, out, lse, B, L, S, H, E, q_sb, q_sl, k_sb, k_sl, v_sb, v_sl, scale, stream);
+}
+extern "C" int ign_attn_bwd_x6(IGN_ATTN_BWD_ARGS) {
+    return attn_bwd_x6_impl<3>("ign_attn_bwd_x6", q, k, v, out, lse, gout, gq, gk, gv, delta_ws, B, L, S, H, E, q_sb, q_sl, k_sb, k_sl,
+                               v_sb, v_sl, scale, stream);
+}
+// operands (Q, K, V, P, dO, dS) rounded to bf16, one product per MFMA step, fp32 accumulation and softmax: the arithmetic of the
+// reference's default bf16-autocast mode for the two attention matmuls
+extern "C" int ign_attn_fwd_bf16(IGN_ATTN_FWD_ARGS) {
+    return attn_fwd_x6_impl<1>("ign_attn_fwd_bf16", q, k, v, out, lse, B, L, S, H, E, q_sb, q_sl, k_sb, k_sl, v_sb, v_sl, scale, stream);
+}
+extern "C" int ign_attn_bwd_bf16(IGN_ATTN_BWD_ARGS) {
+    return attn_bwd_x6_impl<1>("ign_attn_bwd_bf16", q, k, v, out, lse, gout, gq, gk, gv, delta_ws, B, L, S, H, E, q_sb, q_sl, k_sb,
+                               k_sl, v_sb, v_sl, scale, stream);
 }

@@ -167,8 +167,10 @@ class AttentionFn(torch.autograd.Function):
         lse = torch.empty(B, H, L, device=q.device, dtype=torch.float32)
         (qb, ql), (kb, kl), (vb, vl) = _bl_strides(q, "q"), _bl_strides(k, "k"), _bl_strides(v, "v")
         L_ = _lib.lib()
-        # "bf16x6": split-bf16 products on the bf16 matrix cores (fp32 accuracy); "f32": the fp32-MFMA kernel
-        fwd = L_.ign_attn_fwd_x6 if ATTN_MATH == "bf16x6" else L_.ign_attn_fwd
+        # "bf16x6": split-bf16 products on the bf16 matrix cores (fp32 accuracy); "f32": the fp32-MFMA kernel; inside an
+        # autocast region (the reference's default mode): operands rounded to bf16, one product
+        ctx.bf16 = torch.is_autocast_enabled() and E <= 64
+        fwd = L_.ign_attn_fwd_bf16 if ctx.bf16 else (L_.ign_attn_fwd_x6 if ATTN_MATH == "bf16x6" else L_.ign_attn_fwd)
         _lib.check(fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, L, S, H, E, qb, ql, kb, kl, vb, vl, float(scale),
                        _stream()), "ign_attn_fwd")
         ctx.save_for_backward(q, k, v, out, lse)
@@ -187,7 +189,8 @@ class AttentionFn(torch.autograd.Function):
         delta = torch.empty(B, H, L, device=q.device, dtype=torch.float32)
         (qb, ql), (kb, kl), (vb, vl) = _bl_strides(q, "q"), _bl_strides(k, "k"), _bl_strides(v, "v")
         # split-bf16 kernels up to E = 64 (E = 128 exceeds their register budget: the fp32-MFMA backward is faster there)
-        bwd = _lib.lib().ign_attn_bwd_x6 if (ATTN_MATH == "bf16x6" and E <= 64) else _lib.lib().ign_attn_bwd
+        bwd = (_lib.lib().ign_attn_bwd_bf16 if ctx.bf16 else
+               _lib.lib().ign_attn_bwd_x6 if (ATTN_MATH == "bf16x6" and E <= 64) else _lib.lib().ign_attn_bwd)
         _lib.check(bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(gout), _ptr(gq), _ptr(gk), _ptr(gv), _ptr(delta),
                        B, L, S, H, E, qb, ql, kb, kl, vb, vl, ctx.scale, _stream()), "ign_attn_bwd")
         return gq, gk, gv, None

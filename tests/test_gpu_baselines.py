@@ -442,3 +442,30 @@ def test_deep_experts_inside_autocast_use_the_bf16_kernels(name, kw, monkeypatch
     d = _rel(out.float(), ref.float())
     assert 1e-6 < d < 8e-2, d
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("B,L,S,H,E", [(2, 200, 200, 4, 64), (2, 130, 75, 2, 32), (1, 33, 257, 3, 16)])
+def test_attention_inside_autocast_is_the_bf16_single_product_form(B, L, S, H, E):
+    """Inside torch.autocast(bfloat16) the attention core rounds Q, K, V, P (and dO, dS) to bf16 and issues one product per MFMA
+    step: bf16-level distance from the float64 reference (forward and all three gradients), and not the fp32-accurate result."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    g = torch.Generator().manual_seed(L + S + E)
+    q = torch.randn(B, L, H, E, generator=g).to(dev).requires_grad_(True)
+    k = torch.randn(B, S, H, E, generator=g).to(dev).requires_grad_(True)
+    v = torch.randn(B, S, H, E, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(B, L, H, E, generator=g)
+    scale = 1.0 / math.sqrt(E)
+    exact = ops.attention(q, k, v, scale).detach()
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        o = ops.attention(q, k, v, scale)
+    assert o.dtype == torch.float32
+    (o * go.to(dev)).sum().backward()
+    qr, kr, vr = (t.detach().double().cpu().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("blhe,bshe->bhls", qr, kr)
+    oref = torch.einsum("bhls,bshd->blhd", torch.softmax(scale * s, dim=-1), vr)
+    (oref * go.double()).sum().backward()
+    assert 1e-4 < _rel(o, oref) < 3e-2 and _rel(exact, oref) < 2e-5
+    for name, a, b in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+        assert _rel(a, b) < 5e-2, name
