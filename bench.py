@@ -112,6 +112,10 @@ def main():
     ap.add_argument("--groups", choices=["4x5", "6x10"], default="4x5",
                     help="shapelet bank of the IGN config: 4x5 = what the reference driver builds (4 length groups x 5 shapelets, "
                          "SURVEY D4; the headline); 6x10 = the SBM/LTS bank (6 groups x 10, lengths .05-.8 T) as a stress case")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = the parity path (the reference run with --amp, BASELINE.json's headline); bf16 = the "
+                         "reference's DEFAULT mode, torch.autocast(bfloat16) around forward + loss: GEMM operands rounded to "
+                         "bf16 on the same kernels (one product per MFMA step), shapelet path and softmax stay fp32")
     ap.add_argument("--config", choices=["ign", "eegcnn", "transformer"], default="ign",
                     help="ign = BASELINE.json's headline (config 1 / 5); eegcnn / transformer = the baselines of "
                          "configs 3 / 4 on the same synthetic tensors")
@@ -181,11 +185,24 @@ def main():
 
     graphed = None
 
+    amp = args.precision == "bf16"
+
     def step(i):
         x, y = xs[i % n_batches], ys[i % n_batches]
         if graphed is not None:
             return graphed(x, y)
-        if args.config == "ign":
+        if amp:
+            # the composition of Experiment.train inside the autocast region (exp:319-329)
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                if args.config == "ign":
+                    out, info = model(x, mask, None, None)
+                    loss = F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y)
+                elif args.config == "eegcnn":
+                    out, info = model(x.permute(0, 2, 1).contiguous())
+                    loss = F.cross_entropy(out, y) + info.loss.mean()
+                else:
+                    loss = F.cross_entropy(model(x, mask, None, None), y)
+        elif args.config == "ign":
             out, info = model(x, mask, None, None)
             # = F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y), as Experiment.train
             loss = ign_ops.ign_loss(info.shapelet_preds, info.dnn_preds, y, 1.0)[0] + info.loss.mean()
@@ -286,8 +303,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if not amp else "bf16 (autocast: GEMM operands bf16, fp32 accumulate; shapelet path and softmax fp32)",
+            "data": "synthetic",
         }
+        if amp:
+            res["metric"] += " [reference default precision: bf16 autocast]"
         common = {"per_gpu_batch": B, "global_batch": B * world, "samples_per_epoch": N_TRAIN,
                   "parallelism": f"dp{world}", "final_loss": float(last), "hipgraph": bool(use_graph)}
         if rehearsal:
