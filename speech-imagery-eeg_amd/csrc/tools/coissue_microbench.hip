@@ -13,8 +13,10 @@
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+__device__ int g_prio;
 __global__ void __launch_bounds__(256) mfma_kernel(float* out, int iters, float seed) {
     extern __shared__ float dummy[];
+    if (seed < 0.f) __builtin_amdgcn_s_setprio(3);
     f32x16 c0, c1, c2, c3;
     for (int r = 0; r < 16; ++r) { c0[r] = seed + r; c1[r] = seed - r; c2[r] = seed * r; c3[r] = 1.f + r; }
     const float a = threadIdx.x * 1e-6f + seed * 1e-3f, b = 1.0f - threadIdx.x * 1e-6f;
@@ -35,6 +37,7 @@ __global__ void __launch_bounds__(256) mfma_kernel(float* out, int iters, float 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __global__ void __launch_bounds__(256) mfma_bf16_kernel(float* out, int iters, float seed) {
     extern __shared__ float dummy[];
+    if (seed < 0.f) __builtin_amdgcn_s_setprio(3);
     f32x16 c0, c1, c2, c3;
     for (int r = 0; r < 16; ++r) { c0[r] = seed + r; c1[r] = seed - r; c2[r] = seed * r; c3[r] = 1.f + r; }
     bf16x8 a, b;
@@ -75,6 +78,7 @@ __global__ void __launch_bounds__(64) valu_kernel(float* out, int iters, float s
     if (s == 12345.678f) out[threadIdx.x] = s + dummy[0];
 }
 
+static float g_seed = 1.5f;      // negative: the MFMA kernel raises its wave priority (s_setprio 3)
 static float run(hipStream_t sm, hipStream_t sv, float* out, int mfma_wg, int mfma_iters, size_t mfma_lds, int valu_wg,
                  int valu_iters, size_t valu_lds, int mode, int order, float* t_m, float* t_v, int bf16 = 0) {
     hipEvent_t m0, m1, v0, v1, w0, w1;
@@ -86,8 +90,8 @@ static float run(hipStream_t sm, hipStream_t sv, float* out, int mfma_wg, int mf
     auto lm = [&]() {
         if (mfma_wg <= 0) return;
         CHECK(hipEventRecord(m0, sm));
-        if (bf16) hipLaunchKernelGGL(mfma_bf16_kernel, dim3(mfma_wg), dim3(256), mfma_lds, sm, out, mfma_iters, 1.5f);
-        else hipLaunchKernelGGL(mfma_kernel, dim3(mfma_wg), dim3(256), mfma_lds, sm, out, mfma_iters, 1.5f);
+        if (bf16) hipLaunchKernelGGL(mfma_bf16_kernel, dim3(mfma_wg), dim3(256), mfma_lds, sm, out, mfma_iters, g_seed);
+        else hipLaunchKernelGGL(mfma_kernel, dim3(mfma_wg), dim3(256), mfma_lds, sm, out, mfma_iters, g_seed);
         CHECK(hipEventRecord(m1, sm));
     };
     auto lv = [&]() {
@@ -112,7 +116,8 @@ static float run(hipStream_t sm, hipStream_t sv, float* out, int mfma_wg, int mf
     return wall;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1 && atoi(argv[1]) == 1) { g_seed = -1.5f; printf("# MFMA kernel at s_setprio 3\n"); }
     float* out;
     CHECK(hipMalloc(&out, 1 << 20));
     hipStream_t sm, sv;
