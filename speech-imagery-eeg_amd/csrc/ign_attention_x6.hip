@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
     const bool q_ok = qi < a.L;
 
     // Q^T operand: lane (query, h) holds e = 16s + 8h .. +7 of slab s, three planes, scale folded in before the split
+    const float sc2 = a.scale * 1.44269504088896341f;
     bf16x8 Qf[3][NS];
     {
         const float* qp = a.q + b * a.q_sb + (long long)(q_ok ? qi : a.L - 1) * a.q_sl + head * E + 8 * h;
@@ -119,8 +120,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
         for (int s = 0; s < NS; ++s) {
             const float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * s);
             const float4 t1 = *reinterpret_cast<const float4*>(qp + 16 * s + 4);
-            const float t[8] = {t0.x * a.scale, t0.y * a.scale, t0.z * a.scale, t0.w * a.scale,
-                                t1.x * a.scale, t1.y * a.scale, t1.z * a.scale, t1.w * a.scale};
+            // scale * log2(e) folded in: the softmax below runs in base 2 (v_exp_f32 is 2^x: no multiply per score)
+            const float t[8] = {t0.x * sc2, t0.y * sc2, t0.z * sc2, t0.w * sc2, t1.x * sc2, t1.y * sc2, t1.z * sc2, t1.w * sc2};
             splitN_x8<NP>(t, Qf[0][s], Qf[1][s], Qf[2][s]);
         }
     }
@@ -184,18 +185,21 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
                 }
                 // online softmax over this lane's 16 keys + the partner half's 16 keys
                 float mloc = -INFINITY;
+                if (kt0 + kb + 32 > a.S) {                       // wave-uniform: only the last tile has keys past S
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (kt0 + kb + acc_row(r, h) >= a.S) acc[r] = -INFINITY;
-                    mloc = fmaxf(mloc, acc[r]);
+                    for (int r = 0; r < 16; ++r)
+                        if (kt0 + kb + acc_row(r, h) >= a.S) acc[r] = -INFINITY;
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, acc[r]);
                 mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
                 const float mnew = fmaxf(m, mloc);
-                const float alpha = __expf(m - mnew);
+                const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                const bool rescale = __builtin_amdgcn_ballot_w64(mnew != m) != 0;     // wave-uniform: the running max moved
                 float psum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    acc[r] = __expf(acc[r] - mnew);
+                    acc[r] = __builtin_amdgcn_exp2f(acc[r] - mnew);
                     psum += acc[r];
                 }
                 psum += __shfl_xor(psum, 32, 64);
@@ -211,8 +215,10 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
                 }
 #pragma unroll
                 for (int d = 0; d < ED; ++d) {
+                    if (rescale) {                               // after the first tiles the maximum rarely moves
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
+                        for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
+                    }
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
                         const __bf16* vp = Vs + (kb + 16 * s2) * PV + voff + d * 32;
@@ -244,7 +250,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
                     *reinterpret_cast<float4*>(op + d0) = make_float4(O[d][4 * g] * inv, O[d][4 * g + 1] * inv,
                                                                       O[d][4 * g + 2] * inv, O[d][4 * g + 3] * inv);
             }
-        if (h == 0) a.lse_out[((long long)b * a.H + head) * a.L + qi] = m + __logf(l);
+        if (h == 0) a.lse_out[((long long)b * a.H + head) * a.L + qi] = m * 0.693147180559945309f + __logf(l);
     }
 }
 
@@ -385,11 +391,11 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_x6_kernel(const AttnX6BwdA
         const float* gp = a.go + (((long long)b * a.L + qrow) * a.H + head) * E + 8 * h;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            load_split8<NP>(qp + 16 * s, a.scale, Qf[0][s], Qf[1][s], Qf[2][s]);
+            load_split8<NP>(qp + 16 * s, a.scale * 1.44269504088896341f, Qf[0][s], Qf[1][s], Qf[2][s]);   // base-2 softmax
             load_split8<NP>(gp + 16 * s, 1.f, Gf[0][s], Gf[1][s], Gf[2][s]);
         }
     }
-    const float lse_q = a.lse[((long long)b * a.H + head) * a.L + qrow];
+    const float lse_q = a.lse[((long long)b * a.H + head) * a.L + qrow] * 1.44269504088896341f;
     const float del_q = a.delta[((long long)b * a.H + head) * a.L + qrow];
     f32x16 dQ[ED];
 #pragma unroll
@@ -414,11 +420,13 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_x6_kernel(const AttnX6BwdA
         x6_rows_times_regs<E, NP>(st, Ks, Qf, l31, h);
         x6_rows_times_regs<E, NP>(dp, Vs, Gf, l31, h);
         // rows = keys kt0 + acc_row(r,h), column = this lane's query
+        if (kt0 + AB_T > a.S) {                                  // wave-uniform: only the last tile has keys past S
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = (kt0 + acc_row(r, h) < a.S) ? __expf(st[r] - lse_q) : 0.f;
-            dp[r] = p * (dp[r] - del_q);
+            for (int r = 0; r < 16; ++r)
+                if (kt0 + acc_row(r, h) >= a.S) st[r] = -INFINITY;
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(st[r] - lse_q) * (dp[r] - del_q);
         x6_tileT_times_acc<E, NP>(dQ, Ks, dp, lane);
     }
     if (q_ok) store_grad_rows<E>(a.gq + (((long long)b * a.L + qi) * a.H + head) * E, dQ, a.scale, h);
@@ -441,6 +449,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
     const int b = blockIdx.z, head = blockIdx.y;
     const int ki = blockIdx.x * 128 + wave * 32 + l31;
     const bool k_ok = ki < a.S;
+    const float kmask = k_ok ? 0.f : -INFINITY;                   // a lane past S contributes p = 2^-inf = 0
     const long long krow = k_ok ? ki : a.S - 1;
 
     bf16x8 Kf[3][NS], Vf[3][DV ? 1 : NS];
@@ -449,7 +458,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
         const float* vp = a.v + b * a.v_sb + krow * a.v_sl + head * E + 8 * h;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            load_split8<NP>(kp + 16 * s, a.scale, Kf[0][s], Kf[1][s], Kf[2][s]);
+            load_split8<NP>(kp + 16 * s, a.scale * 1.44269504088896341f, Kf[0][s], Kf[1][s], Kf[2][s]);   // base-2 softmax
             if constexpr (!DV) load_split8<NP>(vp + 16 * s, 1.f, Vf[0][s], Vf[1][s], Vf[2][s]);
         }
     }
@@ -471,7 +480,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
     IGN_AB_GLOAD(0, a.L, qbase, a.q_sl, gbase, g_sl)
     if (threadIdx.x < 2 * AB_T) {
         const int q = threadIdx.x & (AB_T - 1);
-        rl = q < a.L ? (threadIdx.x < AB_T ? lse_b[q] : del_b[q]) : (threadIdx.x < AB_T ? INFINITY : 0.f);
+        rl = q < a.L ? (threadIdx.x < AB_T ? lse_b[q] * 1.44269504088896341f : del_b[q]) : (threadIdx.x < AB_T ? INFINITY : 0.f);
     }
     for (int qt0 = 0; qt0 < a.L; qt0 += AB_T) {
         __syncthreads();
@@ -482,7 +491,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
             IGN_AB_GLOAD(qt0 + AB_T, a.L, qbase, a.q_sl, gbase, g_sl)
             if (threadIdx.x < 2 * AB_T) {
                 const int q = qt0 + AB_T + (threadIdx.x & (AB_T - 1));
-                rl = q < a.L ? (threadIdx.x < AB_T ? lse_b[q] : del_b[q]) : (threadIdx.x < AB_T ? INFINITY : 0.f);
+                rl = q < a.L ? (threadIdx.x < AB_T ? lse_b[q] * 1.44269504088896341f : del_b[q]) : (threadIdx.x < AB_T ? INFINITY : 0.f);
             }
         }
         f32x16 s;
@@ -493,10 +502,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 lv = *reinterpret_cast<const float4*>(Ls + 8 * g + 4 * h);
-            s[4 * g] = k_ok ? __expf(s[4 * g] - lv.x) : 0.f;
-            s[4 * g + 1] = k_ok ? __expf(s[4 * g + 1] - lv.y) : 0.f;
-            s[4 * g + 2] = k_ok ? __expf(s[4 * g + 2] - lv.z) : 0.f;
-            s[4 * g + 3] = k_ok ? __expf(s[4 * g + 3] - lv.w) : 0.f;
+            s[4 * g] = __builtin_amdgcn_exp2f(s[4 * g] - lv.x + kmask);
+            s[4 * g + 1] = __builtin_amdgcn_exp2f(s[4 * g + 1] - lv.y + kmask);
+            s[4 * g + 2] = __builtin_amdgcn_exp2f(s[4 * g + 2] - lv.z + kmask);
+            s[4 * g + 3] = __builtin_amdgcn_exp2f(s[4 * g + 3] - lv.w + kmask);
         }
         if constexpr (DV) {
             x6_tileT_times_acc<E, NP>(G, Gs, s, lane);
