@@ -165,9 +165,10 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
         for (int sub = 0; sub < AX_KT / 32; ++sub) {
             const int kb = sub * 32;
             if (kt0 + kb < a.S) {
-                f32x16 acc;
+                // two partial accumulators: a chain of dependent MFMAs on ONE accumulator issues at about half rate
+                f32x16 acc, acc2;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
                 const __bf16* kr = Ks + (kb + l31) * PK + 8 * h;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
@@ -176,13 +177,18 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
                     const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(kr + 2 * KPLANE + 16 * s);
                     if constexpr (NP == 3) {
                         acc = MFMA16(k2, Qf[0][s], acc);
-                        acc = MFMA16(k0, Qf[2][s], acc);
+                        acc2 = MFMA16(k0, Qf[2][s], acc2);
                         acc = MFMA16(k1, Qf[1][s], acc);
-                        acc = MFMA16(k1, Qf[0][s], acc);
+                        acc2 = MFMA16(k1, Qf[0][s], acc2);
                         acc = MFMA16(k0, Qf[1][s], acc);
+                        acc2 = MFMA16(k0, Qf[0][s], acc2);
+                    } else {
+                        if (s & 1) acc2 = MFMA16(k0, Qf[0][s], acc2);
+                        else acc = MFMA16(k0, Qf[0][s], acc);
                     }
-                    acc = MFMA16(k0, Qf[0][s], acc);
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
                 // online softmax over this lane's 16 keys + the partner half's 16 keys
                 float mloc = -INFINITY;
                 if (kt0 + kb + 32 > a.S) {                       // wave-uniform: only the last tile has keys past S
@@ -213,27 +219,29 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
                                         acc[8 * s2 + 4], acc[8 * s2 + 5], acc[8 * s2 + 6], acc[8 * s2 + 7]};
                     splitN_x8<NP>(t, Pf[0][s2], Pf[1][s2], Pf[2][s2]);
                 }
+                if (rescale) {                                   // after the first tiles the maximum rarely moves
 #pragma unroll
-                for (int d = 0; d < ED; ++d) {
-                    if (rescale) {                               // after the first tiles the maximum rarely moves
+                    for (int d = 0; d < ED; ++d)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
-                    }
+                }
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 vf[ED][3];
+#pragma unroll
+                    for (int d = 0; d < ED; ++d) {
                         const __bf16* vp = Vs + (kb + 16 * s2) * PV + voff + d * 32;
-                        const bf16x8 v0 = lds_tr8(vp, vp + 8 * PV);
-                        const bf16x8 v1 = lds_tr8(vp + VPLANE, vp + VPLANE + 8 * PV);
-                        const bf16x8 v2 = lds_tr8(vp + 2 * VPLANE, vp + 2 * VPLANE + 8 * PV);
+                        vf[d][0] = lds_tr8(vp, vp + 8 * PV);
                         if constexpr (NP == 3) {
-                            O[d] = MFMA16(v2, Pf[0][s2], O[d]);
-                            O[d] = MFMA16(v0, Pf[2][s2], O[d]);
-                            O[d] = MFMA16(v1, Pf[1][s2], O[d]);
-                            O[d] = MFMA16(v1, Pf[0][s2], O[d]);
-                            O[d] = MFMA16(v0, Pf[1][s2], O[d]);
+                            vf[d][1] = lds_tr8(vp + VPLANE, vp + VPLANE + 8 * PV);
+                            vf[d][2] = lds_tr8(vp + 2 * VPLANE, vp + 2 * VPLANE + 8 * PV);
                         }
-                        O[d] = MFMA16(v0, Pf[0][s2], O[d]);
                     }
+                    // the feature blocks are independent accumulators: alternate them
+#define IGN_PV(pa_, pb_) _Pragma("unroll") for (int d = 0; d < ED; ++d) O[d] = MFMA16(vf[d][pa_], Pf[pb_][s2], O[d]);
+                    if constexpr (NP == 3) { IGN_PV(2, 0) IGN_PV(0, 2) IGN_PV(1, 1) IGN_PV(1, 0) IGN_PV(0, 1) }
+                    IGN_PV(0, 0)
+#undef IGN_PV
                 }
             }
         }
@@ -303,13 +311,28 @@ template <int E, int NP>
 __device__ __forceinline__ void x6_rows_times_regs(f32x16& acc, const __bf16* T, const bf16x8 (&F)[3][E / 16], int l31, int h) {
     constexpr int P = AbCfg<E>::P, PLANE = AbCfg<E>::PLANE;
     const __bf16* tr = T + l31 * P + 8 * h;
+    f32x16 acc2;                      // second partial accumulator: dependent MFMAs on one accumulator issue at about half rate
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < E / 16; ++s) {
         const bf16x8 t0 = *reinterpret_cast<const bf16x8*>(tr + 16 * s);
-        const bf16x8 t1 = *reinterpret_cast<const bf16x8*>(tr + PLANE + 16 * s);
-        const bf16x8 t2 = *reinterpret_cast<const bf16x8*>(tr + 2 * PLANE + 16 * s);
-        IGN_X6_PRODUCTS(acc, t0, t1, t2, F[0][s], F[1][s], F[2][s])
+        if constexpr (NP == 3) {
+            const bf16x8 t1 = *reinterpret_cast<const bf16x8*>(tr + PLANE + 16 * s);
+            const bf16x8 t2 = *reinterpret_cast<const bf16x8*>(tr + 2 * PLANE + 16 * s);
+            acc = MFMA16(t2, F[0][s], acc);
+            acc2 = MFMA16(t0, F[2][s], acc2);
+            acc = MFMA16(t1, F[1][s], acc);
+            acc2 = MFMA16(t1, F[0][s], acc2);
+            acc = MFMA16(t0, F[1][s], acc);
+            acc2 = MFMA16(t0, F[0][s], acc2);
+        } else {
+            if (s & 1) acc2 = MFMA16(t0, F[0][s], acc2);
+            else acc = MFMA16(t0, F[0][s], acc);
+        }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
 }
 
 // G[d] (rows = feature d*32 + .., column = lane) += T^T * W, T in LDS planes (transposing reads), W = 16 register values of this
@@ -327,15 +350,23 @@ __device__ __forceinline__ void x6_tileT_times_acc(f32x16 (&G)[(E + 31) / 32], c
         splitN_x8<NP>(t, W[0][s2], W[1][s2], W[2][s2]);
     }
 #pragma unroll
-    for (int d = 0; d < ED; ++d)
+    for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 tf[ED][3];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
+        for (int d = 0; d < ED; ++d) {
             const __bf16* tp = T + (16 * s2) * P + off + d * 32;
-            const bf16x8 t0 = lds_tr8(tp, tp + 8 * P);
-            const bf16x8 t1 = lds_tr8(tp + PLANE, tp + PLANE + 8 * P);
-            const bf16x8 t2 = lds_tr8(tp + 2 * PLANE, tp + 2 * PLANE + 8 * P);
-            IGN_X6_PRODUCTS(G[d], t0, t1, t2, W[0][s2], W[1][s2], W[2][s2])
+            tf[d][0] = lds_tr8(tp, tp + 8 * P);
+            if constexpr (NP == 3) {
+                tf[d][1] = lds_tr8(tp + PLANE, tp + PLANE + 8 * P);
+                tf[d][2] = lds_tr8(tp + 2 * PLANE, tp + 2 * PLANE + 8 * P);
+            }
         }
+        // the feature blocks are independent accumulators: alternate them
+#define IGN_TW(pa_, pb_) _Pragma("unroll") for (int d = 0; d < ED; ++d) G[d] = MFMA16(tf[d][pa_], W[pb_][s2], G[d]);
+        if constexpr (NP == 3) { IGN_TW(2, 0) IGN_TW(0, 2) IGN_TW(1, 1) IGN_TW(1, 0) IGN_TW(0, 1) }
+        IGN_TW(0, 0)
+#undef IGN_TW
+    }
 }
 
 // rows t0 .. t0+31 of two (rows, H, E) fp32 tensors -> registers (zero past `nrows`); thread -> float4 piece (sr + RPP*p, sc)
