@@ -83,8 +83,16 @@ class EEGcnn(nn.Module):
         y2 = a_f * (w1[f] (*) (W2 x)) + b_f * rowsum(W2)  (see csrc/ign_eegcnn.hip), block 2 as a depthwise HIP convolution +
         a 64x64 channel GEMM; BatchNorm-1's batch variance comes from ign_conv1_sumsq_* so the (B,F1,C,T) tensor of the
         reference (eegcnn.py:90-91) is never formed."""
-        if not x.is_cuda or torch.is_autocast_enabled():
+        if not x.is_cuda:
             return self._forward_reference_ops(x)
+        if torch.is_autocast_enabled():
+            # the reference's default bf16 mode: this block's VALU kernels have no bf16 form and run in fp32 (a superset of the
+            # reference's accuracy); the encoder behind it picks the bf16 single-product GEMM / attention kernels itself
+            with torch.autocast(device_type="cuda", enabled=False):
+                return self._forward_hip(x.float())
+        return self._forward_hip(x)
+
+    def _forward_hip(self, x):
         B, C, T = x.shape
         bn1 = self.block1_bn1
         w1 = self.block1_conv1.weight.reshape(self.block1_conv1.weight.shape[0], -1)          # (F1, k1)

@@ -469,3 +469,42 @@ def test_attention_inside_autocast_is_the_bf16_single_product_form(B, L, S, H, E
     assert 1e-4 < _rel(o, oref) < 3e-2 and _rel(exact, oref) < 2e-5
     for name, a, b in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
         assert _rel(a, b) < 5e-2, name
+
+
+def test_eegcnn_inside_autocast_stays_on_the_hand_written_kernels(monkeypatch):
+    """EEG-CNN in the reference's default bf16 mode: the convolution block keeps its fp32 HIP kernels (autocast disabled inside),
+    the encoder uses the bf16 single-product GEMM / attention kernels; logits within bf16 distance of the fp32 run."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import _lib
+    from models.eegcnn import EEGCNNTransformer
+    L = _lib.lib()
+    calls = {"bf16": 0, "dw": 0}
+    real = {n: getattr(L, n) for n in ("ign_clconv_fwd_bf16", "ign_dwconv1d_fwd")}
+
+    class Spy:
+        def __getattr__(self, n):
+            if n in real:
+                def f(*a, _n=n):
+                    calls["bf16" if "bf16" in _n else "dw"] += 1
+                    return real[_n](*a)
+                return f
+            return getattr(L, n)
+
+    monkeypatch.setattr(_lib, "lib", lambda: Spy())
+    cfg = make_cfg(enc_in=122, seq_len=1000, num_class=3, c_out=3, d_model=128)
+    torch.manual_seed(0)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = EEGCNNTransformer(cfg).to(dev).train()
+        x = torch.randn(4, 122, 1000, device=dev)
+        ref, _ = m(x)
+        assert calls["bf16"] == 0 and calls["dw"] > 0
+        calls["dw"] = 0
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            out, _ = m(x)
+    assert calls["bf16"] > 0 and calls["dw"] > 0
+    out.float().sum().backward()
+    d = _rel(out.float(), ref.float())
+    assert 1e-6 < d < 8e-2, d
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
