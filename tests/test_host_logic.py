@@ -287,3 +287,34 @@ def test_raw_chisco_items_and_prefetcher_passthrough(tmp_path):
     assert len(got) == len(want) == 3
     for (a, b_, m), (c, d, n) in zip(got, want):
         assert torch.allclose(a, c, atol=1e-6) and torch.equal(b_, d) and torch.equal(m, n)
+
+
+def test_abi_argument_errors_of_the_gemm_and_attention_entry_points():
+    """Argument checking happens before any launch: callable without a GPU, returns the documented codes and a reason."""
+    import ctypes
+    from ign_hip import _lib
+    if not os.path.exists(_lib.lib_path()):
+        pytest.skip("libign_hip.so not built (run __graft_entry__.build())")
+    L = _lib.lib()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    ARG, UNSUP = -1001, -1002
+    # weight gradient, split-bf16: tap counts without an instantiated kernel / k = 1 with odd channel counts
+    assert L.ign_clconv_wgrad_x6(p, 0, p, None, None, p, p, 2, 50, 8, 8, 4, None) == UNSUP
+    assert b"k in" in L.ign_last_error()
+    assert L.ign_clconv_wgrad_x6(p, 0, p, None, None, p, p, 1, 50, 6, 8, 1, None) == UNSUP
+    assert L.ign_clconv_wgrad_bf16(None, 0, p, None, None, p, p, 2, 50, 8, 8, 3, None) == ARG
+    assert L.ign_clconv_wgrad_x6_workspace_bytes(2, 50, 8, 8, 4) == 0
+    assert L.ign_clconv_wgrad_x6_workspace_bytes(1, 4096, 64, 64, 1) > 0
+    # forward GEMMs: more than 16 taps / a prologue with only one of its two vectors
+    assert L.ign_clconv_fwd_x6(p, p, None, None, None, p, None, 1, 64, 8, 8, 17, None) == UNSUP
+    assert L.ign_clconv_fwd_bf16(p, p, None, p, None, p, None, 1, 64, 8, 8, 3, None) == ARG
+    # attention: head sizes, alignment, strides
+    for fn in (L.ign_attn_fwd_x6, L.ign_attn_fwd_bf16):
+        assert fn(p, p, p, p, p, 1, 8, 8, 1, 48, 384, 48, 384, 48, 384, 48, 0.1, None) == UNSUP
+        assert fn(p, p, p, p, None, 1, 8, 8, 1, 64, 512, 64, 512, 64, 512, 64, 0.1, None) == ARG
+        assert fn(p, p, p, p, p, 1, 8, 8, 1, 64, 512, 62, 512, 64, 512, 64, 0.1, None) == ARG
+    assert b"stride" in L.ign_last_error()
+    for fn in (L.ign_attn_bwd_x6, L.ign_attn_bwd_bf16):
+        assert fn(p, p, p, p, p, p, p, p, p, p, 1, 8, 8, 1, 24, 192, 24, 192, 24, 192, 24, 0.1, None) == UNSUP
+        assert fn(p, p, p, p, p, p, p, p, None, p, 1, 8, 8, 1, 64, 512, 64, 512, 64, 512, 64, 0.1, None) == ARG
