@@ -270,8 +270,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
 // form that is 96 + 64 + 32 + 24 + fragments > 256 VGPRs at two waves per SIMD, so dK and dV are separate kernels that each
 // recompute S (MFMAs per 32x32 tile: dQ 72, dK 72, dV 48 of 32 cycles -- against 224 of 64 cycles in fp32).
 struct AttnX6BwdArgs {
-    const float *q, *k, *v, *go, *lse, *delta;     // go (B,L,H,E) contiguous; lse, delta (B,H,L)
-    float *gq, *gk, *gv;
+    const float *q, *k, *v, *o, *go, *lse, *delta; // o, go (B,L,H,E) contiguous; lse, delta (B,H,L)
+    float *gq, *gk, *gv, *delta_out;               // delta_out: written by the dQ kernel (delta = rowsum(dO * O)), read by dK
     long long q_sb, q_sl, k_sb, k_sl, v_sb, v_sl;
     int B, L, S, H, E;
     float scale;
@@ -417,17 +417,24 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_x6_kernel(const AttnX6BwdA
     const long long qrow = q_ok ? qi : a.L - 1;
 
     bf16x8 Qf[3][NS], Gf[3][NS];
+    float del_q = 0.f;                                         // delta = rowsum(dO * O): this lane's half of the row, then lane ^ 32
     {
         const float* qp = a.q + b * a.q_sb + qrow * a.q_sl + head * E + 8 * h;
         const float* gp = a.go + (((long long)b * a.L + qrow) * a.H + head) * E + 8 * h;
+        const float* op = a.o + (((long long)b * a.L + qrow) * a.H + head) * E + 8 * h;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             load_split8<NP>(qp + 16 * s, a.scale * 1.44269504088896341f, Qf[0][s], Qf[1][s], Qf[2][s]);   // base-2 softmax
-            load_split8<NP>(gp + 16 * s, 1.f, Gf[0][s], Gf[1][s], Gf[2][s]);
+            const float4 g0 = *reinterpret_cast<const float4*>(gp + 16 * s), g1 = *reinterpret_cast<const float4*>(gp + 16 * s + 4);
+            const float4 o0 = *reinterpret_cast<const float4*>(op + 16 * s), o1 = *reinterpret_cast<const float4*>(op + 16 * s + 4);
+            del_q += g0.x * o0.x + g0.y * o0.y + g0.z * o0.z + g0.w * o0.w + g1.x * o1.x + g1.y * o1.y + g1.z * o1.z + g1.w * o1.w;
+            const float t[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            splitN_x8<NP>(t, Gf[0][s], Gf[1][s], Gf[2][s]);
         }
     }
+    del_q += __shfl_xor(del_q, 32, 64);
+    if (q_ok && h == 0) a.delta_out[((long long)b * a.H + head) * a.L + qi] = del_q;
     const float lse_q = a.lse[((long long)b * a.H + head) * a.L + qrow] * 1.44269504088896341f;
-    const float del_q = a.delta[((long long)b * a.H + head) * a.L + qrow];
     f32x16 dQ[ED];
 #pragma unroll
     for (int d = 0; d < ED; ++d)
@@ -562,24 +569,6 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
     }
 }
 
-// delta[b,h,l] = sum_e dO * O (same as attn_delta_kernel)
-__global__ void __launch_bounds__(256) attn_delta_x6_kernel(const float* __restrict__ o, const float* __restrict__ go,
-                                                            float* __restrict__ delta, int B, int L, int H, int E) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;      // over (b, l, h)
-    if (idx >= (long long)B * L * H) return;
-    const float* po = o + idx * E;
-    const float* pg = go + idx * E;
-    float s = 0.f;
-    for (int e = 0; e < E; e += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(po + e);
-        const float4 y = *reinterpret_cast<const float4*>(pg + e);
-        s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-    }
-    const int hh = (int)(idx % H);
-    const long long bl = idx / H;
-    delta[((long long)(bl / L) * H + hh) * L + (int)(bl % L)] = s;
-}
-
 // ------------------------------------------------------------------------------------------------ C ABI
 template <int NP>
 static int attn_fwd_x6_impl(const char* who, const float* q, const float* k, const float* v, float* out, float* lse, int B, int L,
@@ -660,16 +649,10 @@ static int attn_bwd_x6_impl(const char* who, const float* q, const float* k, con
         }
     hipStream_t s = (hipStream_t)stream;
     AttnX6BwdArgs a = {};
-    a.q = q; a.k = k; a.v = v; a.go = gout; a.lse = lse; a.delta = delta_ws; a.gq = gq; a.gk = gk; a.gv = gv;
+    a.q = q; a.k = k; a.v = v; a.o = out; a.go = gout; a.lse = lse; a.delta = delta_ws; a.delta_out = delta_ws;
+    a.gq = gq; a.gk = gk; a.gv = gv;
     a.q_sb = q_sb; a.q_sl = q_sl; a.k_sb = k_sb; a.k_sl = k_sl; a.v_sb = v_sb; a.v_sl = v_sl;
     a.B = B; a.L = L; a.S = S; a.H = H; a.E = E; a.scale = scale;
-    int rc;
-    {
-        const long long n = (long long)B * L * H;
-        IgnScopedTimer tm("attn_delta", s);
-        hipLaunchKernelGGL(attn_delta_x6_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, gout, delta_ws, B, L, H, E);
-    }
-    if ((rc = ign_check_launch("attn_delta_x6_kernel"))) return rc;
     const dim3 gk_grid((S + 127) / 128, H, B), gq_grid((L + 127) / 128, H, B);
 #define IGN_AB(EE, KERNEL, GRID)                                                                                              \
     do {                                                                                                                      \
@@ -683,11 +666,12 @@ static int attn_bwd_x6_impl(const char* who, const float* q, const float* k, con
     } while (0)
 #define IGN_AB_ALL(EE)                                                                                                        \
     do {                                                                                                                      \
+        /* dQ first: it also writes delta = rowsum(dO * O), which the dK kernel reads */                                      \
+        { IgnScopedTimer tm("attn_bwd_dq", s);                                                                                \
+          IGN_AB(EE, (attn_bwd_dq_x6_kernel<EE, NP>), gq_grid); }                                                             \
         { IgnScopedTimer tm("attn_bwd_dkdv", s);                                                                              \
           IGN_AB(EE, (attn_bwd_dkv_x6_kernel<EE, true, NP>), gk_grid);                                                        \
           IGN_AB(EE, (attn_bwd_dkv_x6_kernel<EE, false, NP>), gk_grid); }                                                     \
-        { IgnScopedTimer tm("attn_bwd_dq", s);                                                                                \
-          IGN_AB(EE, (attn_bwd_dq_x6_kernel<EE, NP>), gq_grid); }                                                             \
     } while (0)
     switch (E) {
         case 16: IGN_AB_ALL(16); break;
