@@ -258,6 +258,129 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
     nt_epilogue<EPI>(a, acc, reinterpret_cast<float*>(smem16), mt, m0, n0, bi * ca.trows + min(ca.trows, t0 + TM));
 }
 
+// ---- the k = 1 case with wide outputs (a Linear layer: N % 256 == 0): 128 x 256 output tile, eight waves (2 x 4 of 64 x 64).
+// A Linear layer has no taps to share a staged span, so in clconv_x6t_kernel every 24-MFMA step pays for loading, splitting and
+// storing a 128 x 16 activation tile; on this part those instructions do not hide under other waves' MFMAs, they add
+// to them.  Sharing the activation tile between twice as many waves halves that cost per MFMA: per wave and step one float4 to
+// load / split / store instead of two, the weight side unchanged.  Same packed weights (two consecutive 128-row n-tiles), same
+// arithmetic and summation order per output, same epilogue code.
+constexpr int X6W_ABUF = 3 * TM * X6_PITCH;                       // one 128-row activation tile, three planes
+constexpr int X6W_BBUF = 2 * 3 * X6_PLANE;                        // two 128-row weight blocks, three planes each
+constexpr size_t X6W_LDS_BYTES = (size_t)2 * (X6W_ABUF + X6W_BBUF) * sizeof(unsigned short);
+
+template <int NP>
+__global__ void __launch_bounds__(512, 2) clconv_x6w_kernel(const ConvX6Args ca) {
+    const GemmNTArgs& a = ca.g;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    __bf16* Abuf = reinterpret_cast<__bf16*>(smem16);
+    __bf16* Bbuf = Abuf + 2 * X6W_ABUF;
+    constexpr int APLANE = TM * X6_PITCH;
+
+    const int ntw = a.N / 256;                                    // wide n-tiles
+    const int nwg = a.mtiles * ntw;
+    int lid = blockIdx.x;
+    {
+        const int per = nwg / 8;
+        if (lid < per * 8) lid = (lid & 7) * per + (lid >> 3);
+    }
+    const int mt = lid / ntw, nw = lid - mt * ntw;
+    const int m0 = mt * TM, n0 = nw * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;                      // wn 0..3
+    const int ncc = ca.cp / KC;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // activation staging: thread -> float4 (row tid >> 2, channels 4 * (tid & 3))
+    const int arow = tid >> 2, ach = (tid & 3) * 4;
+    const float* ap = a.A + (long long)min(m0 + arow, a.M - 1) * ca.cin + ach;
+    float ra[4];
+    // weight staging: threads 0..255 -> n-tile 2*nw, 256..511 -> n-tile 2*nw + 1; row (tid & 255) >> 1, 8-channel half tid & 1
+    const int bt = tid >> 8, brw = (tid & 255) >> 1, bh = tid & 1;
+    const unsigned short* bsrc = a.B3 + (size_t)(2 * nw + bt) * (size_t)ncc * X6_BLOCK + (size_t)brw * KC + 8 * bh;
+    constexpr size_t bplane = (size_t)TN * KC;
+    uint4 rb00, rb01 = {}, rb02 = {}, rb10, rb11 = {}, rb12 = {};
+
+    auto aload = [&](int cc) {
+        const int ch = cc * KC + ach;
+        if (ch < ca.cin) vload<4>(ra, ap + cc * KC);              // cin % 4 == 0: a float4 is entirely inside or outside
+        else ra[0] = ra[1] = ra[2] = ra[3] = 0.f;
+    };
+    auto astore = [&](int buf) { split_store<4, NP>(ra, Abuf + buf * X6W_ABUF + arow * X6_PITCH + ach, APLANE); };
+    auto bstore = [&](int buf, const uint4& r0, const uint4& r1, const uint4& r2) {
+        __bf16* st = Bbuf + buf * X6W_BBUF + bt * 3 * X6_PLANE + brw * X6_PITCH + 8 * bh;
+        *reinterpret_cast<uint4*>(st) = r0;
+        if constexpr (NP == 3) {
+            *reinterpret_cast<uint4*>(st + X6_PLANE) = r1;
+            *reinterpret_cast<uint4*>(st + 2 * X6_PLANE) = r2;
+        }
+    };
+#define IGN_BLOADW(r0, r1, r2, st)                                                      \
+    do {                                                                                \
+        const size_t off_ = (size_t)min((st), ncc - 1) * X6_BLOCK;                      \
+        r0 = *reinterpret_cast<const uint4*>(bsrc + off_);                              \
+        if constexpr (NP == 3) {                                                        \
+            r1 = *reinterpret_cast<const uint4*>(bsrc + bplane + off_);                 \
+            r2 = *reinterpret_cast<const uint4*>(bsrc + 2 * bplane + off_);             \
+        }                                                                               \
+    } while (0)
+
+    aload(0);
+    IGN_BLOADW(rb00, rb01, rb02, 0);
+    IGN_BLOADW(rb10, rb11, rb12, 1);
+    astore(0);
+    bstore(0, rb00, rb01, rb02);
+    __syncthreads();
+
+    auto body = [&](int step, bool odd) {
+        if (odd) IGN_BLOADW(rb10, rb11, rb12, step + 2);
+        else IGN_BLOADW(rb00, rb01, rb02, step + 2);
+        const bool next = step + 1 < ncc;
+        if (next) aload(step + 1);
+        const __bf16* As = Abuf + (step & 1) * X6W_ABUF + (wm * 64 + l31) * X6_PITCH + 8 * h;
+        const __bf16* Bs = Bbuf + (step & 1) * X6W_BBUF + (wn >> 1) * 3 * X6_PLANE + ((wn & 1) * 64 + l31) * X6_PITCH + 8 * h;
+        bf16x8 af[2][NP], bf[2][NP];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                af[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * APLANE + i * 32 * X6_PITCH);
+                bf[i][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * X6_PLANE + i * 32 * X6_PITCH);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#define IGN_X6(pa_, pb_)                                                                                   \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[0][pb_], acc[0][0], 0, 0, 0);   \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[1][pb_], acc[0][1], 0, 0, 0);   \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[0][pb_], acc[1][0], 0, 0, 0);   \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[1][pb_], acc[1][1], 0, 0, 0);
+        if constexpr (NP == 3) { IGN_X6(2, 0) IGN_X6(0, 2) IGN_X6(1, 1) IGN_X6(1, 0) IGN_X6(0, 1) }
+        IGN_X6(0, 0)
+#undef IGN_X6
+        __builtin_amdgcn_sched_barrier(0);
+        if (odd) bstore((step + 1) & 1, rb00, rb01, rb02);
+        else bstore((step + 1) & 1, rb10, rb11, rb12);
+        if (next) astore((step + 1) & 1);
+        __syncthreads();
+    };
+    for (int step = 0; step < ncc; step += 2) {
+        body(step, false);
+        if (step + 1 < ncc) body(step + 1, true);
+    }
+#undef IGN_BLOADW
+    // epilogue: bias + store (nt_epilogue_body derives wm / wn from the thread index: wn 0..3 covers the 256 columns)
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    const int m_lim = a.M;
+    if (m0 + TM <= m_lim) nt_epilogue_body<EPI_BIAS_STATS, true>(a, acc, s1, s2, m0, n0, m_lim);
+    else nt_epilogue_body<EPI_BIAS_STATS, false>(a, acc, s1, s2, m0, n0, m_lim);
+}
+
 // Step-block-major planes for the kernel above: block (n-tile, chunk cc, tap j) = [plane][row 0..127][16 channels of chunk cc]
 // of tap j, contiguous; rows past N and channels past C are zero.
 //   forward: rows = co, value W[co][ci][j];   data gradient: rows = ci, channels = co, value W[co][ci][k-1-jj].
@@ -612,7 +735,25 @@ static int launch_x6t(const ConvX6Args& a, int V, bool pro, hipStream_t s) {
     return ign_check_launch("clconv_x6t_kernel");
 }
 
+template <int NP>
+static int launch_x6w(const ConvX6Args& a, hipStream_t s) {
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_x6w_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)X6W_LDS_BYTES);
+        once = true;
+    }
+    const unsigned nwg = (unsigned)(a.g.mtiles * (a.g.N / 256));
+    hipLaunchKernelGGL((clconv_x6w_kernel<NP>), dim3(nwg), dim3(512), X6W_LDS_BYTES, s, a);
+    return ign_check_launch("clconv_x6w_kernel");
+}
+
 int ign_clconv_launch_x6t(const ConvX6Args& a, int epi, int V, bool pro, hipStream_t s) {
+    // Linear layers with wide outputs: the 128 x 256 tile kernel (see clconv_x6w_kernel)
+    static const bool wide = !(getenv("IGN_X6_WIDE") && atoi(getenv("IGN_X6_WIDE")) == 0);
+    if (wide && a.k == 1 && a.g.N % 256 == 0 && V == 4 && !pro && epi == EPI_BIAS_STATS && !a.g.part && a.tps * 1 == a.g.mtiles &&
+        a.trows == a.g.M)
+        return a.nprod == 1 ? launch_x6w<1>(a, s) : launch_x6w<3>(a, s);
     if (a.nprod == 1)
         return epi == EPI_BIAS_STATS ? launch_x6t<EPI_BIAS_STATS, 1>(a, V, pro, s) : launch_x6t<EPI_MASK_STATS, 1>(a, V, pro, s);
     return epi == EPI_BIAS_STATS ? launch_x6t<EPI_BIAS_STATS, 3>(a, V, pro, s) : launch_x6t<EPI_MASK_STATS, 3>(a, V, pro, s);

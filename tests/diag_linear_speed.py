@@ -31,3 +31,14 @@ for (Ci, Co) in [(512, 512), (512, 2048), (2048, 512), (64, 512)]:
     e32 = float((dw - ref).abs().max() / ref.abs().max()); e6 = float((dw6 - ref).abs().max() / ref.abs().max())
     print(f"wgrad Ci={Ci} Co={Co}: f32 {t32:.3f} ms ({flops/t32/1e9:.0f} TFLOP/s, err {e32:.1e})  bf16x6 {t6:.3f} ms "
           f"({flops/t6/1e9:.0f} TFLOP/s-equiv, err {e6:.1e})", flush=True)
+
+# forward GEMM (ign_clconv_fwd_x6, k = 1): 128x128 tiles (IGN_X6_WIDE=0) vs the 128x256 eight-wave kernel
+for (Ci, Co) in [(512, 512), (512, 2048), (2048, 512), (512, 1536)]:
+    x = torch.randn(M, Ci, device=dev); w = torch.randn(Co, Ci, device=dev) / Ci ** 0.5; b = torch.randn(Co, device=dev)
+    wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, 1)), device=dev, dtype=torch.bfloat16)
+    _lib.check(L.ign_clconv_pack_weights_x3(p(w), p(wt3), None, Co, Ci, 1, s()), "pack")
+    y = torch.empty(M, Co, device=dev)
+    t = timeit(lambda: _lib.check(L.ign_clconv_fwd_x6(p(x), p(wt3), p(b), None, None, p(y), None, 1, M, Ci, Co, 1, s()), "f"))
+    ref = x[:4096].double() @ w.double().t() + b.double()
+    err = float((y[:4096] - ref).abs().max() / ref.abs().max())
+    print(f"fwd Ci={Ci} Co={Co} (IGN_X6_WIDE={os.environ.get('IGN_X6_WIDE', '1')}): {t:.3f} ms ({2.0*M*Ci*Co/t/1e9:.0f} TFLOP/s-equiv, err {err:.1e})", flush=True)
