@@ -298,22 +298,24 @@ __global__ void __launch_bounds__(512, 2) clconv_x6w_kernel(const ConvX6Args ca)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // activation staging: thread -> float4 (row tid >> 2, channels 4 * (tid & 3))
+    // activation staging: thread -> float4 (row tid >> 2, channels 4 * (tid & 3)); two register sets by step parity, loaded two
+    // steps ahead like the weights
     const int arow = tid >> 2, ach = (tid & 3) * 4;
     const float* ap = a.A + (long long)min(m0 + arow, a.M - 1) * ca.cin + ach;
-    float ra[4];
+    float ra0[4], ra1[4];
     // weight staging: threads 0..255 -> n-tile 2*nw, 256..511 -> n-tile 2*nw + 1; row (tid & 255) >> 1, 8-channel half tid & 1
     const int bt = tid >> 8, brw = (tid & 255) >> 1, bh = tid & 1;
     const unsigned short* bsrc = a.B3 + (size_t)(2 * nw + bt) * (size_t)ncc * X6_BLOCK + (size_t)brw * KC + 8 * bh;
     constexpr size_t bplane = (size_t)TN * KC;
     uint4 rb00, rb01 = {}, rb02 = {}, rb10, rb11 = {}, rb12 = {};
 
-    auto aload = [&](int cc) {
-        const int ch = cc * KC + ach;
-        if (ch < ca.cin) vload<4>(ra, ap + cc * KC);              // cin % 4 == 0: a float4 is entirely inside or outside
-        else ra[0] = ra[1] = ra[2] = ra[3] = 0.f;
-    };
-    auto astore = [&](int buf) { split_store<4, NP>(ra, Abuf + buf * X6W_ABUF + arow * X6_PITCH + ach, APLANE); };
+#define IGN_ALOADW(ra_, cc_)                                                                 \
+    do {                                                                                     \
+        const int c_ = min((cc_), ncc - 1);                                                  \
+        if (c_ * KC + ach < ca.cin) vload<4>(ra_, ap + c_ * KC);  /* cin % 4 == 0 */         \
+        else ra_[0] = ra_[1] = ra_[2] = ra_[3] = 0.f;                                        \
+    } while (0)
+    auto astore = [&](int buf, const float (&r)[4]) { split_store<4, NP>(r, Abuf + buf * X6W_ABUF + arow * X6_PITCH + ach, APLANE); };
     auto bstore = [&](int buf, const uint4& r0, const uint4& r1, const uint4& r2) {
         __bf16* st = Bbuf + buf * X6W_BBUF + bt * 3 * X6_PLANE + brw * X6_PITCH + 8 * bh;
         *reinterpret_cast<uint4*>(st) = r0;
@@ -332,18 +334,20 @@ __global__ void __launch_bounds__(512, 2) clconv_x6w_kernel(const ConvX6Args ca)
         }                                                                               \
     } while (0)
 
-    aload(0);
+    IGN_ALOADW(ra0, 0);
     IGN_BLOADW(rb00, rb01, rb02, 0);
+    IGN_ALOADW(ra1, 1);
     IGN_BLOADW(rb10, rb11, rb12, 1);
-    astore(0);
+    astore(0, ra0);
     bstore(0, rb00, rb01, rb02);
     __syncthreads();
 
-    auto body = [&](int step, bool odd) {
-        if (odd) IGN_BLOADW(rb10, rb11, rb12, step + 2);
-        else IGN_BLOADW(rb00, rb01, rb02, step + 2);
-        const bool next = step + 1 < ncc;
-        if (next) aload(step + 1);
+    // Waves w and w + 4 share a SIMD and run the same program between the same barriers.  Waves 4..7 do the step's stores BEFORE
+    // its MFMAs, waves 0..3 after (MI355X_MICROARCH.md, "try a stagger").  Measured neutral here (135/158/182/176 vs
+    // 136/157/183/177 TFLOP/s-equivalent): SQ_VALU_MFMA_COEXEC_CYCLES stays at 1.4 % of SQ_VALU_MFMA_BUSY_CYCLES either way
+    // (profiles/r1m_pmc_gemm_coexec.json) -- the idle matrix-pipe time is barrier / s_waitcnt wait (32 % of wave cycles).
+    const bool late = wave >= 4;
+    auto mm = [&](int step) {
         const __bf16* As = Abuf + (step & 1) * X6W_ABUF + (wm * 64 + l31) * X6_PITCH + 8 * h;
         const __bf16* Bs = Bbuf + (step & 1) * X6W_BBUF + (wn >> 1) * 3 * X6_PLANE + ((wn & 1) * 64 + l31) * X6_PITCH + 8 * h;
         bf16x8 af[2][NP], bf[2][NP];
@@ -364,9 +368,18 @@ __global__ void __launch_bounds__(512, 2) clconv_x6w_kernel(const ConvX6Args ca)
         IGN_X6(0, 0)
 #undef IGN_X6
         __builtin_amdgcn_sched_barrier(0);
-        if (odd) bstore((step + 1) & 1, rb00, rb01, rb02);
-        else bstore((step + 1) & 1, rb10, rb11, rb12);
-        if (next) astore((step + 1) & 1);
+    };
+    auto body = [&](int step, bool odd) {
+        // the register sets of this step's parity hold data that is already in LDS: refill them for step + 2
+        if (odd) { IGN_BLOADW(rb10, rb11, rb12, step + 2); IGN_ALOADW(ra1, step + 2); }
+        else { IGN_BLOADW(rb00, rb01, rb02, step + 2); IGN_ALOADW(ra0, step + 2); }
+        const bool next = step + 1 < ncc;
+        auto st = [&]() {
+            if (odd) { bstore((step + 1) & 1, rb00, rb01, rb02); if (next) astore((step + 1) & 1, ra0); }
+            else { bstore((step + 1) & 1, rb10, rb11, rb12); if (next) astore((step + 1) & 1, ra1); }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (late) { st(); mm(step); } else { mm(step); st(); }
         __syncthreads();
     };
     for (int step = 0; step < ncc; step += 2) {
@@ -374,6 +387,7 @@ __global__ void __launch_bounds__(512, 2) clconv_x6w_kernel(const ConvX6Args ca)
         if (step + 1 < ncc) body(step + 1, true);
     }
 #undef IGN_BLOADW
+#undef IGN_ALOADW
     // epilogue: bias + store (nt_epilogue_body derives wm / wn from the thread index: wn 0..3 covers the 256 columns)
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
     const int m_lim = a.M;
