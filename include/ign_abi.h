@@ -254,6 +254,13 @@ int ign_clconv_dgrad_bf16(const float* dyp, const void* wt3_dgrad, const float* 
                           int B, int Tin, int Ci, int Co, int k, void* stream);
 int ign_clconv_wgrad_bf16(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
                           float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream);
+/* A Linear layer's weight AND bias gradient in one pass over dy (M, Co) and x (M, Ci): dW = dy^T x on the split-bf16 k = 1 kernel,
+ * db = column sums of dy accumulated by the tiles that stage those values anyway (db may be NULL).  Workspace:
+ * ign_clconv_wgrad_x6_workspace_bytes(1, M, Ci, Co, 1).  _bf16: the single-product (autocast) form.  Co % 4 == Ci % 4 == 0. */
+int ign_linear_wgrad_x6(const float* dy, const float* x, float* dw, float* db, void* workspace, long long M, int Ci, int Co,
+                        void* stream);
+int ign_linear_wgrad_bf16(const float* dy, const float* x, float* dw, float* db, void* workspace, long long M, int Ci, int Co,
+                          void* stream);
 size_t ign_clconv_wgrad_workspace_bytes(int B, int Tin, int Ci, int Co, int k);
 int ign_clconv_wgrad(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
                      float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream);

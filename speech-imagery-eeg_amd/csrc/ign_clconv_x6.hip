@@ -618,6 +618,7 @@ constexpr size_t W1_LDS_BYTES = (size_t)2 * W1_STAGE * sizeof(unsigned short);
 
 struct Wgrad1Args {
     const float* dy; const float* x; float* part;      // dy (M, Co), x (M, Ci), part (nsplit, Co, Ci)
+    float* part_b;                                     // (nsplit, Co) column sums of dy (the bias gradient) or null
     long long M;
     int Ci, Co, nunits, nsplit, citiles, ntiles;
 };
@@ -655,6 +656,9 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float rd[2][4], rx[2][4];
+    // bias gradient = column sums of dy: the tiles of the first ci-column see every dy value of their co-block once
+    const bool want_b = a.part_b != nullptr && cit == 0;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     auto gload = [&](int u) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -668,6 +672,10 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1
     auto lstore = [&](int buf) {
         __bf16* P = smem + buf * W1_STAGE;
         __bf16* Q = P + 3 * W1_PLANE;
+        if (want_b) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) bsum[v] += rd[0][v] + rd[1][v];
+        }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             split_store<4, NP>(rd[p], P + (sr + 8 * p) * W1_PITCH + sc, W1_PLANE);
@@ -711,6 +719,18 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1
         __syncthreads();
     }
 
+    if (want_b) {
+        // the eight threads that staged rows sr = 0..7 of the same four columns: fixed-order sum through LDS
+        float* red = reinterpret_cast<float*>(smem16);           // every wave is past its last operand read (loop barrier)
+        *reinterpret_cast<float4*>(red + sr * 128 + sc) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
+        __syncthreads();
+        if (tid < 128 && co0 + tid < a.Co) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t += red[r * 128 + tid];
+            a.part_b[(long long)split * a.Co + co0 + tid] = t;
+        }
+    }
     float* out = a.part + (long long)split * a.Co * a.Ci;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -832,7 +852,7 @@ static int wgrad_x6_k1_splits(long long M, int Ci, int Co, int* nunits, int* til
 extern "C" size_t ign_clconv_wgrad_x6_workspace_bytes(int B, int Tin, int Ci, int Co, int k) {
     if (k == 1 && B > 0 && Tin > 0 && Ci > 0 && Co > 0) {
         int nunits, tiles;
-        return (size_t)wgrad_x6_k1_splits((long long)B * Tin, Ci, Co, &nunits, &tiles) * Co * Ci * sizeof(float);
+        return (size_t)wgrad_x6_k1_splits((long long)B * Tin, Ci, Co, &nunits, &tiles) * Co * (Ci + 1) * sizeof(float);  // + bias partials
     }
     const int Tout = Tin - k + 1, ru = wgrad_x6_rows_per_unit(k);
     if (B <= 0 || Tout <= 0 || Ci <= 0 || Co <= 0 || !ru) return 0;
@@ -843,7 +863,8 @@ extern "C" size_t ign_clconv_wgrad_x6_workspace_bytes(int B, int Tin, int Ci, in
 
 template <int NP>
 static int wgrad_x6_impl(const char* who, const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
-                         float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream) {
+                         float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream,
+                         float* db = nullptr) {
     const int Tout = Tin - k + 1, ru = wgrad_x6_rows_per_unit(k);
     if (!dyp || !x || !dw_oik || !workspace || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || dy_pad < 0 ||
         ((pro_a == nullptr) != (pro_b == nullptr))) {
@@ -862,6 +883,7 @@ static int wgrad_x6_impl(const char* who, const float* dyp, int dy_pad, const fl
         int tiles;
         w.nsplit = wgrad_x6_k1_splits(w.M, Ci, Co, &w.nunits, &tiles);
         w.citiles = (Ci + 127) / 128; w.ntiles = tiles;
+        w.part_b = db ? (float*)workspace + (size_t)w.nsplit * Co * Ci : nullptr;
         static bool once = false;
         if (!once) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_wgrad_x6_k1_kernel<NP>),
@@ -873,8 +895,9 @@ static int wgrad_x6_impl(const char* who, const float* dyp, int dy_pad, const fl
             hipLaunchKernelGGL(clconv_wgrad_x6_k1_kernel<NP>, dim3((unsigned)(tiles * ((w.nsplit + 7) / 8 * 8))), dim3(256), W1_LDS_BYTES,
                                s, w);
         }
-        const int rc1 = ign_check_launch("clconv_wgrad_x6_k1_kernel");
+        int rc1 = ign_check_launch("clconv_wgrad_x6_k1_kernel");
         if (rc1) return rc1;
+        if (db && (rc1 = ign_clconv_launch_wgrad_reduce(w.part_b, db, w.nsplit, Co, 1, 1, s))) return rc1;
         return ign_clconv_launch_wgrad_reduce((const float*)workspace, dw_oik, w.nsplit, Co, Ci, 1, s);
     }
     if (Co % 4 || !ru) { ign_set_error("%s: needs Co %% 4 == 0 and k in {1,2,3,5,8} (Co=%d k=%d)", who, Co, k); return IGN_E_UNSUP; }
@@ -912,4 +935,18 @@ extern "C" int ign_clconv_wgrad_x6(const float* dyp, int dy_pad, const float* x,
 extern "C" int ign_clconv_wgrad_bf16(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
                                      float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream) {
     return wgrad_x6_impl<1>("ign_clconv_wgrad_bf16", dyp, dy_pad, x, pro_a, pro_b, dw_oik, workspace, B, Tin, Ci, Co, k, stream);
+}
+
+// A Linear layer's weight AND bias gradient in one pass over dy: dW = dy^T x, db = column sums of dy (the tiles of the first
+// ci-column accumulate them from the dy values they stage anyway).  dy (M, Co), x (M, Ci); workspace as for
+// ign_clconv_wgrad_x6 with (B, Tin, k) = (1, M, 1).
+extern "C" int ign_linear_wgrad_x6(const float* dy, const float* x, float* dw, float* db, void* workspace, long long M, int Ci,
+                                   int Co, void* stream) {
+    if (M <= 0 || M > 0x7fffffffLL) { ign_set_error("ign_linear_wgrad_x6: M = %lld rows out of range", M); return IGN_E_ARG; }
+    return wgrad_x6_impl<3>("ign_linear_wgrad_x6", dy, 0, x, nullptr, nullptr, dw, workspace, 1, (int)M, Ci, Co, 1, stream, db);
+}
+extern "C" int ign_linear_wgrad_bf16(const float* dy, const float* x, float* dw, float* db, void* workspace, long long M, int Ci,
+                                     int Co, void* stream) {
+    if (M <= 0 || M > 0x7fffffffLL) { ign_set_error("ign_linear_wgrad_bf16: M = %lld rows out of range", M); return IGN_E_ARG; }
+    return wgrad_x6_impl<1>("ign_linear_wgrad_bf16", dy, 0, x, nullptr, nullptr, dw, workspace, 1, (int)M, Ci, Co, 1, stream, db);
 }

@@ -59,6 +59,8 @@ SIGNATURES = {
     "ign_clconv_fwd_bf16": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ign_clconv_dgrad_bf16": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ign_clconv_wgrad_bf16": (ci, [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ign_linear_wgrad_x6": (ci, [vp, vp, vp, vp, vp, ll, ci, ci, vp]),
+    "ign_linear_wgrad_bf16": (ci, [vp, vp, vp, vp, vp, ll, ci, ci, vp]),
     "ign_clconv_wgrad_workspace_bytes": (sz, [ci, ci, ci, ci, ci]),
     "ign_clconv_wgrad": (ci, [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ign_bn_finalize_fwd": (ci, [vp, ci, ll, ci, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp, vp]),

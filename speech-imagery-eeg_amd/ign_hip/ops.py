@@ -294,19 +294,23 @@ class LinearFn(torch.autograd.Function):
             _lib.check(_gemm(L, ctx.bf16)[0](_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, 1, M, Co, Ci, 1, _stream()),
                        "ign_clconv_fwd_x6(dx)")
             dx = dx.view(ctx.xshape)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty(Co, Ci, device=g2.device, dtype=torch.float32)
             if Ci % 4 == 0 and LINEAR_WGRAD == "bf16x6":
+                # weight and bias gradient in one pass over dy (the bias gradient rides on the tiles that stage dy anyway)
                 ws = torch.empty(int(L.ign_clconv_wgrad_x6_workspace_bytes(1, M, Ci, Co, 1)) // 4, device=g2.device,
                                  dtype=torch.float32)
-                _lib.check(_gemm(L, ctx.bf16)[1](_ptr(g2), 0, _ptr(x2), None, None, _ptr(dw), _ptr(ws), 1, M, Ci, Co, 1, _stream()),
-                           "ign_clconv_wgrad_x6")
+                if want_db:
+                    db = torch.empty(Co, device=g2.device, dtype=torch.float32)
+                fn = L.ign_linear_wgrad_bf16 if ctx.bf16 else L.ign_linear_wgrad_x6
+                _lib.check(fn(_ptr(g2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(ws), M, Ci, Co, _stream()), "ign_linear_wgrad_x6")
             else:
                 ws = torch.empty(int(L.ign_clconv_wgrad_workspace_bytes(1, M, Ci, Co, 1)) // 4, device=g2.device,
                                  dtype=torch.float32)
                 _lib.check(L.ign_clconv_wgrad(_ptr(g2), 0, _ptr(x2), None, None, _ptr(dw), _ptr(ws), 1, M, Ci, Co, 1, _stream()),
                            "ign_clconv_wgrad")
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if want_db and db is None:
             db = g2.sum(dim=0)
         return dx, dw, db
 
