@@ -128,6 +128,15 @@ int ign_attn_bwd_bf16(const float* q, const float* k, const float* v, const floa
                  int B, int L, int S, int H, int E,
                  long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl,
                  float scale, void* stream);
+/* ign_attn_bwd_x6 (bf16 = 0) / ign_attn_bwd_bf16 (bf16 = 1) writing gq / gk / gv with the caller's batch and sequence strides
+ * (elements, multiples of 4; head stride E): the three gradients can land in ONE packed (B, L, 3, H, E) buffer -- the gradient of
+ * a fused q/k/v projection -- without a gather pass.                                                                      */
+int ign_attn_bwd_x6_strided(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* gout,
+                 float* gq, float* gk, float* gv, float* delta_ws,
+                 int B, int L, int S, int H, int E,
+                 long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl,
+                 float scale, void* stream,
+                            long long g_sb, long long g_sl, int bf16);
 
 /* Skinny expert-head GEMM  out[b,n] = sum_f X[b,f] W[n,f] (+ bias[n]),  N <= 16 classes, F % 4 == 0, row pitch ldx.
  * Replaces nn.Linear at IGN/model/Shapelet.py:171,200 (SBM head), IGN/model/Transformer.py:72,109,

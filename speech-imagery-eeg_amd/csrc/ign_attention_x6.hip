@@ -273,6 +273,7 @@ struct AttnX6BwdArgs {
     const float *q, *k, *v, *o, *go, *lse, *delta; // o, go (B,L,H,E) contiguous; lse, delta (B,H,L)
     float *gq, *gk, *gv, *delta_out;               // delta_out: written by the dQ kernel (delta = rowsum(dO * O)), read by dK
     long long q_sb, q_sl, k_sb, k_sl, v_sb, v_sl;
+    long long gq_sb, gkv_sb, g_sl;                 // element strides of the gradient outputs (batch for gq / gk, gv; sequence)
     int B, L, S, H, E;
     float scale;
 };
@@ -467,7 +468,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_x6_kernel(const AttnX6BwdA
         for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(st[r] - lse_q) * (dp[r] - del_q);
         x6_tileT_times_acc<E, NP>(dQ, Ks, dp, lane);
     }
-    if (q_ok) store_grad_rows<E>(a.gq + (((long long)b * a.L + qi) * a.H + head) * E, dQ, a.scale, h);
+    if (q_ok) store_grad_rows<E>(a.gq + b * a.gq_sb + (long long)qi * a.g_sl + head * E, dQ, a.scale, h);
 }
 
 // ---- dK / dV: block = 4 waves x 32 keys (lanes); loops over query tiles.  S = Q K^T (rows = queries), P = exp(S - lse);
@@ -564,7 +565,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
         }
     }
     if (k_ok) {
-        float* dst = (DV ? a.gv : a.gk) + (((long long)b * a.S + ki) * a.H + head) * E;
+        float* dst = (DV ? a.gv : a.gk) + b * a.gkv_sb + (long long)ki * a.g_sl + head * E;
         store_grad_rows<E>(dst, G, DV ? 1.f : a.scale, h);
     }
 }
@@ -626,7 +627,7 @@ template <int NP>
 static int attn_bwd_x6_impl(const char* who, const float* q, const float* k, const float* v, const float* out, const float* lse,
                             const float* gout, float* gq, float* gk, float* gv, float* delta_ws, int B, int L, int S, int H,
                             int E, long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb,
-                            long long v_sl, float scale, void* stream) {
+                            long long v_sl, float scale, void* stream, long long g_sb = 0, long long g_sl = 0) {
     if (B <= 0 || L <= 0 || S <= 0 || H <= 0 || H > 65535 || B > 65535) {
         ign_set_error("%s: bad dimensions B=%d L=%d S=%d H=%d", who, B, L, S, H);
         return IGN_E_ARG;
@@ -634,6 +635,10 @@ static int attn_bwd_x6_impl(const char* who, const float* q, const float* k, con
     if (E != 16 && E != 32 && E != 64 && E != 128) {
         ign_set_error("%s: head dimension E=%d not instantiated (16, 32, 64, 128)", who, E);
         return IGN_E_UNSUP;
+    }
+    if ((g_sb != 0) != (g_sl != 0) || g_sb < 0 || (g_sb & 3) || (g_sl & 3) || (g_sl && g_sl < (long long)H * E)) {
+        ign_set_error("%s: gradient strides (%lld, %lld) must both be 0 (contiguous) or multiples of 4 with g_sl >= H*E", who, g_sb, g_sl);
+        return IGN_E_ARG;
     }
     const void* ptrs[10] = {q, k, v, out, lse, gout, gq, gk, gv, delta_ws};
     for (int i = 0; i < 10; ++i)
@@ -653,6 +658,9 @@ static int attn_bwd_x6_impl(const char* who, const float* q, const float* k, con
     a.gq = gq; a.gk = gk; a.gv = gv;
     a.q_sb = q_sb; a.q_sl = q_sl; a.k_sb = k_sb; a.k_sl = k_sl; a.v_sb = v_sb; a.v_sl = v_sl;
     a.B = B; a.L = L; a.S = S; a.H = H; a.E = E; a.scale = scale;
+    a.g_sl = g_sl ? g_sl : (long long)H * E;
+    a.gq_sb = g_sb ? g_sb : (long long)L * H * E;
+    a.gkv_sb = g_sb ? g_sb : (long long)S * H * E;
     const dim3 gk_grid((S + 127) / 128, H, B), gq_grid((L + 127) / 128, H, B);
 #define IGN_AB(EE, KERNEL, GRID)                                                                                              \
     do {                                                                                                                      \
@@ -704,4 +712,14 @@ extern "C" int ign_attn_fwd_bf16(IGN_ATTN_FWD_ARGS) {
 extern "C" int ign_attn_bwd_bf16(IGN_ATTN_BWD_ARGS) {
     return attn_bwd_x6_impl<1>("ign_attn_bwd_bf16", q, k, v, out, lse, gout, gq, gk, gv, delta_ws, B, L, S, H, E, q_sb, q_sl, k_sb,
                                k_sl, v_sb, v_sl, scale, stream);
+}
+
+// The same backward writing gq / gk / gv with the caller's batch and sequence strides (elements; head stride E): lets the three
+// gradients land in ONE packed (B, L, 3, H, E) buffer -- the gradient of a fused q/k/v projection -- without a gather.
+extern "C" int ign_attn_bwd_x6_strided(IGN_ATTN_BWD_ARGS, long long g_sb, long long g_sl, int bf16) {
+    if (g_sb <= 0 || g_sl <= 0) { ign_set_error("ign_attn_bwd_x6_strided: gradient strides must be positive"); return IGN_E_ARG; }
+    return bf16 ? attn_bwd_x6_impl<1>("ign_attn_bwd_x6_strided", q, k, v, out, lse, gout, gq, gk, gv, delta_ws, B, L, S, H, E, q_sb,
+                                      q_sl, k_sb, k_sl, v_sb, v_sl, scale, stream, g_sb, g_sl)
+                : attn_bwd_x6_impl<3>("ign_attn_bwd_x6_strided", q, k, v, out, lse, gout, gq, gk, gv, delta_ws, B, L, S, H, E, q_sb,
+                                      q_sl, k_sb, k_sl, v_sb, v_sl, scale, stream, g_sb, g_sl);
 }

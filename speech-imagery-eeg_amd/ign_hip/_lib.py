@@ -27,6 +27,8 @@ SIGNATURES = {
     "ign_attn_fwd_x6": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
     "ign_attn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
     "ign_attn_bwd_x6": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
+    "ign_attn_bwd_x6_strided": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp, ll, ll,
+                                     ci]),
     "ign_attn_fwd_bf16": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
     "ign_attn_bwd_bf16": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
     "ign_head_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ll, vp]),

@@ -200,6 +200,53 @@ def attention(q, k, v, scale):
     return AttentionFn.apply(q, k, v, scale)
 
 
+class PackedAttentionFn(torch.autograd.Function):
+    """Self-attention on a packed projection qkv (B, L, 3, H, E) -> (B, L, H, E): q / k / v are read as strided views and the
+    three gradients are written straight into one packed buffer (ign_attn_bwd_x6_strided), so a fused q/k/v Linear layer gets
+    its output gradient without a stack / gather pass."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale):
+        _need_gpu("attention", qkv)
+        qkv = qkv.contiguous()
+        B, L, three, H, E = qkv.shape
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        out = torch.empty(B, L, H, E, device=qkv.device, dtype=torch.float32)
+        lse = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32)
+        sb, sl = qkv.stride(0), qkv.stride(1)
+        L_ = _lib.lib()
+        ctx.bf16 = torch.is_autocast_enabled()
+        fwd = L_.ign_attn_fwd_bf16 if ctx.bf16 else L_.ign_attn_fwd_x6
+        _lib.check(fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, L, L, H, E, sb, sl, sb, sl, sb, sl, float(scale),
+                       _stream()), "ign_attn_fwd_x6")
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qkv, out, lse = ctx.saved_tensors
+        B, L, three, H, E = qkv.shape
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        gout = gout.contiguous()
+        gqkv = torch.empty_like(qkv)
+        delta = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32)
+        sb, sl = qkv.stride(0), qkv.stride(1)
+        _lib.check(_lib.lib().ign_attn_bwd_x6_strided(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(gout),
+                                                      _ptr(gqkv[:, :, 0]), _ptr(gqkv[:, :, 1]), _ptr(gqkv[:, :, 2]), _ptr(delta),
+                                                      B, L, L, H, E, sb, sl, sb, sl, sb, sl, ctx.scale, _stream(), sb, sl,
+                                                      1 if ctx.bf16 else 0), "ign_attn_bwd_x6_strided")
+        return gqkv, None
+
+
+def attention_packed(qkv, scale):
+    """softmax(scale q k^T) v for qkv (B, L, 3, H, E); the split-bf16 kernels cover E <= 64 (else the unpacked path)."""
+    E = qkv.shape[-1]
+    if ATTN_MATH != "bf16x6" or E > 64:
+        return attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], scale)
+    return PackedAttentionFn.apply(qkv, scale)
+
+
 class HeadLinearFn(torch.autograd.Function):
     """Skinny expert-head GEMM x (B,F) @ W(N,F)^T + bias -> (B,N) on ign_head_fwd/bwd."""
 

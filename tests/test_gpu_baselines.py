@@ -508,3 +508,23 @@ def test_eegcnn_inside_autocast_stays_on_the_hand_written_kernels(monkeypatch):
     d = _rel(out.float(), ref.float())
     assert 1e-6 < d < 8e-2, d
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("B,L,H,E", [(2, 200, 4, 64), (3, 77, 2, 32), (1, 130, 3, 16)])
+def test_packed_attention_equals_unpacked(B, L, H, E):
+    """ops.attention_packed on a packed (B, L, 3, H, E) projection: same output as the unpacked call, and the packed gradient
+    equals the three separate gradients stacked (written through ign_attn_bwd_x6_strided, no gather)."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    g = torch.Generator().manual_seed(B + L + H + E)
+    qkv = torch.randn(B, L, 3, H, E, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(B, L, H, E, generator=g).to(dev)
+    scale = 1.0 / math.sqrt(E)
+    o1 = ops.attention_packed(qkv, scale)
+    g1, = torch.autograd.grad(o1, qkv, go)
+    q, k, v = (qkv[:, :, i].detach().contiguous().requires_grad_(True) for i in range(3))
+    o2 = ops.attention(q, k, v, scale)
+    gq, gk, gv = torch.autograd.grad(o2, (q, k, v), go)
+    assert torch.equal(o1, o2)
+    assert torch.equal(g1, torch.stack([gq, gk, gv], dim=2))
