@@ -285,8 +285,10 @@ class HeadLinearFn(torch.autograd.Function):
 
 def head_linear(x, w, bias=None):
     """nn.Linear with few outputs (class logits).  Shapes the streaming kernel does not cover go to torch's GEMM
-    (still on the GPU; there is no CPU path)."""
-    if x.dim() != 2 or x.shape[1] % 4 or w.shape[0] > 16 or not x.is_cuda or x.dtype != torch.float32 \
+    (still on the GPU; CPU tensors are refused)."""
+    if not x.is_cuda:
+        raise _lib.IgnError(f"head_linear: tensor on {x.device}; the product path runs on the MI355X only (no CPU fallback)")
+    if x.dim() != 2 or x.shape[1] % 4 or w.shape[0] > 16 or x.dtype != torch.float32 \
             or w.dtype != torch.float32 or torch.is_autocast_enabled():
         return torch.nn.functional.linear(x, w, bias)
     return HeadLinearFn.apply(x, w, bias)
@@ -365,7 +367,9 @@ class LinearFn(torch.autograd.Function):
 def linear(x, w, bias=None):
     """nn.Linear / 1x1 Conv1d on the hand-written GEMM kernels (inside an autocast region: their single-product bf16 form);
     shapes they do not cover (and non-fp32 tensors) go to torch's GEMM."""
-    if (not x.is_cuda or x.dtype != torch.float32 or w.dtype != torch.float32
+    if not x.is_cuda:
+        raise _lib.IgnError(f"linear: tensor on {x.device}; the product path runs on the MI355X only (no CPU fallback)")
+    if (x.dtype != torch.float32 or w.dtype != torch.float32
             or w.shape[0] % 4 or x.numel() == 0 or x.shape[-1] != w.shape[1]
             or x.numel() // x.shape[-1] >= (1 << 30) or LINEAR_IMPL != "hip"):
         return torch.nn.functional.linear(x, w, bias)

@@ -31,7 +31,10 @@ class TokenEmbedding(nn.Module):
         nn.init.kaiming_normal_(self.tokenConv.weight, mode='fan_in', nonlinearity='leaky_relu')
 
     def forward(self, x):                       # (B,T,C) -> (B,T,d)
-        if x.is_cuda and x.dtype == torch.float32 and self.tokenConv.out_channels % 4 == 0:
+        if not x.is_cuda:
+            from ign_hip._lib import IgnError
+            raise IgnError(f"token embedding: tensor on {x.device}; the product path runs on the MI355X only (no CPU fallback)")
+        if x.dtype == torch.float32 and self.tokenConv.out_channels % 4 == 0:
             # circular padding = one wrapped row per side; then a valid channels-last convolution on the implicit-GEMM kernels
             from ign_hip import ops
             return ops.conv1d_cl(torch.cat([x[:, -1:], x, x[:, :1]], dim=1), self.tokenConv.weight)

@@ -41,7 +41,9 @@ class FullyConvNetwork(nn.Module):
         return F.relu(h)
 
     def forward(self, x, x_mark_enc=None, x_dec=None, x_mark_dec=None, mask=None, x_bct=None):
-        if x.is_cuda and x.dtype == torch.float32:
+        if not x.is_cuda:
+            raise ops._lib.IgnError(f"FCN expert: tensor on {x.device}; the deep experts run on the MI355X only (no CPU fallback)")
+        if x.dtype == torch.float32:
             if _USE_CLCONV:
                 # x (B,T,C) is already the channels-last operand of the implicit GEMM: no transpose, no im2col
                 pooled = fcn.fcn_body(x, [(b[0], b[1]) for b in (self.block1, self.block2, self.block3)])

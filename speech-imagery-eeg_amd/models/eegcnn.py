@@ -84,7 +84,7 @@ class EEGcnn(nn.Module):
         a 64x64 channel GEMM; BatchNorm-1's batch variance comes from ign_conv1_sumsq_* so the (B,F1,C,T) tensor of the
         reference (eegcnn.py:90-91) is never formed."""
         if not x.is_cuda:
-            return self._forward_reference_ops(x)
+            raise ops._lib.IgnError(f"EEG-CNN: tensor on {x.device}; the product path runs on the MI355X only (no CPU fallback)")
         if torch.is_autocast_enabled():
             # the reference's default bf16 mode: this block's VALU kernels have no bf16 form and run in fp32 (a superset of the
             # reference's accuracy); the encoder behind it picks the bf16 single-product GEMM / attention kernels itself

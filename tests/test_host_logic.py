@@ -318,3 +318,23 @@ def test_abi_argument_errors_of_the_gemm_and_attention_entry_points():
     for fn in (L.ign_attn_bwd_x6, L.ign_attn_bwd_bf16):
         assert fn(p, p, p, p, p, p, p, p, p, p, 1, 8, 8, 1, 24, 192, 24, 192, 24, 192, 24, 0.1, None) == UNSUP
         assert fn(p, p, p, p, p, p, p, p, None, p, 1, 8, 8, 1, 64, 512, 64, 512, 64, 512, 64, 0.1, None) == ARG
+
+
+@pytest.mark.parametrize("name", ["FCN", "ResNet", "PatchTST", "TimesNet", "Transformer", "EEGCNN"])
+def test_every_deep_expert_refuses_cpu_tensors(name):
+    """No silent CPU path anywhere in the product models: a CPU tensor raises IgnError in every deep expert / baseline."""
+    import contextlib, io
+    from conftest import make_cfg
+    from ign_hip._lib import IgnError
+    from models.InterpGN import dnn_dict
+    cfg = make_cfg(seq_len=96, d_model=16, d_ff=16, top_k=2, num_kernels=2, n_heads=1)
+    x = torch.randn(2, 96, 6)
+    mask = torch.ones(2, 96)
+    with contextlib.redirect_stdout(io.StringIO()):
+        if name == "EEGCNN":
+            from models.eegcnn import EEGCNNTransformer
+            m, args = EEGCNNTransformer(make_cfg(enc_in=6, seq_len=1000, num_class=3, c_out=3, d_model=64)), (torch.randn(2, 6, 1000),)
+        else:
+            m, args = dnn_dict[name](cfg), (x, mask, None, None)
+        with pytest.raises(IgnError):
+            m(*args)
