@@ -194,6 +194,12 @@ int ign_conv1_sumsq_fwd(const float* x, const float* w1, const float* mu, float*
 int ign_conv1_sumsq_bwd(const float* x, const float* w1, const float* mu, float* g_fj, void* workspace,
                         int rows, int T, int F1, int k1, int pad_left, void* stream);
 
+/* Lag sums C[d] = sum_rows sum_u x[row][u] x[row][u+d], d < K <= 128 -- with edge terms from the first / last k-1 samples of
+ * each row they give the window Gram matrix G[j,j'] = sum x_pad[t+j] x_pad[t+j'] and BatchNorm-1's batch variance of
+ * IGN/model/eegcnn.py:90-91 as the quadratic form w1^T G w1 (gradient 2 G w1): K*T FMA per row for all filters, no backward
+ * pass over the data.  part: (ign_autocorr_parts(rows), K) partial sums, added up by the caller in double.                   */
+long long ign_autocorr_parts(int rows);
+int ign_autocorr_fwd(const float* x_rows, float* part, int rows, int T, int K, void* stream);
 /* Depthwise (per-channel) 1-D convolution over time, zero 'same' padding: y[b,c,t] = sum_j w[c,j] xpad[b,c,t+j].
  * Replaces the temporal convolutions of IGN/model/eegcnn.py:67 (after the channel contraction) and :78 (block2_conv1).
  * flip=1 correlates with the reversed filter (gradient w.r.t. x: call with dy and pad_left = k-1-pad_left).

@@ -434,3 +434,61 @@ extern "C" int ign_dwconv1d_bwd_weight(const float* x, const float* dy, float* d
     ign_launch_reduce_parts((const float*)workspace, dw, nbs, (size_t)Cc * k, s);
     return ign_check_launch("reduce_parts_kernel");
 }
+
+// ------------------------------------------------------------------------------------------------ lag sums (autocorrelation)
+// C[d] = sum_rows sum_u x[row][u] * x[row][u + d], d = 0 .. K-1 (K <= 128).
+// BatchNorm-1 of the EEG-CNN block needs the batch variance of y[f] = w1[f] (*) x over (batch, electrode, time) -- the one
+// statistic that touches the un-contracted (B, F1, C, T) convolution (IGN/model/eegcnn.py:90-91).  sum_t y[f,t]^2 is the
+// quadratic form w1[f]^T G w1[f] with G[j,j'] = sum_{rows,t} xpad[t+j] xpad[t+j'], and G is this lag vector minus edge terms
+// that only involve the first / last k-1 samples of each row (models/eegcnn.py: _window_gram).  The lag sums cost K*T FMA per
+// row for ALL filters -- F1 times fewer than evaluating the convolutions (conv1_sumsq_fwd_kernel) -- and the gradient with
+// respect to w1 becomes 2 G w1: the 6.2e10-FMA backward pass (conv1_sumsq_bwd_kernel) disappears from the step.
+constexpr int AC_LAGS = 128;
+constexpr int AC_ROWS = 16;                       // rows per block (two at a time: threads 0..127 / 128..255)
+
+__global__ void __launch_bounds__(256) autocorr_kernel(const float* __restrict__ x, float* __restrict__ part, int rows, int T,
+                                                       int K, int xs_len) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int slot = threadIdx.x >> 7, d = threadIdx.x & 127;
+    float* xs = smem + slot * xs_len;
+    const int T4 = (T + 3) & ~3;
+    float acc = 0.f;
+    for (int i = 0; i < AC_ROWS; i += 2) {
+        const int r = blockIdx.x * AC_ROWS + i + slot;
+        __syncthreads();
+        for (int u = d; u < xs_len; u += AC_LAGS) xs[u] = (r < rows && u < T) ? x[(size_t)r * T + u] : 0.f;
+        __syncthreads();
+        if (d < K && r < rows) {
+            const float* xd = xs + d;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int u = 0; u < T4; u += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(xs + u);            // same address in every lane: broadcast
+                a0 = fmaf(a.x, xd[u], a0);
+                a1 = fmaf(a.y, xd[u + 1], a1);
+                a2 = fmaf(a.z, xd[u + 2], a2);
+                a3 = fmaf(a.w, xd[u + 3], a3);
+            }
+            acc += (a0 + a1) + (a2 + a3);
+        }
+    }
+    if (d < K) part[((size_t)blockIdx.x * 2 + slot) * K + d] = acc;
+}
+
+extern "C" long long ign_autocorr_parts(int rows) { return rows > 0 ? 2LL * ((rows + AC_ROWS - 1) / AC_ROWS) : 0; }
+
+// part: (ign_autocorr_parts(rows), K) partial lag sums; the caller adds them up (in double)
+extern "C" int ign_autocorr_fwd(const float* x, float* part, int rows, int T, int K, void* stream) {
+    static const char* who = "ign_autocorr_fwd";
+    if (!x || !part || rows <= 0 || T <= 0 || K <= 0) {
+        ign_set_error("%s: bad argument (rows=%d T=%d K=%d)", who, rows, T, K);
+        return IGN_E_ARG;
+    }
+    if (K > AC_LAGS) { ign_set_error("%s: K=%d lags exceed %d", who, K, AC_LAGS); return IGN_E_UNSUP; }
+    const int xs_len = (((T + 3) & ~3) + AC_LAGS + 4 + 3) & ~3;
+    const size_t lds = (size_t)2 * xs_len * sizeof(float);
+    if (lds > 64 * 1024) { ign_set_error("%s: T=%d needs %zu bytes of LDS", who, T, lds); return IGN_E_TOOBIG; }
+    const int nb = (rows + AC_ROWS - 1) / AC_ROWS;
+    IgnScopedTimer tm("autocorr", (hipStream_t)stream);
+    hipLaunchKernelGGL(autocorr_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, x, part, rows, T, K, xs_len);
+    return ign_check_launch("autocorr_kernel");
+}

@@ -531,6 +531,18 @@ class Conv1SumSqFn(torch.autograd.Function):
         return None, 2.0 * g.unsqueeze(1) * G, None, None
 
 
+def autocorr(x_rows, K):
+    """C[d] = sum over rows and u of x[row,u] * x[row,u+d], d < K <= 128, as float64 (ign_autocorr_fwd; no gradient: the
+    operand is input data)."""
+    _need_gpu("autocorr", x_rows)
+    L = _lib.lib()
+    x_rows = x_rows.contiguous()
+    R, T = x_rows.shape
+    part = torch.empty(int(L.ign_autocorr_parts(R)), K, device=x_rows.device, dtype=torch.float32)
+    _lib.check(L.ign_autocorr_fwd(_ptr(x_rows), _ptr(part), R, T, K, _stream()), "ign_autocorr_fwd")
+    return part.sum(dim=0, dtype=torch.float64)
+
+
 def conv1_sumsq(x_rows, w1, mu, pad_left):
     return Conv1SumSqFn.apply(x_rows, w1, mu, pad_left)
 

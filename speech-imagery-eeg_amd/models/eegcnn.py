@@ -12,6 +12,7 @@ in_proj_weight`` ... ``classifier.weight``).  The encoder layers are evaluated e
 attention core can run on the fused fp32-MFMA kernel instead of ``nn.MultiheadAttention``'s materialised scores.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -78,6 +79,43 @@ class EEGcnn(nn.Module):
         right = total - head                   # taps j = pl+1 .. k-1
         return torch.cat([left, total.reshape(1), right])
 
+    _GRAM_INDEX = {}
+
+    @classmethod
+    def _window_gram(cls, x2d, k, pl):
+        """G[j,j'] = sum_{rows} sum_{t<T} xp[t+j] xp[t+j'] (float64, (k,k)), xp = the row zero-padded by (pl, k-1-pl): the matrix
+        behind sum_t (w (*) x)[t]^2 = w^T G w.  G[j,j+d] = C[d] - sum_{s<j} xp[s] xp[s+d] - sum_{s>=T+j} xp[s] xp[s+d]: the full lag
+        sums C (ops.autocorr, one pass over x) minus edge terms that only involve the first / last k-1 samples of each row."""
+        R, T = x2d.shape
+        dev = x2d.device
+        C = ops.autocorr(x2d, k)
+        m = k - 1
+        key = (k, str(dev))
+        if key not in cls._GRAM_INDEX:
+            j, jp = torch.arange(k, device=dev).view(k, 1), torch.arange(k, device=dev).view(1, k)
+            col = torch.arange(m, device=dev).view(m, 1) + torch.arange(k, device=dev).view(1, k)       # s + d
+            cls._GRAM_INDEX[key] = ((jp - j).abs(), torch.minimum(j.expand(k, k), jp.expand(k, k)), col.clamp(max=m - 1), col < m)
+        d, lo, colc, valid = cls._GRAM_INDEX[key]
+        head = F.pad(x2d[:, :k - 1 - pl], (pl, 0))                 # xp[:, 0 : k-1]
+        tail = F.pad(x2d[:, T - pl:], (0, k - 1 - pl))             # xp[:, T : T+k-1]
+
+        def gram64(a):
+            # (m, R) @ (R, m) over ~1000-row chunks in fp32 (batched GEMM), chunks added in float64 (a float64 GEMM of this
+            # skinny shape takes 3.3 ms in hipBLAS; this takes 0.15)
+            nch = max(1, (R + 1023) // 1024)
+            rows = (R + nch - 1) // nch
+            a = F.pad(a, (0, 0, 0, nch * rows - R)).view(nch, rows, m)
+            return torch.bmm(a.transpose(1, 2), a).sum(dim=0, dtype=torch.float64)
+
+        Hh, Ht = gram64(head), gram64(tail)
+        zero = Hh.new_zeros(())
+        Dh = torch.where(valid, Hh.gather(1, colc), zero)          # D[s, d] = H[s, s+d]
+        Dt = torch.where(valid, Ht.gather(1, colc), zero)
+        z = Hh.new_zeros(1, k)
+        cumh = torch.cat([z, Dh.cumsum(0)], 0)                     # [j, d] = sum_{s<j}
+        cumt = torch.cat([Dt.flip(0).cumsum(0).flip(0), z], 0)     # [j, d] = sum_{s>=j}
+        return C[d] - cumh[lo, d] - cumt[lo, d]
+
     def forward(self, x):
         """(B, C, T) -> (B, F2, T / (P1*P2)).  GPU path: block 1 is evaluated as
         y2 = a_f * (w1[f] (*) (W2 x)) + b_f * rowsum(W2)  (see csrc/ign_eegcnn.hip), block 2 as a depthwise HIP convolution +
@@ -104,7 +142,15 @@ class EEGcnn(nn.Module):
         if bn1.training or not bn1.track_running_stats:
             n = B * C * T
             mu1 = (w1 @ self._shifted_sums(x, k1, pl1)) / n
-            var1 = ops.conv1_sumsq(x.view(B * C, T), w1, mu1, pl1) / n
+            if _BN1_VARIANCE == "gram" and k1 <= 128 and T >= k1:
+                # E[y^2] = w^T G w / n with the window Gram matrix of the INPUT (no pass over the (B,F1,C,T) convolution, and
+                # autograd's gradient 2 G w needs no pass over the data at all); float64 for the difference of two moments
+                with torch.no_grad():
+                    G = self._window_gram(x.view(B * C, T), k1, pl1)
+                wd = w1.double()
+                var1 = (torch.einsum('fj,jk,fk->f', wd, G, wd) / n - mu1.double().square()).float()
+            else:
+                var1 = ops.conv1_sumsq(x.view(B * C, T), w1, mu1, pl1) / n
             if bn1.track_running_stats:
                 with torch.no_grad():
                     bn1.num_batches_tracked.add_(1)
@@ -134,6 +180,11 @@ class EEGcnn(nn.Module):
         x = self.block2_conv2(self.block2_conv1(x))
         x = self.block2_drop(self.block2_pool(self.block2_elu(self.block2_bn(x))))
         return x.squeeze(2)                                          # (B,F2,T')
+
+
+# BatchNorm-1 batch variance: "gram" = quadratic form over the input's window Gram matrix (ops.autocorr); "conv" = brute-force
+# pass over the un-stored convolution (ign_conv1_sumsq_*: 3.1e10 FMA forward, 6.2e10 backward at the benchmark shape)
+_BN1_VARIANCE = os.environ.get("IGN_EEG_BN1", "gram")
 
 
 def _encoder_layer_forward(layer, x, n_heads):

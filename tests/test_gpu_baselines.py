@@ -528,3 +528,22 @@ def test_packed_attention_equals_unpacked(B, L, H, E):
     gq, gk, gv = torch.autograd.grad(o2, (q, k, v), go)
     assert torch.equal(o1, o2)
     assert torch.equal(g1, torch.stack([gq, gk, gv], dim=2))
+
+
+@pytest.mark.parametrize("R,T,k,pl", [(7, 200, 125, 62), (33, 1000, 125, 62), (5, 64, 25, 12), (3, 130, 8, 0), (2, 129, 128, 127)])
+def test_window_gram_matrix_equals_brute_force(R, T, k, pl):
+    """EEGcnn._window_gram (lag sums from ign_autocorr_fwd + edge terms) against the brute-force Gram matrix of all padded windows
+    in float64, and the quadratic form against sum_t (w (*) x)^2 of the convolution itself."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models.eegcnn import EEGcnn
+    g = torch.Generator().manual_seed(R + T + k)
+    x = torch.randn(R, T, generator=g)
+    G = EEGcnn._window_gram(x.to(dev), k, pl).cpu()
+    xp = F.pad(x.double(), (pl, k - 1 - pl))
+    W = xp.unfold(1, k, 1)[:, :T]
+    Gref = torch.einsum('rtj,rtk->jk', W, W)
+    assert float((G - Gref).abs().max() / Gref.abs().max()) < 2e-6
+    w = torch.randn(4, k, generator=g).double()
+    y = F.conv1d(xp.unsqueeze(1), w.unsqueeze(1))                                   # (R, 4, T)
+    assert _rel(torch.einsum('fj,jk,fk->f', w, G, w), y.square().sum(dim=(0, 2))) < 2e-6
