@@ -116,6 +116,11 @@ def main():
                     help="fp32 = the parity path (the reference run with --amp, BASELINE.json's headline); bf16 = the "
                          "reference's DEFAULT mode, torch.autocast(bfloat16) around forward + loss: GEMM operands rounded to "
                          "bf16 on the same kernels (one product per MFMA step), shapelet path and softmax stay fp32")
+    ap.add_argument("--dnn", choices=["FCN", "ResNet", "PatchTST", "TimesNet"], default="FCN",
+                    help="deep expert of the gated mixture (config ign): FCN = the reference driver's default and the headline; "
+                         "the others are the remaining `--dnn_type` experts (PatchTST: d_model 64, d_ff 128, 4 heads; TimesNet: "
+                         "d_model 32, d_ff 32, top-3 periods, 6 inception kernels -- the reference's 512 / 2048 defaults put 3.9 M "
+                         "patch tokens / 121-tap 2-D convolutions over 2048 channels on this input)")
     ap.add_argument("--config", choices=["ign", "eegcnn", "transformer"], default="ign",
                     help="ign = BASELINE.json's headline (config 1 / 5); eegcnn / transformer = the baselines of "
                          "configs 3 / 4 on the same synthetic tensors")
@@ -150,7 +155,11 @@ def main():
     from ign_hip.ddp import FlatAdam, FlatParamBucket
     from models.InterpGN import InterpGN
 
-    cfg = ch_config()
+    cfg = ch_config(dnn_type=args.dnn)
+    if args.dnn == "PatchTST":
+        cfg.d_model, cfg.d_ff, cfg.n_heads = 64, 128, 4
+    elif args.dnn == "TimesNet":
+        cfg.d_model, cfg.d_ff, cfg.top_k, cfg.num_kernels = 32, 32, 3, 6
     B, T, C = args.batch, cfg.seq_len, cfg.enc_in
     torch.manual_seed(0)                       # same initial replica on every rank
     if args.config == "ign":
@@ -308,6 +317,8 @@ def main():
         }
         if amp:
             res["metric"] += " [reference default precision: bf16 autocast]"
+        if args.config == "ign" and args.dnn != "FCN":
+            res["metric"] += f" [deep expert {args.dnn}]"
         common = {"per_gpu_batch": B, "global_batch": B * world, "samples_per_epoch": N_TRAIN,
                   "parallelism": f"dp{world}", "final_loss": float(last), "hipgraph": bool(use_graph)}
         if rehearsal:

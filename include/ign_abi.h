@@ -194,6 +194,16 @@ int ign_conv1_sumsq_fwd(const float* x, const float* w1, const float* mu, float*
 int ign_conv1_sumsq_bwd(const float* x, const float* w1, const float* mu, float* g_fj, void* workspace,
                         int rows, int T, int F1, int k1, int pad_left, void* stream);
 
+/* LayerNorm over the last dimension of an (R, D) matrix (nn.LayerNorm semantics: biased variance, eps inside the sqrt), forward
+ * and backward; D % 4 == 0, D <= 4096 (backward: D <= 2048).  fwd saves mean / rstd (R each).  bwd: gx and, when not NULL,
+ * dgamma / dbeta (fixed-order two-pass reduction: reproducible); part = ign_layernorm_parts(R, D) * 2 * D floats of workspace.
+ * Replaces IGN/layers/Transformer_EncDec.py:36-37,48,76-77, the norms of nn.TransformerEncoderLayer in IGN/model/eegcnn.py:219-228
+ * and IGN/model/TimesNet.py:197.                                                                                          */
+long long ign_layernorm_parts(long long R, int D);
+int ign_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long long R, int D,
+                      float eps, void* stream);
+int ign_layernorm_bwd(const float* x, const float* gy, const float* gamma, const float* mean, const float* rstd, float* gx,
+                      float* dgamma, float* dbeta, float* part, long long R, int D, void* stream);
 /* Lag sums C[d] = sum_rows sum_u x[row][u] x[row][u+d], d < K <= 128 -- with edge terms from the first / last k-1 samples of
  * each row they give the window Gram matrix G[j,j'] = sum x_pad[t+j] x_pad[t+j'] and BatchNorm-1's batch variance of
  * IGN/model/eegcnn.py:90-91 as the quadratic form w1^T G w1 (gradient 2 G w1): K*T FMA per row for all filters, no backward

@@ -23,6 +23,9 @@ SIGNATURES = {
     "ign_standardise_nct_to_btc": (ci, [vp, vp, vp, ci, ci, ci, cf, vp]),
     "ign_shapelet_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),
     "ign_shapelet_bwd_workspace_bytes": (sz, [ci, ci, ci, ci, ci, ci, ci]),
+    "ign_layernorm_parts": (ll, [ll, ci]),
+    "ign_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ll, ci, cf, vp]),
+    "ign_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp]),
     "ign_autocorr_parts": (ll, [ci]),
     "ign_autocorr_fwd": (ci, [vp, vp, ci, ci, ci, vp]),
     "ign_attn_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),

@@ -11,6 +11,8 @@ import os
 DIST_L1, DIST_MSE, DIST_COS, DIST_PEARSON = 0, 1, 2, 3
 LINEAR_IMPL = os.environ.get("IGN_LINEAR", "hip")      # "torch": route ops.linear to hipBLASLt (A/B measurements)
 ATTN_MATH = os.environ.get("IGN_ATTN_MATH", "bf16x6")          # "f32": attention core on the fp32-MFMA kernels
+LAYERNORM_IMPL = os.environ.get("IGN_LAYERNORM", "hip")          # "torch": nn.LayerNorm's own kernels (A/B runs)
+LAYERNORM_MIN_ROWS = 65536
 LINEAR_WGRAD = os.environ.get("IGN_LINEAR_WGRAD", "bf16x6")   # "f32": weight gradient of ops.linear on the fp32-MFMA TN kernel
 GATE_RBF, GATE_LTS = 0x00, 0x10
 
@@ -374,6 +376,57 @@ def linear(x, w, bias=None):
             or x.numel() // x.shape[-1] >= (1 << 30) or LINEAR_IMPL != "hip"):
         return torch.nn.functional.linear(x, w, bias)
     return LinearFn.apply(x, w, bias)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension on ign_layernorm_fwd / _bwd (HBM-bound row kernels; torch's kernels for narrow rows
+    -- PatchTST's 3.9 M rows of 64 -- run 10x off the memory roofline)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _need_gpu("layer_norm", x, weight, bias)
+        L = _lib.lib()
+        D = x.shape[-1]
+        x2 = x.reshape(-1, D)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        R = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(R, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(R, device=x.device, dtype=torch.float32)
+        _lib.check(L.ign_layernorm_fwd(_ptr(x2), _ptr(weight), _ptr(bias), _ptr(y), _ptr(mean), _ptr(rstd), R, D, float(eps),
+                                       _stream()), "ign_layernorm_fwd")
+        ctx.save_for_backward(x2, weight, mean, rstd)
+        ctx.has_bias = bias is not None
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        x2, weight, mean, rstd = ctx.saved_tensors
+        R, D = x2.shape
+        g2 = gy.reshape(R, D)
+        g2 = g2 if g2.is_contiguous() else g2.contiguous()
+        gx = torch.empty_like(x2)
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dgamma = torch.empty(D, device=x2.device, dtype=torch.float32) if need_w else None
+        dbeta = torch.empty(D, device=x2.device, dtype=torch.float32) if need_w and ctx.has_bias else None
+        part = torch.empty(int(L.ign_layernorm_parts(R, D)) * 2 * D, device=x2.device, dtype=torch.float32)
+        _lib.check(L.ign_layernorm_bwd(_ptr(x2), _ptr(g2), _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dgamma), _ptr(dbeta),
+                                       _ptr(part), R, D, _stream()), "ign_layernorm_bwd")
+        return gx.view(gy.shape), dgamma, dbeta, None
+
+
+def layer_norm(x, norm):
+    """Apply an nn.LayerNorm module (normalised over the last dimension, affine) on the hand-written kernels; shapes they do not
+    cover go through the module itself (torch on the GPU)."""
+    D = x.shape[-1]
+    # below ~64k rows the op is launch-bound and torch's single fused backward wins by a few microseconds per call (EEG-CNN:
+    # 25 600 rows, 8.34 vs 8.50 ms/step); above, torch's kernels fall off the memory roofline (Transformer: 256 000 rows of 512,
+    # 96.9 -> 94.9 ms/step; PatchTST: 3.9 M rows of 64, 123.9 -> 79.4 ms/step)
+    if (not x.is_cuda or x.dtype != torch.float32 or norm.weight is None or len(norm.normalized_shape) != 1 or D % 4 or D > 2048
+            or x.numel() < LAYERNORM_MIN_ROWS * D or LAYERNORM_IMPL != "hip"):
+        return norm(x)
+    return LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
 
 
 class ConvCLFn(torch.autograd.Function):

@@ -21,12 +21,12 @@ class EncoderLayer(nn.Module):
 
     def forward(self, x, attn_mask=None, tau=None, delta=None):
         new_x, attn = self.attention(x, x, x, attn_mask=attn_mask, tau=tau, delta=delta)
-        x = self.norm1(x + self.dropout(new_x))
+        x = ops.layer_norm(x + self.dropout(new_x), self.norm1)
         # the k=1 convolutions are plain GEMMs over (B*T, d): apply them without the two transposes
         y = ops.linear(x, self.conv1.weight.squeeze(-1), self.conv1.bias)
         y = self.dropout(self.activation(y))
         y = self.dropout(ops.linear(y, self.conv2.weight.squeeze(-1), self.conv2.bias))
-        return self.norm2(x + y), attn
+        return ops.layer_norm(x + y, self.norm2), attn
 
 
 class Encoder(nn.Module):
@@ -44,5 +44,5 @@ class Encoder(nn.Module):
             x, attn = layer(x, attn_mask=attn_mask, tau=tau, delta=delta)
             attns.append(attn)
         if self.norm is not None:
-            x = self.norm(x)
+            x = ops.layer_norm(x, self.norm) if isinstance(self.norm, nn.LayerNorm) else self.norm(x)
         return x, attns

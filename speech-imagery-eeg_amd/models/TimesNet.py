@@ -120,7 +120,7 @@ class Model(nn.Module):
             raise IgnError(f"TimesNet expert: tensor on {x_enc.device}; the deep experts run on the MI355X only (no CPU fallback)")
         enc_out = self.enc_embedding(x_enc, None)
         for i in range(self.layer):
-            enc_out = self.layer_norm(self.model[i](enc_out))
+            enc_out = ops.layer_norm(self.model[i](enc_out), self.layer_norm)
         output = self.dropout(self.act(enc_out))
         output = output * x_mark_enc.unsqueeze(-1)                              # zero the padded steps
         return ops.head_linear(output.reshape(output.shape[0], -1), self.projection.weight, self.projection.bias)

@@ -194,10 +194,10 @@ def _encoder_layer_forward(layer, x, n_heads):
     qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias).view(B, S, 3, n_heads, d // n_heads)
     o = ops.attention_packed(qkv, 1.0 / math.sqrt(d // n_heads))      # gradients land in one packed buffer
     a = ops.linear(o.reshape(B, S, d), sa.out_proj.weight, sa.out_proj.bias)
-    x = layer.norm1(x + layer.dropout1(a))
+    x = ops.layer_norm(x + layer.dropout1(a), layer.norm1)
     ff = ops.linear(layer.dropout(F.relu(ops.linear(x, layer.linear1.weight, layer.linear1.bias))), layer.linear2.weight,
                     layer.linear2.bias)
-    return layer.norm2(x + layer.dropout2(ff))
+    return ops.layer_norm(x + layer.dropout2(ff), layer.norm2)
 
 
 class EEGCNNTransformer(nn.Module):

@@ -547,3 +547,40 @@ def test_window_gram_matrix_equals_brute_force(R, T, k, pl):
     w = torch.randn(4, k, generator=g).double()
     y = F.conv1d(xp.unsqueeze(1), w.unsqueeze(1))                                   # (R, 4, T)
     assert _rel(torch.einsum('fj,jk,fk->f', w, G, w), y.square().sum(dim=(0, 2))) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(1000, 64), (7, 33, 16), (3, 100, 512), (2, 5, 2048), (130, 12), (4, 9, 200), (1, 1, 128)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_layer_norm_against_float64(shape, bias, monkeypatch):
+    """ops.layer_norm (ign_layernorm_fwd / _bwd) against float64 torch: output, input gradient, d(gamma), d(beta); bitwise
+    reproducible across calls."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    monkeypatch.setattr(ops, "LAYERNORM_MIN_ROWS", 0)          # exercise the kernels at every size
+    D = shape[-1]
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g) * 3 + 1.5
+    gy = torch.randn(*shape, generator=g)
+    ln = torch.nn.LayerNorm(D, bias=bias)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        if bias:
+            ln.bias.normal_(0, 0.3)
+    ref = torch.nn.LayerNorm(D, bias=bias).double()
+    ref.load_state_dict({k: v.double() for k, v in ln.state_dict().items()})
+    xd = x.double().requires_grad_(True)
+    (ref(xd) * gy.double()).sum().backward()
+    lg = ln.to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    y = ops.layer_norm(xg, lg)
+    (y * gy.to(dev)).sum().backward()
+    assert _rel(y, ref(xd)) < 2e-6
+    assert _rel(xg.grad, xd.grad) < 5e-6
+    assert _rel(lg.weight.grad, ref.weight.grad) < 1e-5
+    if bias:
+        assert _rel(lg.bias.grad, ref.bias.grad) < 1e-5
+    g1 = (xg.grad.clone(), lg.weight.grad.clone())
+    xg.grad = None; lg.weight.grad = None
+    (ops.layer_norm(xg, lg) * gy.to(dev)).sum().backward()
+    assert torch.equal(g1[0], xg.grad) and torch.equal(g1[1], lg.weight.grad)
