@@ -475,12 +475,28 @@ class ConvCLFn(torch.autograd.Function):
             _lib.check(_gemm(L, ctx.bf16)[0](_ptr(gyp), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, B, Tout + 2 * (k - 1), Co, Ci,
                                              k, _stream()), "ign_clconv_fwd_x6(dx)")
         if ctx.needs_input_grad[1]:
-            dw = torch.empty(Co, Ci, k, device=gy.device, dtype=torch.float32)
             x6 = k in (2, 3, 5, 8) and LINEAR_WGRAD == "bf16x6"
-            wsb, fn, name = ((L.ign_clconv_wgrad_x6_workspace_bytes, _gemm(L, ctx.bf16)[1], "ign_clconv_wgrad_x6") if x6 else
-                             (L.ign_clconv_wgrad_workspace_bytes, L.ign_clconv_wgrad, "ign_clconv_wgrad"))
-            ws = torch.empty(max(1, int(wsb(B, Tin, Ci, Co, k)) // 4), device=gy.device, dtype=torch.float32)
-            _lib.check(fn(_ptr(gyp), k - 1, _ptr(x), None, None, _ptr(dw), _ptr(ws), B, Tin, Ci, Co, k, _stream()), name)
+            if not x6 and k > 1 and Ci % 4 == 0 and LINEAR_WGRAD == "bf16x6":
+                # tap counts without an instantiated multi-tap kernel (k = 4, 7, 11, ...): one k = 1 GEMM per tap on FLAT row
+                # views.  With dy zero-padded by k-1 rows at the END of every sample, dW[:, :, j] = dy_flat[0 : M-j]^T x_flat[j : M]
+                # -- the pairs that straddle two samples multiply zero rows -- so each tap is the Linear-layer weight gradient
+                # on the split-bf16 kernel with the operand pointer advanced by j rows (no copies of x).
+                M = B * Tin
+                dye = torch.nn.functional.pad(gy, (0, 0, 0, k - 1)).contiguous()
+                dwt = torch.empty(k, Co, Ci, device=gy.device, dtype=torch.float32)
+                ws = torch.empty(int(L.ign_clconv_wgrad_x6_workspace_bytes(1, M, Ci, Co, 1)) // 4, device=gy.device,
+                                 dtype=torch.float32)
+                fn = L.ign_linear_wgrad_bf16 if ctx.bf16 else L.ign_linear_wgrad_x6
+                for j in range(k):
+                    _lib.check(fn(_ptr(dye), ctypes.c_void_p(x.data_ptr() + 4 * j * Ci), _ptr(dwt[j]), None, _ptr(ws), M - j, Ci, Co,
+                                  _stream()), "ign_linear_wgrad_x6(tap)")
+                dw = dwt.permute(1, 2, 0).contiguous()
+            else:
+                dw = torch.empty(Co, Ci, k, device=gy.device, dtype=torch.float32)
+                wsb, fn, name = ((L.ign_clconv_wgrad_x6_workspace_bytes, _gemm(L, ctx.bf16)[1], "ign_clconv_wgrad_x6") if x6 else
+                                 (L.ign_clconv_wgrad_workspace_bytes, L.ign_clconv_wgrad, "ign_clconv_wgrad"))
+                ws = torch.empty(max(1, int(wsb(B, Tin, Ci, Co, k)) // 4), device=gy.device, dtype=torch.float32)
+                _lib.check(fn(_ptr(gyp), k - 1, _ptr(x), None, None, _ptr(dw), _ptr(ws), B, Tin, Ci, Co, k, _stream()), name)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1))
         return dx, dw, db

@@ -37,6 +37,27 @@ def FFT_for_Period(x, k=2):
     return period, amp.mean(-1)[:, top_list]
 
 
+class _RowStack(torch.autograd.Function):
+    """(B, H+K-1, W, C) -> (B, H, W, K, C): out[b, h, w, r, :] = hp[b, h+r, w, :] (the K kernel rows stacked into the channel
+    axis).  The backward adds the K slices back in place -- autograd's own slice gradients allocate and add a full-size zero
+    tensor per slice."""
+
+    @staticmethod
+    def forward(ctx, hp, K):
+        H = hp.shape[1] - K + 1
+        ctx.K = K
+        return torch.stack([hp[:, r:r + H] for r in range(K)], dim=3)
+
+    @staticmethod
+    def backward(ctx, g):
+        K = ctx.K
+        B, H, W, _, C = g.shape
+        ghp = g.new_zeros(B, H + K - 1, W, C)
+        for r in range(K):
+            ghp[:, r:r + H] += g[:, :, :, r]
+        return ghp, None
+
+
 class Inception_Block_V1(nn.Module):
     def __init__(self, in_channels, out_channels, num_kernels=6, init_weight=True):
         super().__init__()
@@ -63,7 +84,7 @@ class Inception_Block_V1(nn.Module):
         P, K = self.num_kernels - 1, 2 * self.num_kernels - 1
         w, b = self.fused_kernel()
         hp = F.pad(h, (0, 0, P, P, P, P))
-        rows = torch.stack([hp[:, r:r + H] for r in range(K)], dim=3)            # (B, H, W+2P, K, C)
+        rows = _RowStack.apply(hp, K)                                            # (B, H, W+2P, K, C)
         w2 = w.permute(0, 2, 1, 3).reshape(self.out_channels, K * C, K)           # [co][(row r, ci)][column s]
         y = ops.conv1d_cl(rows.view(B * H, W + 2 * P, K * C), w2, b)
         return y.view(B, H, W, self.out_channels)
