@@ -584,3 +584,57 @@ def test_layer_norm_against_float64(shape, bias, monkeypatch):
     xg.grad = None; lg.weight.grad = None
     (ops.layer_norm(xg, lg) * gy.to(dev)).sum().backward()
     assert torch.equal(g1[0], xg.grad) and torch.equal(g1[1], lg.weight.grad)
+
+
+# ------------------------------------------------------------------ size-independent properties at the benchmark shape (B=256, L=1000)
+def test_attention_x6_full_size_batch_independence_and_linearity():
+    """B=256, H=8, L=S=1000, E=64 (the Transformer baseline's attention): every sample's output / gradients equal those of a
+    2-sample call holding the same samples (bitwise: no cross-sample coupling, no launch-shape dependence), the output is linear
+    in V, and permuting the keys leaves it unchanged up to rounding."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    B, L, H, E = 256, 1000, 8, 64
+    g = torch.Generator(device="cpu").manual_seed(7)
+    q = torch.randn(B, L, H, E, generator=g).to(dev).requires_grad_(True)
+    k = torch.randn(B, L, H, E, generator=g).to(dev).requires_grad_(True)
+    v = torch.randn(B, L, H, E, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(B, L, H, E, generator=g).to(dev)
+    o = ops.attention(q, k, v, 0.125)
+    gq, gk, gv = torch.autograd.grad(o, (q, k, v), go)
+    idx = [3, 250]
+    qs, ks, vs = (t[idx].detach().clone().requires_grad_(True) for t in (q, k, v))
+    os_ = ops.attention(qs, ks, vs, 0.125)
+    gqs, gks, gvs = torch.autograd.grad(os_, (qs, ks, vs), go[idx])
+    assert torch.equal(o[idx], os_) and torch.equal(gq[idx], gqs) and torch.equal(gk[idx], gks) and torch.equal(gv[idx], gvs)
+    with torch.no_grad():
+        o2 = ops.attention(q[:8], k[:8], 2.5 * v[:8], 0.125)
+        assert _rel(o2, 2.5 * o[:8]) < 1e-5
+        perm = torch.randperm(L, generator=g).to(dev)
+        o3 = ops.attention(q[:8], k[:8][:, perm].contiguous(), v[:8][:, perm].contiguous(), 0.125)
+        assert _rel(o3, o[:8]) < 1e-5
+
+
+def test_linear_x6_full_size_row_independence_and_additivity():
+    """M = 256 000 rows, 512 -> 2048 (the Transformer FFN): output rows equal those of a small call on the same rows (bitwise), the
+    weight gradient is additive over row halves and the bias gradient is the column sum of the upstream gradient."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    M, Ci, Co = 256000, 512, 2048
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(M, Ci, generator=g).to(dev)
+    w = (torch.randn(Co, Ci, generator=g) / Ci ** 0.5).to(dev).requires_grad_(True)
+    b = torch.randn(Co, generator=g).to(dev).requires_grad_(True)
+    gy = torch.randn(M, Co, generator=g).to(dev)
+    y = ops.linear(x, w, b)
+    rows = slice(128 * 700, 128 * 702)                      # two whole 128-row tiles
+    with torch.no_grad():
+        assert torch.equal(y[rows], ops.linear(x[rows].contiguous(), w, b))
+    dw, db = torch.autograd.grad(y, (w, b), gy)
+    h = M // 2
+    y1, y2 = ops.linear(x[:h], w, b), ops.linear(x[h:], w, b)
+    dw1, db1 = torch.autograd.grad(y1, (w, b), gy[:h])
+    dw2, db2 = torch.autograd.grad(y2, (w, b), gy[h:])
+    assert _rel(dw, dw1 + dw2) < 1e-5 and _rel(db, db1 + db2) < 1e-5
+    assert _rel(db, gy.double().sum(0)) < 1e-5
