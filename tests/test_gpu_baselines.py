@@ -638,3 +638,27 @@ def test_linear_x6_full_size_row_independence_and_additivity():
     dw2, db2 = torch.autograd.grad(y2, (w, b), gy[h:])
     assert _rel(dw, dw1 + dw2) < 1e-5 and _rel(db, db1 + db2) < 1e-5
     assert _rel(db, gy.double().sum(0)) < 1e-5
+
+
+def test_resnet_and_layernorm_full_size_sample_independence():
+    """ResNet expert in eval mode at the benchmark shape (B=256, T=1000, C=122): a sample's logits do not depend on the batch it
+    sits in (bitwise; convolution tiles never straddle samples).  LayerNorm at PatchTST's row count (3.9 M rows of 64): rows are
+    independent of the launch shape."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    from models.ResNet import Model
+    torch.manual_seed(0)
+    m = Model(make_cfg(enc_in=122, seq_len=1000, num_class=3)).to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(256, 1000, 122, generator=g).to(dev)
+    with torch.no_grad():
+        full = m(x)
+        part = m(x[[5, 77, 255]].contiguous())
+    assert torch.equal(full[[5, 77, 255]], part)
+    ln = torch.nn.LayerNorm(64).to(dev)
+    h = torch.randn(256 * 122 * 125, 64, generator=g).to(dev)
+    with torch.no_grad():
+        y = ops.layer_norm(h, ln)
+        assert torch.equal(y[1000003:1000003 + 70000], ops.layer_norm(h[1000003:1000003 + 70000].contiguous(), ln))
+        assert _rel(y[:4096], torch.nn.functional.layer_norm(h[:4096].double(), (64,), ln.weight.double(), ln.bias.double())) < 2e-6
