@@ -85,7 +85,7 @@ __device__ __forceinline__ void lds_load(float (&dst)[JJ], const float* p) {
 }
 
 template <int JJ, int DIST>
-__global__ void __launch_bounds__(512, 8) shp_bwd_kernel(const ShpBwdArgs a) {
+__global__ void __launch_bounds__(512, 7) shp_bwd_kernel(const ShpBwdArgs a) {
     static_assert(JJ % 4 == 0, "float4 LDS reads need 4-float alignment");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                        // [xs_len]      x[b,c,t0 + i]
