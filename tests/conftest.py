@@ -56,3 +56,62 @@ def _reset_torch_matmul_precision():
     torch.set_float32_matmul_precision('highest')
     yield
     torch.set_float32_matmul_precision('highest')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Parity ledger.  Every golden / oracle comparison of a `-m gpu` test goes through `parity()`, which records the error
+# actually observed (max abs error, the scale it is judged against, and the error as a multiple of north_star's 1e-4
+# budget) before asserting.  At session end the ledger is written to gpurun_out/parity.json; the copy judged is
+# committed as profiles/parity_r2.json.  IGN_PARITY_RECORD_ONLY=1 records without asserting (used once to survey).
+_LEDGER = {}
+NORTH_STAR_TOL = 1e-4
+
+
+def _np64(a):
+    import torch
+    if torch.is_tensor(a):
+        a = a.detach().double().cpu().numpy()
+    return np.asarray(a, dtype=np.float64)
+
+
+def parity(label, got, ref, tol=NORTH_STAR_TOL, kind="scale", floor=0.0, f64=None, ref_is="reference fp32"):
+    """kind="elem":  |got-ref| <= tol*(1+|ref|) element-wise (numpy allclose with rtol=atol=tol) -- for O(1) outputs.
+    kind="scale": max|got-ref| <= tol*max(max|ref|, floor) -- for gradients / statistics whose scale is not O(1).
+    `f64` (optional) is a float64 run of the same reference module: when the fp32 fixture itself is further than `tol`
+    from it, the bound widens to the reference's own distance from float64 (the HIP result must be no further from
+    the exact answer than the reference's fp32 result is) -- both distances are recorded."""
+    g, r = _np64(got), _np64(ref)
+    assert g.shape == r.shape, f"{label}: shape {g.shape} vs {r.shape}"
+    diff = np.abs(g - r)
+    if kind == "elem":
+        budget = float((diff / (1.0 + np.abs(r))).max()) if diff.size else 0.0
+        scale = float(np.abs(r).max()) if r.size else 0.0
+    else:
+        scale = max(float(np.abs(r).max()) if r.size else 0.0, floor, 1e-30)
+        budget = float(diff.max()) / scale if diff.size else 0.0
+    rec = dict(max_abs_err=float(diff.max()) if diff.size else 0.0, scale=scale, kind=kind, tol=tol,
+               err_over_1e4=budget / NORTH_STAR_TOL, against=ref_is)
+    ok = budget <= tol
+    if f64 is not None:
+        t = _np64(f64)
+        sc = max(float(np.abs(t).max()), floor, 1e-30)
+        e_hip, e_ref = float(np.abs(g - t).max()) / sc, float(np.abs(r - t).max()) / sc
+        rec.update(hip_vs_f64=e_hip, ref_fp32_vs_f64=e_ref)
+        ok = ok or e_hip <= max(tol, e_ref)
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::", 1)[-1]
+    _LEDGER.setdefault(test, {})[label] = rec
+    if os.environ.get("IGN_PARITY_RECORD_ONLY") != "1":
+        assert ok, f"{label}: {rec}"
+    return rec
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _LEDGER:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    worst = max((r["err_over_1e4"] for t in _LEDGER.values() for r in t.values()), default=0.0)
+    with open(os.path.join(out, "parity.json"), "w") as f:
+        json.dump(dict(north_star_tol=NORTH_STAR_TOL, worst_err_over_1e4=worst, n_records=sum(len(t) for t in _LEDGER.values()),
+                       tests=_LEDGER), f, indent=1, sort_keys=True)

@@ -403,10 +403,143 @@ def case_run_flags(R=None):
 CASES["run_flags"] = case_run_flags
 
 
+
+
+# ------------------------------------------------------------------------------------ data contract
+def _import_data_factory():
+    """The reference's data_factory package with in-memory stubs for the packages this image lacks (`mne`, `sktime`:
+    SURVEY D13).  `sktime.datasets.load_from_tsfile_to_dataframe` is bound to the reference's OWN vendored copy of that
+    parser (IGN/data_factory/monash.py:36), so UEAloader runs unmodified on top of reference code only."""
+    import importlib
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for n in ("mne", "seaborn", "patoolib", "sktime", "sktime.datasets"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sink = io.StringIO()
+    with contextlib.redirect_stdout(sink):
+        sys.modules["data_provider"] = importlib.import_module("data_factory")          # D1: the directory's other spelling
+        monash = importlib.import_module("data_factory.monash")
+        sys.modules["sktime.datasets"].load_from_tsfile_to_dataframe = monash.load_from_tsfile_to_dataframe
+        sys.modules["sktime"].datasets = sys.modules["sktime.datasets"]
+        mods = {n: importlib.import_module("data_factory." + n) for n in ("uea", "eeg", "eeg_processor", "data_loader")}
+    mods["monash"] = monash
+    return mods
+
+
+def _write_ts_cases(tsdir):
+    """Small UEA-format files (generated text, committed as data): equal length, ragged across samples, and missing
+    values ('?'); classes do not appear in sorted order.  The reference reads classification files with sktime's parser
+    (absent, un-pinned: SURVEY D13); its vendored copy (monash.py:36) is the REGRESSION variant, which wants a
+    `@targetlabel` tag and numeric labels -- so the files carry both tags and use the class names 0 / 1 / 2, which both
+    parsers accept and which sort identically as strings and as floats."""
+    os.makedirs(tsdir, exist_ok=True)
+    rng = np.random.RandomState(7)
+
+    def series(n):
+        return ",".join(repr(round(float(v), 4)) for v in rng.randn(n) * 3 + 1)
+
+    head = "@problemName {name}\n@timeStamps false\n@missing {miss}\n@univariate false\n@dimensions 3\n@equalLength {eq}\n{sl}" \
+           "@classLabel true 0 1 2\n@targetlabel true\n@data\n"
+    files = {}
+    labs = ["2", "0", "1", "0", "2", "1", "1"]
+    for split, n in (("TRAIN", 7), ("TEST", 4)):
+        body = "".join(":".join(series(20) for _ in range(3)) + ":" + labs[i] + "\n" for i in range(n))
+        files[f"EqLen_{split}.ts"] = head.format(name="EqLen", miss="false", eq="true", sl="@seriesLength 20\n") + body
+    lens = [12, 20, 15, 9, 20]
+    body = "".join(":".join(series(L) for _ in range(3)) + ":" + labs[i] + "\n" for i, L in enumerate(lens))
+    files["Ragged_TRAIN.ts"] = "# ragged across samples\n" + head.format(name="Ragged", miss="false", eq="false", sl="") + body
+    rows = []
+    for i in range(5):
+        dims = []
+        for d in range(3):
+            vals = [repr(round(float(v), 4)) for v in rng.randn(16)]
+            for j in rng.choice(16, size=3, replace=False):
+                vals[j] = "?"
+            if i == 2 and d == 1:
+                vals[0] = vals[-1] = "?"                 # missing at both edges: filled from the nearest value
+            dims.append(",".join(vals))
+        rows.append(":".join(dims) + ":" + labs[i] + "\n")
+    files["Missing_TRAIN.ts"] = head.format(name="Missing", miss="true", eq="true", sl="@seriesLength 16\n") + "".join(rows)
+    for name, text in files.items():
+        with open(os.path.join(tsdir, name), "w", encoding="utf-8") as f:
+            f.write(text)
+    return sorted(files)
+
+
+def case_uea_contract(R=None):
+    """Label table, split rule, Normalizer, padding_mask / collate_fn and the `.ts` -> UEAloader pipeline, produced by the
+    reference's own data_factory code (eeg.py, eeg_processor.py, uea.py, monash.py, data_loader.py)."""
+    import warnings
+    import pandas as pd
+    warnings.simplefilter("ignore")
+    D = _import_data_factory()
+    out = {}
+    # (1) 39 -> 3 table: both copies (eeg_processor.py:455-461 and the duplicate in eeg.py:63-69)
+    m1, m2 = D["eeg_processor"].create_3category_mapping(), D["eeg"].create_3category_mapping()
+    assert m1 == m2 and sorted(m1) == list(range(39))
+    out["label3"] = np.array([m1[i] for i in range(39)], dtype=np.int64)
+    # (2) split rule: the unmodified method on a stand-in `self`, seeded the way the ctor does (eeg.py:149)
+    ns = (1, 2, 3, 7, 10, 40, 57, 1000)
+    out["split_ns"] = np.array(ns)
+    sink = io.StringIO()
+    for n in ns:
+        for flag in ("train", "val", "test"):
+            me = types.SimpleNamespace(test_size=0.2, val_size=0.1, debug=False, flag=flag, _prepare_samples=lambda n=n: list(range(n)))
+            np.random.seed(42)
+            with contextlib.redirect_stdout(sink):
+                sel = D["eeg"].EEGDataset._split_samples_by_flag(me)
+            out[f"split_{n}_{flag}"] = np.array(sel, dtype=np.int64)
+    # (3) Normalizer, the upstream way: rows = time steps, index = sample id, columns = channels
+    rng = np.random.RandomState(3)
+    lens = [5, 7, 6]
+    vals = rng.randn(sum(lens), 4) * np.array([1.0, 10.0, 0.1, 3.0]) + np.array([0.0, 5.0, -2.0, 100.0])
+    ids = np.repeat(np.arange(3), lens)
+    df = pd.DataFrame(vals, index=ids)
+    out["norm_in"], out["norm_ids"] = vals, ids
+    for nt in ("standardization", "minmax", "per_sample_std", "per_sample_minmax"):
+        out["norm_" + nt] = D["uea"].Normalizer(nt).normalize(df).values
+    # the EEG call site as written (eeg.py:351-367): a (C, T) frame with the default RangeIndex -> all NaN (defect D14)
+    frame = torch.from_numpy(rng.randn(4, 50).astype(np.float32))
+    as_written = D["uea"].Normalizer("per_sample_std").normalize(pd.DataFrame(frame.numpy())).values
+    out["eeg_norm_as_written_nan_fraction"] = np.float64(np.isnan(as_written).mean())
+    # ... and the same class applied as upstream intends: time steps as rows, ONE sample id
+    out["eeg_norm_in"] = frame.numpy()
+    out["eeg_norm_intended"] = D["uea"].Normalizer("per_sample_std").normalize(
+        pd.DataFrame(frame.numpy().T, index=np.zeros(50, dtype=int))).values.T
+    # (4) padding_mask / collate_fn (uea.py:7-55)
+    lengths = torch.tensor([3, 8, 5, 8])
+    out["pm_lengths"], out["pm_mask"] = lengths.numpy(), D["uea"].padding_mask(lengths, max_len=8).numpy()
+    items = [(torch.from_numpy(rng.randn(L, 3)), torch.tensor([i % 3], dtype=torch.int8)) for i, L in enumerate((6, 10, 4, 13))]
+    for i, (x, _) in enumerate(items):
+        out[f"col_x{i}"] = x.numpy()
+    for max_len in (8, 13):
+        X, t, pm = D["uea"].collate_fn(items, max_len=max_len)
+        out[f"col{max_len}_X"], out[f"col{max_len}_t"], out[f"col{max_len}_mask"] = X.numpy(), t.numpy(), pm.numpy()
+    # (5) .ts files -> UEAloader (vendored parser + the unmodified loader)
+    tsdir = os.path.join(HERE, "ts")
+    names = _write_ts_cases(tsdir)
+    for fname in names:
+        stem = fname[:-3]
+        with contextlib.redirect_stdout(sink):
+            ds = D["data_loader"].UEAloader(tsdir, file_list=[fname])
+        out[f"ts_{stem}_feature"] = ds.feature_df.values.astype(np.float64)
+        out[f"ts_{stem}_index"] = np.asarray(ds.feature_df.index, dtype=np.int64)
+        out[f"ts_{stem}_labels"] = ds.labels_df.values.astype(np.int64)
+        out[f"ts_{stem}_classes"] = np.array(list(ds.class_names), dtype="U16")
+        out[f"ts_{stem}_maxlen"] = np.int64(ds.max_seq_len)
+        batch = [ds[i] for i in range(len(ds))]
+        X, t, pm = D["uea"].collate_fn(batch, max_len=18)
+        out[f"ts_{stem}_X18"], out[f"ts_{stem}_t18"], out[f"ts_{stem}_mask18"] = X.numpy(), t.numpy(), pm.numpy()
+    save("uea_contract", **out)
+
+
+CASES["uea_contract"] = case_uea_contract
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     names = sys.argv[1:] or list(CASES)
-    R = import_reference() if any(n != "run_flags" for n in names) else None
+    R = import_reference() if any(n not in ("run_flags", "uea_contract") for n in names) else None
     for n in names:
         print(f"== {n}")
         CASES[n](R)

@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import golden, make_cfg, sd_from
+from conftest import golden, make_cfg, parity, sd_from
 
 pytestmark = pytest.mark.gpu
 
@@ -45,8 +45,8 @@ def test_attention_core_golden(amath, monkeypatch):
     q, k, v = (_t(g[n], dev).requires_grad_(True) for n in ("q", "k", "v"))
     o = ops.attention(q, k, v, 1.0 / math.sqrt(q.shape[-1]))
     (o * _t(g["go"], dev)).sum().backward()
-    assert _rel(o, g["o"]) < 1e-4
-    assert _rel(q.grad, g["gq"]) < 1e-4 and _rel(k.grad, g["gk"]) < 1e-4 and _rel(v.grad, g["gv"]) < 1e-4
+    for lab, a, b in (("o", o, g["o"]), ("gq", q.grad, g["gq"]), ("gk", k.grad, g["gk"]), ("gv", v.grad, g["gv"])):
+        parity(lab, a, b, kind="scale")
 
 
 @pytest.mark.parametrize("B,L,S,H,E", [(2, 1000, 1000, 8, 64), (3, 100, 100, 8, 64), (2, 130, 75, 2, 32),
@@ -105,16 +105,15 @@ def test_transformer_baseline_golden():
     out = m(x, mask, None, None)
     loss = F.cross_entropy(out, y)
     loss.backward()
-    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=2e-4, atol=2e-4)
-    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    parity("out", out, g["out"], kind="elem", f64=g.get("out64"))
+    parity("loss", loss, g["loss"], kind="elem")
+    gmax = max(float(np.abs(g[k]).max()) for k in g if k.startswith("grad."))
     for n, p in m.named_parameters():
         if "grad." + n not in g:                 # temporal_embedding: constructed but never called on this path
             assert p.grad is None, n
             continue
-        ref = g["grad." + n]
-        scale = max(float(np.abs(ref).max()), 1e-7)
-        err = float(np.abs(p.grad.cpu().numpy() - ref).max())
-        assert err <= 3e-4 * scale + 1e-8, f"{n}: {err:.3e} vs scale {scale:.3e}"
+        # floor: key_projection.bias has a TRUE gradient of zero (softmax is shift-invariant); both sides hold 1e-9 noise
+        parity("grad." + n, p.grad, g["grad." + n], kind="scale", floor=1e-4 * gmax, f64=g.get("grad64." + n))
 
 
 def test_eegcnn_baseline_golden():
@@ -133,23 +132,22 @@ def test_eegcnn_baseline_golden():
     loss = F.cross_entropy(out, y) + info.loss.mean()
     loss.backward()
     feat = m.eegcnn(x)              # same order as the fixture script: two train-mode passes update the BN stats twice
-    np.testing.assert_allclose(feat.detach().cpu().numpy(), g["feat"], rtol=2e-4, atol=2e-4)
-    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=3e-4, atol=3e-4)
-    assert abs(loss.item() - float(g["loss"])) < 2e-4
+    parity("feat", feat, g["feat"], kind="elem", f64=g.get("feat64"))
+    parity("out", out, g["out"], kind="elem", f64=g.get("out64"))
+    parity("loss", loss, g["loss"], kind="elem")
     for n, p in m.named_parameters():
         ref = g["grad." + n]
         scale = max(float(np.abs(ref).max()), 1e-7)
         if scale < 1e-5:       # e.g. block1_bn1.bias: a per-channel constant removed again by block1_bn2 -> true grad 0
             assert float(p.grad.abs().max()) < 1e-5, f"{n}: not noise-level"
             continue
-        err = float(np.abs(p.grad.cpu().numpy() - ref).max())
-        assert err <= 1e-3 * scale + 1e-7, f"{n}: {err:.3e} vs scale {scale:.3e}"
+        parity("grad." + n, p.grad, ref, kind="scale", f64=g.get("grad64." + n))
     for k in (k for k in g if k.startswith("sd_after.")):
-        np.testing.assert_allclose(m.state_dict()[k[9:]].cpu().numpy(), g[k], rtol=1e-3, atol=1e-4, err_msg=k)
+        parity(k, m.state_dict()[k[9:]], g[k], kind="elem", f64=g.get("sd_after64." + k[9:]))
     m.eval()
     with torch.no_grad():
         oe, _ = m(x)
-    np.testing.assert_allclose(oe.cpu().numpy(), g["eval_out"], rtol=3e-4, atol=3e-4)
+    parity("eval_out", oe, g["eval_out"], kind="elem", f64=g.get("eval_out64"))
     with pytest.raises(ValueError):
         m(x, torch.ones(4, 1000, device=dev))                # the reference's mask path cannot run (D9)
 
@@ -212,7 +210,7 @@ def test_eegcnn_block_matches_reference_ops_in_eval_and_train():
         m.train(mode); ref.train(mode)
         a = m(x)
         b = ref._forward_reference_ops(x)
-        assert _rel(a, b) < 2e-4, f"train={mode}"
+        parity(f"out train={mode}", a, b, kind="scale", ref_is="same module, layer-by-layer torch ops (fp32, GPU)")
         if mode:
             ga = torch.autograd.grad(a.square().sum(), [p for p in m.parameters()])
             gb = torch.autograd.grad(b.square().sum(), [p for p in ref.parameters()])
@@ -220,9 +218,10 @@ def test_eegcnn_block_matches_reference_ops_in_eval_and_train():
                 sc = float(v.abs().max())
                 if sc < 1e-4 * float(max(t.abs().max() for t in gb)):
                     continue                      # zero-gradient parameters (bias removed by the next BatchNorm)
-                assert float((u - v).abs().max()) < 2e-3 * sc, n
+                parity("grad." + n, u, v, kind="scale", ref_is="same module, layer-by-layer torch ops (fp32, GPU)")
             for k in m.state_dict():
-                assert _rel(m.state_dict()[k].float(), ref.state_dict()[k].float()) < 2e-4, k
+                parity("sd." + k, m.state_dict()[k].float(), ref.state_dict()[k].float(), kind="scale",
+                       ref_is="same module, layer-by-layer torch ops (fp32, GPU)")
 
 
 @pytest.mark.parametrize("shape,Co,bias", [((256, 100, 512), 256, True), ((3, 77, 64), 512, True), ((5, 130), 12, False),
@@ -282,15 +281,17 @@ def test_conv1d_cl_against_float64(B, Tin, Ci, Co, k, bias):
         assert _rel(bg.grad, bd.grad) < 1e-5
 
 
-def _check_expert_golden(m, g, out, loss, tol_out=2e-4, tol_grad=5e-4):
-    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=tol_out, atol=tol_out)
-    assert abs(loss.item() - float(g["loss"])) < 1e-4
+def _check_expert_golden(m, g, out, loss):
+    """Logits / loss element-wise at 1e-4; every gradient at 1e-4 of its scale, the scale floored at 1e-4 of the largest
+    gradient in the model (tensors whose true gradient is ~0 -- a bias in front of BatchNorm -- hold rounding noise)."""
+    parity("out", out, g["out"], kind="elem", f64=g.get("out64"))
+    parity("loss", loss, g["loss"], kind="elem")
     gmax = max(float(np.abs(g[k]).max()) for k in g if k.startswith("grad."))
     for n, p in m.named_parameters():
-        ref = g["grad." + n]
-        scale = max(float(np.abs(ref).max()), 1e-3 * gmax)
-        err = float(np.abs(p.grad.cpu().numpy() - ref).max())
-        assert err <= tol_grad * scale + 1e-8, f"{n}: {err:.3e} vs scale {scale:.3e}"
+        if "grad." + n not in g:                 # temporal_embedding: constructed, never called on this path
+            assert p.grad is None, n
+            continue
+        parity("grad." + n, p.grad, g["grad." + n], kind="scale", floor=1e-4 * gmax, f64=g.get("grad64." + n))
 
 
 @pytest.mark.parametrize("tag,C,T,N", [("bm", 6, 100, 4), ("odd", 3, 61, 2)])
@@ -313,10 +314,10 @@ def test_resnet_expert_golden(tag, C, T, N):
     sd = m.state_dict()
     for k in g:
         if k.startswith("sd_after."):
-            np.testing.assert_allclose(sd[k[9:]].cpu().numpy(), g[k], rtol=2e-4, atol=2e-5, err_msg=k)
+            parity(k, sd[k[9:]], g[k], kind="elem")
     m.eval()
     with torch.no_grad():
-        np.testing.assert_allclose(m(x).cpu().numpy(), g["eval_out"], rtol=2e-4, atol=2e-4)
+        parity("eval_out", m(x), g["eval_out"], kind="elem")
 
 
 def test_patchtst_expert_golden():
@@ -374,16 +375,7 @@ def test_timesnet_expert_golden():
     out = m(x, mask, None, None)
     loss = F.cross_entropy(out, y)
     loss.backward()
-    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=2e-4, atol=2e-4)
-    assert abs(loss.item() - float(g["loss"])) < 1e-4
-    gmax = max(float(np.abs(g[k]).max()) for k in g if k.startswith("grad."))
-    for n, p in m.named_parameters():
-        if "grad." + n not in g:                 # temporal_embedding: constructed, never called on this path
-            assert p.grad is None, n
-            continue
-        ref = g["grad." + n]
-        err = float(np.abs(p.grad.cpu().numpy() - ref).max())
-        assert err <= 5e-4 * max(float(np.abs(ref).max()), 1e-3 * gmax) + 1e-8, f"{n}: {err:.3e}"
+    _check_expert_golden(m, g, out, loss)
 
 
 def test_inception_block_fused_equals_separate_convs():

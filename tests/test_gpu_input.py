@@ -32,6 +32,20 @@ def test_standardise_matches_cpu_normalizer(B, C, T):
         assert float((out.std(dim=1, unbiased=True) - 1).abs().max()) < 1e-3
 
 
+def test_standardise_equals_reference_normalizer_called_the_upstream_way():
+    """The device kernel against the reference's own Normalizer('per_sample_std') (IGN/data_factory/uea.py:97-99) applied
+    as upstream intends -- time steps as rows, one sample id (tests/golden/uea_contract.npz; the EEG call site as written
+    returns NaN: fork defect D14)."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa: F401
+    from conftest import golden, parity
+    from ign_hip import ops
+    g = golden("uea_contract")
+    x = torch.from_numpy(g["eeg_norm_in"]).to(dev)[None]                       # (1, C, T)
+    out = ops.standardise_nct_to_btc(x)[0].T                                  # -> (C, T)
+    parity("standardised frame", out, g["eeg_norm_intended"], kind="elem", ref_is="reference Normalizer (pandas, float32 in)")
+
+
 def test_prefetcher_equals_cpu_loader_path(tmp_path):
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa: F401

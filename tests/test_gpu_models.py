@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import golden, make_cfg, sd_from
+from conftest import golden, make_cfg, parity, sd_from
 
 pytestmark = pytest.mark.gpu
 
@@ -23,9 +23,9 @@ def _t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-def _close(a, b, tol=1e-4, msg=""):
-    a = a.detach().cpu().numpy()
-    np.testing.assert_allclose(a, np.asarray(b), rtol=tol, atol=tol, err_msg=msg)
+def _close(a, b, label, f64=None):
+    """|a-b| <= 1e-4 (1 + |b|) element-wise, recorded in the parity ledger (conftest.parity)."""
+    parity(label, a, b, kind="elem", f64=f64)
 
 
 def _is_pre_bn_conv_bias(name):
@@ -36,16 +36,19 @@ def _is_pre_bn_conv_bias(name):
     return name.startswith("deep_model.block") and name.endswith(".0.bias")
 
 
-def _grads_close(model, g, tol=2e-4):
+def _grads_close(model, g):
+    """Every parameter gradient within 1e-4 of its own scale (max |ref|) of the reference's; where the fixture holds a
+    float64 run of the reference ("grad64.*") the bound is the reference's own fp32 distance from it if that is larger."""
+    gmax = max(float(np.abs(g[k]).max()) for k in g if k.startswith("grad."))
     for n, p in model.named_parameters():
         ref = g["grad." + n]
         if _is_pre_bn_conv_bias(n):
             wscale = float(np.abs(g["grad." + n[:-4] + "weight"]).max())
             assert float(p.grad.abs().max()) <= 1e-4 * wscale + 1e-7, f"{n}: not noise-level"
             continue
-        scale = max(float(np.abs(ref).max()), 1e-7)
-        err = float(np.abs(p.grad.detach().cpu().numpy() - ref).max())
-        assert err <= tol * scale + 1e-8, f"{n}: err {err:.3e} scale {scale:.3e}"
+        # scale floor 1e-4 of the model's largest gradient: a tensor whose TRUE gradient is zero (the key-projection bias
+        # of a softmax attention: scores are shift-invariant) holds 1e-9 rounding noise in both implementations
+        parity("grad." + n, p.grad, ref, kind="scale", floor=1e-4 * gmax, f64=g.get("grad64." + n))
 
 
 def _train_loss(name, out, info, y):
@@ -74,12 +77,12 @@ def test_sbm_heads(name, sbm_cls, lts):
     out, info = m(x)
     loss = F.cross_entropy(out, y) + info.loss.mean()
     loss.backward()
-    _close(out, g["out"], 2e-4)
-    _close(info.p, g["p"])
-    _close(info.d, g["d"])
-    _close(info.loss, g["model_loss"])
+    _close(out, g["out"], "out", g.get("out64"))
+    _close(info.p, g["p"], "p")
+    _close(info.d, g["d"], "d")
+    _close(info.loss, g["model_loss"], "model_loss")
     assert info.loss.shape == (1,)
-    assert abs(loss.item() - float(g["train_loss"])) < 1e-4
+    parity("train_loss", loss, g["train_loss"], kind="elem")
     _grads_close(m, g)
 
 
@@ -98,18 +101,18 @@ def test_ign_fcn_bm_golden():
     loss.backward()
     for k, v in (("out", out), ("eta", info.eta), ("shapelet_preds", info.shapelet_preds),
                  ("dnn_preds", info.dnn_preds), ("p", info.p), ("d", info.d), ("model_loss", info.loss)):
-        _close(v, g[k], 2e-4, k)
-    assert abs(loss.item() - float(g["train_loss"])) < 1e-4
+        _close(v, g[k], k, g.get(k + "64"))
+    parity("train_loss", loss, g["train_loss"], kind="elem")
     _grads_close(m, g)
     for k, v in m.state_dict().items():      # BatchNorm running statistics after one train-mode forward
-        _close(v.float(), g["sd_after." + k].astype(np.float32), 1e-4, k)
+        _close(v.float(), g["sd_after." + k].astype(np.float32), "sd_after." + k)
     m.eval()
     with torch.no_grad():
         oe, ie = m(x, None, None, None)
         og, ig = m(x, None, None, None, gating_value=0.05)
-    _close(oe, g["eval_out"], 2e-4)
-    _close(og, g["gated_out"], 2e-4)
-    _close(ig.eta, g["gated_eta"], 2e-4)
+    _close(oe, g["eval_out"], "eval_out")
+    _close(og, g["gated_out"], "gated_out")
+    _close(ig.eta, g["gated_eta"], "gated_eta")
 
 
 def test_ign_fcn_chisco_shape_golden():
@@ -124,12 +127,12 @@ def test_ign_fcn_chisco_shape_golden():
     out, info = m(x, None, None, None)
     loss = _train_loss('InterpGN', out, info, y)
     loss.backward()
-    _close(out, g["out"], 2e-4)
-    _close(info.p, g["p"])
-    _close(info.d, g["d"])
-    _close(info.eta, g["eta"], 2e-4)
-    assert abs(loss.item() - float(g["train_loss"])) < 1e-4
-    _grads_close(m, g, tol=3e-4)
+    _close(out, g["out"], "out", g.get("out64"))
+    _close(info.p, g["p"], "p")
+    _close(info.d, g["d"], "d")
+    _close(info.eta, g["eta"], "eta", g.get("eta64"))
+    parity("train_loss", loss, g["train_loss"], kind="elem")
+    _grads_close(m, g)
 
 
 @pytest.mark.parametrize("tag,posw", [("", False), ("_posw", True)])
@@ -151,7 +154,7 @@ def test_three_adam_steps(tag, posw):
         if posw:
             m.step()
         opt.zero_grad()
-        assert abs(loss.item() - g["losses"][i]) < 2e-4 * max(1.0, abs(g["losses"][i]))
+        parity(f"loss_step{i}", loss, np.float64(g["losses"][i]), kind="elem")
     for k, v in m.state_dict().items():
         if _is_pre_bn_conv_bias(k) or (k.startswith("deep_model.block") and k.endswith(".1.running_mean")):
             continue        # the BN running mean absorbs the (noise-driven) conv bias one-for-one
@@ -233,12 +236,11 @@ def test_sbm_cosine_pearson_vs_oracle(dfunc, mode):
     (F.cross_entropy(o_r, y) + i_r.loss.mean()).backward()
     o, i = m(x.to(dev))
     (F.cross_entropy(o, y.to(dev)) + i.loss.mean()).backward()
-    _close(o, o_r.detach().numpy(), 2e-4)
-    _close(i.p, i_r.p.detach().numpy())
-    _close(i.d, i_r.d.detach().numpy())
+    _close(o, o_r.detach().numpy(), "out")
+    _close(i.p, i_r.p.detach().numpy(), "p")
+    _close(i.d, i_r.d.detach().numpy(), "d")
     for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
-        scale = max(float(q.grad.abs().max()), 1e-7)
-        assert float((p.grad.cpu() - q.grad).abs().max()) <= 3e-4 * scale + 1e-8, n
+        parity("grad." + n, p.grad, q.grad, kind="scale", floor=1e-7, ref_is="CPU oracle fp32")
 
 
 def test_diversity_kernel_vs_torch():
