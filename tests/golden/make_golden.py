@@ -536,6 +536,311 @@ def case_uea_contract(R=None):
 CASES["uea_contract"] = case_uea_contract
 
 
+# ------------------------------------------------------------------------------------ round 2: benchmark-width and harness fixtures
+sys.path.insert(0, HERE)
+from fill import seeded_fill  # noqa: E402  (tests/golden/fill.py: the same fill is applied to this repo's modules in the tests)
+
+SAMPLE = 2048
+
+
+def sample_idx(numel):
+    """the fixed subset of a large gradient that a fixture stores (the tests apply the same rule)"""
+    return torch.linspace(0, numel - 1, min(SAMPLE, numel)).long()
+
+
+def grads_compact(model, prefix):
+    """small tensors in full; large ones as (norm, fixed strided sample)"""
+    out = {}
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach()
+        if g.numel() <= 4096:
+            out[f"{prefix}.{k}"] = npy(g)
+        else:
+            out[f"{prefix}norm.{k}"] = np.float64(g.double().norm().item())
+            out[f"{prefix}sample.{k}"] = npy(g.flatten()[sample_idx(g.numel())])
+    return out
+
+
+def case_transformer_ch512(R):
+    """BASELINE config 4 at its own width: Transformer.Model, enc_in 122, seq_len 1000, d_model 512, 8 heads, d_ff 2048,
+    2 layers, B=2; parameters from seeded_fill (nothing stored); fp32 and float64 runs of the reference module."""
+    T = R["Transformer"]
+    c = cfg(enc_in=122, seq_len=1000, num_class=3, c_out=3, d_model=512, n_heads=8, d_ff=2048, e_layers=2)
+    g = torch.Generator().manual_seed(171)
+    x = torch.randn(2, 1000, 122, generator=g)
+    mask = torch.ones(2, 1000)
+    mask[1, 900:] = 0.
+    y = torch.tensor([2, 0])
+    out = dict(x=npy(x), mask=npy(mask), y=npy(y), seed=np.int64(512))
+    for tag, dt in (("", torch.float32), ("64", torch.float64)):
+        torch.manual_seed(0)
+        m = seeded_fill(T.Model(c), 512).to(dt).train()
+        o = m(x.to(dt), mask.to(dt), None, None)
+        loss = torch.nn.functional.cross_entropy(o, y)
+        loss.backward()
+        out.update({"out" + tag: npy(o), "loss" + tag: npy(loss)}, **grads_compact(m, "grad" + tag))
+        del m
+    save("transformer_ch512", **out)
+
+
+def case_eegcnn_ch512(R):
+    """BASELINE config 3 at its own width: EEGCNNTransformer, d_model 512, B=4, (B,C,T) input, no mask (D9)."""
+    E = R["eegcnn"]
+    c = cfg(enc_in=122, seq_len=1000, num_class=3, c_out=3, d_model=512)
+    g = torch.Generator().manual_seed(181)
+    x = torch.randn(4, 122, 1000, generator=g)
+    y = torch.tensor([0, 1, 2, 1])
+    out = dict(x=npy(x), y=npy(y), seed=np.int64(513))
+    sink = io.StringIO()
+    for tag, dt in (("", torch.float32), ("64", torch.float64)):
+        with contextlib.redirect_stdout(sink):
+            torch.manual_seed(0)
+            m = seeded_fill(E.EEGCNNTransformer(c), 513).to(dt).train()
+            o, _ = m(x.to(dt))
+            loss = torch.nn.functional.cross_entropy(o, y)
+            loss.backward()
+            feat = None
+            if tag == "":
+                sd_after = {k: v for k, v in sd_np(m, "sd_after.").items() if "running" in k}
+                m.eval()
+                with torch.no_grad():
+                    feat = m.eegcnn(x)
+                    oe, _ = m(x)
+                out.update(eval_feat=npy(feat), eval_out=npy(oe), **sd_after)
+        out.update({"out" + tag: npy(o), "loss" + tag: npy(loss)}, **grads_compact(m, "grad" + tag))
+        del m
+    save("eegcnn_ch512", **out)
+
+
+def _three_steps(m, step_fn, batches, clamp=False):
+    opt = torch.optim.Adam(m.parameters(), lr=5e-3)
+    losses = []
+    m.train()
+    for b in batches:
+        loss = step_fn(m, *b)
+        loss.backward()
+        opt.step()
+        if clamp:
+            m.step()
+        opt.zero_grad()
+        losses.append(loss.item())
+    return np.array(losses, dtype=np.float64)
+
+
+def case_train_steps_r2(R):
+    """3 Adam steps (lr 5e-3) of the reference's training step for SBM (6x10 bank), DNN/Transformer and EEG-CNN."""
+    ce = torch.nn.functional.cross_entropy
+    g = torch.Generator().manual_seed(191)
+    xs = torch.randn(3, 8, 100, 6, generator=g)
+    ys = torch.randint(0, 4, (3, 8), generator=g)
+    # SBM
+    torch.manual_seed(0)
+    m = R["Shapelet"].ShapeBottleneckModel(configs=cfg(), num_shapelet=[10] * 6, shapelet_len=[0.05, 0.1, 0.2, 0.3, 0.5, 0.8])
+    sd0 = sd_np(m, "sd0.")
+
+    def sbm_step(m, x, y):
+        out, info = m(x)
+        return ce(out, y) + info.loss.mean()
+    losses = _three_steps(m, sbm_step, [(xs[i], ys[i]) for i in range(3)])
+    save("train_step_sbm", xs=npy(xs), ys=npy(ys), losses=losses, **sd0, **sd_np(m, "sd3."))
+    # DNN / Transformer (d_model 64)
+    torch.manual_seed(0)
+    m = R["Transformer"].Model(cfg())
+    sd0 = sd_np(m, "sd0.")
+    losses = _three_steps(m, lambda m, x, y: ce(m(x, torch.ones(8, 100), None, None), y), [(xs[i], ys[i]) for i in range(3)])
+    nope = lambda d: {k: v for k, v in d.items() if not k.endswith("position_embedding.pe")}     # deterministic sin/cos table
+    save("train_step_dnn_transformer", xs=npy(xs), ys=npy(ys), losses=losses, **nope(sd0), **nope(sd_np(m, "sd3.")))
+    # EEG-CNN (C=8, T=200, d_model 64): input (B,C,T), no mask
+    xe = torch.randn(3, 6, 8, 200, generator=g)
+    ye = torch.randint(0, 3, (3, 6), generator=g)
+    sink = io.StringIO()
+    with contextlib.redirect_stdout(sink):
+        torch.manual_seed(0)
+        m = R["eegcnn"].EEGCNNTransformer(cfg(enc_in=8, seq_len=200, num_class=3, c_out=3, d_model=64))
+        sd0 = {k: v for k, v in sd_np(m, "sd0.").items() if not k.endswith("pos_encoder.pe")}
+        losses = _three_steps(m, lambda m, x, y: ce(m(x)[0], y), [(xe[i], ye[i]) for i in range(3)])
+    sd3 = {k: v for k, v in sd_np(m, "sd3.").items() if not k.endswith("pos_encoder.pe")}
+    save("train_step_eegcnn", xs=npy(xe), ys=npy(ye), losses=losses, **sd0, **sd3)
+
+
+def case_ign_transformer(R):
+    """InterpGN with the Transformer deep expert (dnn_type='Transformer'), BM shape."""
+    I = R["InterpGN"]
+    B = 8
+    g = torch.Generator().manual_seed(201)
+    x = torch.randn(B, 100, 6, generator=g)
+    y = torch.arange(B) % 4
+    mask = torch.ones(B, 100)
+    mask[3, 70:] = 0.
+    c = cfg(dnn_type="Transformer")
+    torch.manual_seed(0)
+    m = I.InterpGN(c)
+    sd0 = {k: v for k, v in sd_np(m).items() if not k.endswith("position_embedding.pe")}
+    m.train()
+    out, info = m(x, mask, None, None)
+    ce = torch.nn.functional.cross_entropy
+    loss = ce(out, y) + info.loss.mean() + ce(info.shapelet_preds, y)
+    loss.backward()
+    save("ign_transformer", x=npy(x), y=npy(y), mask=npy(mask), out=npy(out), eta=npy(info.eta),
+         shapelet_preds=npy(info.shapelet_preds), dnn_preds=npy(info.dnn_preds), p=npy(info.p), d=npy(info.d),
+         model_loss=npy(info.loss), train_loss=npy(loss), **sd0, **grads_np(m))
+
+
+def case_shapelet_ch(R):
+    """One bank at the CHISCO row shape (C=122, T=1000, K=5, L=200, B=2) for the LTS gate and the cosine distance, and a
+    strided bank (T=3100 >= 3000 => stride int(log2 310) = 8, Shapelet.py:162) for the L1 / LTS paths.  Inputs and weights
+    come from a seeded generator (not stored)."""
+    S = R["Shapelet"]
+    for name, dfunc, lts, (B, C, T, K, L, stride) in (("ch_lts", "euclidean", True, (2, 122, 1000, 5, 200, 1)),
+                                                      ("ch_cos", "cosine", False, (2, 122, 1000, 5, 200, 1)),
+                                                      ("strided_l1", "euclidean", False, (2, 3, 3100, 3, 310, 8)),
+                                                      ("strided_lts", "euclidean", True, (2, 3, 3100, 3, 310, 8))):
+        g = torch.Generator().manual_seed(211)
+        xn = torch.randn(B, C, T, generator=g)
+        w = torch.randn(K, C, L, generator=g)
+        thr = torch.rand(1, K, C, generator=g)
+        r = torch.randn(B, K * C, generator=g)
+        cls = S.DistThresholdShapelet if lts else S.Shapelet
+        m = cls(dim_data=C, shapelet_len=L, num_shapelet=K, stride=stride, eps=1.0, distance_func=dfunc)
+        with torch.no_grad():
+            m.weights.copy_(w)
+            if lts:
+                m.threshold.copy_(thr)
+        p, dmin = m(xn)
+        (p * r).sum().backward()
+        out = dict(dims=np.array([B, C, T, K, L, stride]), seed=np.int64(211), p=npy(p), dmin=npy(dmin), grad_w=npy(m.weights.grad))
+        if lts:
+            out["grad_thr"] = npy(m.threshold.grad)
+        save("shapelet_" + name, **out)
+
+
+class _ArrayDataset(torch.utils.data.Dataset):
+    def __init__(self, x, y, num_classes):
+        self.x, self.y = x, y
+        self.seq_len, self.enc_in, self.num_classes = x.shape[1], x.shape[2], num_classes
+
+    def __len__(self):
+        return len(self.y)
+
+    def __getitem__(self, i):
+        return self.x[i], self.y[i]
+
+
+def case_driver_smoke(R):
+    """The reference's UNMODIFIED Experiment.__init__/train/validation/test (exp/experiment_classification.py:85-421,828-1138)
+    on a synthetic provider (SURVEY 8(c) shim 4), BM shape.  Two runs: (a) plain, 3 epochs; (b) accumulation 2, clipping 0.5,
+    cosine lr decay, pos_weight clamp, min_epochs 0 / patience 1 so early stopping fires.  Stored: data, initial state dict,
+    exact per-epoch validation (loss, acc), printed per-epoch train loss (4 decimals), epoch_stop, final state dict (best
+    checkpoint reloaded), checkpoint key set, test loss / accuracy / predictions."""
+    import importlib
+    import re
+    import shutil
+    import tempfile
+    g = torch.Generator().manual_seed(221)
+    tt = torch.arange(100, dtype=torch.float32)[None, :, None]
+
+    def make(n):
+        y = torch.arange(n) % 4
+        x = 1.5 * torch.randn(n, 100, 6, generator=g) + torch.sin(2 * np.pi * (y[:, None, None] + 1) * tt / 100) * (1 + 0.2 * y[:, None, None])
+        return x, y
+    data = {f: make(n) for f, n in (("train", 40), ("val", 16), ("test", 16))}
+
+    def provider(args, flag, bin_edges=None):
+        x, y = data[flag.lower()]
+        ds = _ArrayDataset(x, y, 4)
+
+        def collate(b):
+            xs, ys = zip(*b)
+            return torch.stack(xs), torch.stack(ys), torch.ones(len(xs), 100, dtype=torch.bool)
+        return ds, torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=(flag.lower() != "test"), collate_fn=collate)
+
+    fake_pkg, fake_mod = types.ModuleType("data_provider"), types.ModuleType("data_provider.data_factory")
+    fake_mod.data_provider = provider
+    fake_pkg.data_factory = fake_mod
+    sys.modules["data_provider"], sys.modules["data_provider.data_factory"] = fake_pkg, fake_mod
+    np.Inf = np.inf                                                          # D12
+    X = importlib.import_module("exp.experiment_classification")
+    X.data_provider = provider
+    base = dict(model="InterpGN", dnn_type="FCN", dataset="smoke", data="SYNTH", seed=0, num_shapelet=10, lambda_div=0.1, lambda_reg=0.1,
+                epsilon=1.0, beta_schedule="constant", distance_func="euclidean", sbm_cls="linear", memory_efficient=False,
+                dropout=0.0, lr=5e-3, train_epochs=3, batch_size=8, amp=False, patience=10, min_epochs=0, log_interval=1,
+                gradient_accumulation_steps=1, gradient_clip=0.0, pos_weight=False, lr_decay=False, gating_value=1.0,
+                test_only=False, multi_gpu=False, task_name="classification")
+    runs = {"a": {}, "b": dict(gradient_accumulation_steps=2, gradient_clip=0.5, lr_decay=True, pos_weight=True, patience=2,
+                               train_epochs=14, beta_schedule="cosine", min_epochs=1),
+            "c": dict(model="SBM", num_shapelet=3, lr=0.05, patience=1, train_epochs=12)}
+    out = {f"{f}_x": npy(x) for f, (x, y) in data.items()}
+    out.update({f"{f}_y": npy(y) for f, (x, y) in data.items()})
+    cwd = os.getcwd()
+
+    def run_once(args, zero_bias_noise):
+        work = tempfile.mkdtemp()
+        os.chdir(work)
+        sink = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(sink):
+                torch.manual_seed(0); np.random.seed(0)
+                exp = X.Experiment(args)
+                sd0 = {k: npy(v) for k, v in exp.model.state_dict().items()}
+                if zero_bias_noise:
+                    # A Conv1d bias in front of a batch-statistics BatchNorm has an identically ZERO gradient; what autograd
+                    # returns is rounding noise, which Adam normalises into +-lr steps, and in eval mode the deep expert sees
+                    # `bias - running_mean`.  This variant replaces that noise by its true value (0) -- same mathematics.
+                    for n, p in exp.model.named_parameters():
+                        if n.startswith("deep_model.block") and n.endswith(".0.bias"):
+                            p.register_hook(torch.zeros_like)
+                vals = []
+                orig_val = exp.validation
+
+                def rec():
+                    r = orig_val()
+                    vals.append(r)
+                    return r
+                exp.validation = rec
+                torch.manual_seed(777)                       # DataLoader shuffle seeds are drawn from here on
+                exp.train()
+                torch.set_float32_matmul_precision("highest")
+                ck = torch.load(os.path.join(exp.checkpoint_dir, "checkpoint.pth"), weights_only=True)
+                test_loss, res, _ = exp.test(save_csv=False, result_dir=os.path.join(work, "result"))
+        finally:
+            os.chdir(cwd)
+            shutil.rmtree(work, ignore_errors=True)
+        return exp, sd0, vals, ck, test_loss, res, sink.getvalue()
+
+    for tag, over in runs.items():
+        args = Namespace(**{**base, **over})
+        exp, sd0, vals, ck, test_loss, res, log = run_once(args, False)
+        tl = [float(v) for v in re.findall(r"Train Loss ([0-9.]+)", log)]
+        out.update({("sd0." if args.model == "InterpGN" else f"{tag}.sd0.") + k: v for k, v in sd0.items()})   # a, b: same start
+        for k, v in exp.model.state_dict().items():       # final weights: small tensors in full, large ones norm + sample
+            if v.numel() <= 4096:
+                out[f"{tag}.sdF.{k}"] = npy(v)
+            else:
+                out[f"{tag}.sdFnorm.{k}"] = np.float64(v.double().norm().item())
+                out[f"{tag}.sdFsample.{k}"] = npy(v.flatten()[sample_idx(v.numel())])
+        out.update({f"{tag}.val": np.array(vals, dtype=np.float64), f"{tag}.train_loss_printed": np.array(tl),
+                    f"{tag}.epoch_stop": np.int64(exp.epoch_stop), f"{tag}.early_stop": np.bool_("Early stopping" in log),
+                    f"{tag}.ckpt_keys": np.array(sorted(ck.keys()), dtype="U64"), f"{tag}.ckpt_dir": np.array(exp.checkpoint_dir),
+                    f"{tag}.test_loss": np.float64(test_loss), f"{tag}.test_acc": np.float64(res.accuracy),
+                    f"{tag}.test_preds": npy(res.preds), f"{tag}.test_p": npy(res.p),
+                    f"{tag}.args": np.array(sorted(f"{k}={v}" for k, v in {**base, **over}.items()), dtype="U64")})
+        if args.model == "InterpGN":
+            out[f"{tag}.test_eta"] = npy(res.eta)
+            _, _, vals0, _, test_loss0, res0, _ = run_once(args, True)
+            out.update({f"{tag}.val_zb": np.array(vals0, dtype=np.float64), f"{tag}.test_loss_zb": np.float64(test_loss0),
+                        f"{tag}.test_dnn_zb": npy(res0.dnn_preds) if getattr(res0, "dnn_preds", None) is not None else np.zeros(0)})
+            d = np.abs(np.array(vals)[:, 0] - np.array(vals0)[:, 0]) / (1 + np.abs(np.array(vals)[:, 0]))
+            print(f"  run {tag}: the reference against itself with the zero-gradient bias noise removed: val loss moves by {d.max():.2e} (rel)")
+        print(f"  run {tag}: epochs={len(vals)} epoch_stop={exp.epoch_stop} test_acc={res.accuracy}")
+    save("driver_smoke", **out)
+
+
+CASES.update(transformer_ch512=case_transformer_ch512, eegcnn_ch512=case_eegcnn_ch512, train_steps_r2=case_train_steps_r2,
+             ign_transformer=case_ign_transformer, shapelet_ch=case_shapelet_ch, driver_smoke=case_driver_smoke)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     names = sys.argv[1:] or list(CASES)
