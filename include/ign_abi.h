@@ -77,7 +77,10 @@ int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const float* thr_k
  *   gw_kcl (K,C,L) receives dloss/dw (overwritten, deterministic: fixed-order two-stage reduction over B)
  *   workspace: ign_shapelet_bwd_workspace_bytes() bytes.
  * Gradients w.r.t. the input are not produced (inputs are data: IGN/exp/experiment_classification.py:315).
- * LTS: dloss/dthr is a (B,KC) elementwise reduction the caller forms from g_out and p_out.             */
+ * LTS: dloss/dthr is a (B,KC) elementwise reduction the caller forms from g_out and p_out.
+ * stride > 1 (IGN/model/Shapelet.py:162: int(log2 L) once seq_len >= 3000 -- run_uea.sh's MotorImagery, EigenWorms) is
+ * served by a generic-step kernel; shapelets longer than 2048 positions are split over several blocks.  Rows up to
+ * T ~ 40 000 fit the forward's LDS staging (160 KB per CU); beyond that both calls return IGN_E_TOOBIG.             */
 size_t ign_shapelet_bwd_workspace_bytes(int B, int C, int T, int K, int L, int stride, int mode);
 int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const float* g_out, const float* p_out,
                      const float* dmin_out, int ld, int col0,

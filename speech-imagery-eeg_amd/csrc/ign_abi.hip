@@ -142,7 +142,7 @@ extern "C" int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const f
     const size_t park = (npass > 1) ? (size_t)5 * 5 * 64 * 4 : 0;     // per wave: 5 stats x KT<=5 x 64 lanes
     while (wpb > 1 && (size_t)wpb * (xs_len * 4 + park) > 64 * 1024) wpb >>= 1;
     const size_t lds = (size_t)wpb * (xs_len * 4 + park);
-    if (lds > 64 * 1024) {
+    if (lds > 160 * 1024) {       // the whole LDS of a gfx950 CU: rows up to T ~ 40 000 (the longest UEA set is 17 984)
         ign_set_error("%s: a row needs %zu bytes of LDS staging (T=%d L=%d stride=%d)", who, lds, T, L, stride);
         return IGN_E_TOOBIG;
     }
@@ -178,11 +178,53 @@ extern "C" int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const f
 
 // ------------------------------------------------------------------------------------------ backward
 struct BwdPlan {
-    int JJ, cpk, kb, nkt, threads, tc, xs_len, nbs;
+    int JJ, cpk, kb, nkt, threads, tc, xs_len, nbs, njt;
     size_t lds;
 };
 
-static int plan_bwd(int B, int C, int T, int K, int L, int Tw, BwdPlan* p) {
+// stride > 1 (IGN/model/Shapelet.py:162 at seq_len >= 3000): the generic-step kernel, JJ = 4; one shapelet per block when
+// it needs more than one block of 512 lanes (L > 2048), otherwise the lane-filling tile of shapelets as below.
+static int plan_bwd_strided(int B, int C, int K, int L, int Tw, int stride, BwdPlan* p) {
+    const int JJ = 4;
+    p->JJ = JJ;
+    const int cpk_all = (L + JJ - 1) / JJ;
+    p->njt = (cpk_all + 511) / 512;
+    p->cpk = (cpk_all + p->njt - 1) / p->njt;            // j-chunks per tile, equalised over the tiles
+    if (p->njt > 1) {
+        p->kb = 1;
+    } else {
+        int best_kb = 1;
+        double best_u = -1.0;
+        for (int kb = 1; kb <= K && kb * p->cpk <= 512; ++kb) {
+            const int thr = ((kb * p->cpk + 63) / 64) * 64;
+            const int ntile = (K + kb - 1) / kb;
+            const double u = (double)K * p->cpk / ((double)ntile * thr);
+            if (u > best_u + 1e-9) { best_u = u; best_kb = kb; }
+        }
+        p->kb = best_kb;
+    }
+    p->nkt = (K + p->kb - 1) / p->kb;
+    p->threads = ((p->kb * p->cpk + 63) / 64) * 64;
+    const size_t budget = std::max<size_t>(16 * 1024, (size_t)(p->threads / 64) * 5 * 1024);
+    const long fixed = (long)p->cpk * JJ + 16 * p->kb + 8;
+    long tc_max = ((long)(budget / 4) - fixed) / (stride + p->kb);
+    tc_max = std::max<long>(2 * JJ, (tc_max / (2 * JJ)) * (2 * JJ));
+    const int nchunk = (int)((Tw + tc_max - 1) / tc_max);
+    int tc = (Tw + nchunk - 1) / nchunk;
+    tc = ((tc + 2 * JJ - 1) / (2 * JJ)) * (2 * JJ);
+    p->tc = tc;
+    p->xs_len = (p->cpk * JJ + (tc - 1) * stride + 1 + 3) & ~3;
+    p->lds = ((size_t)p->xs_len + (size_t)p->kb * tc + 16 * (size_t)p->kb) * 4;
+    if (p->lds > 64 * 1024) return IGN_E_TOOBIG;
+    int nbs = (B + 1) / 2;
+    while (nbs > 1 && (size_t)nbs * K * C * L * 4 > ((size_t)256 << 20)) nbs = (nbs + 1) / 2;
+    p->nbs = std::max(1, std::min(nbs, B));
+    return 0;
+}
+
+static int plan_bwd(int B, int C, int T, int K, int L, int Tw, int stride, BwdPlan* p) {
+    if (stride > 1) return plan_bwd_strided(B, C, K, L, Tw, stride, p);
+    p->njt = 1;
     // JJ: shapelet positions per lane.  8 amortises the A / x operand reads over more work; 4 fills the waves better
     // for short shapelets (K*ceil(L/JJ) lanes are rounded up to whole waves).
     int best = 0;
@@ -242,9 +284,9 @@ static int plan_bwd(int B, int C, int T, int K, int L, int Tw, BwdPlan* p) {
 
 extern "C" size_t ign_shapelet_bwd_workspace_bytes(int B, int C, int T, int K, int L, int stride, int mode) {
     (void)mode;
-    if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || L <= 0 || stride != 1 || L > T) return 0;
+    if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || L <= 0 || stride < 1 || L > T) return 0;
     BwdPlan p;
-    if (plan_bwd(B, C, T, K, L, T - L + 1, &p)) return 0;
+    if (plan_bwd(B, C, T, K, L, (T - L) / stride + 1, stride, &p)) return 0;
     return (size_t)p.nbs * K * C * L * sizeof(float);
 }
 
@@ -257,10 +299,6 @@ extern "C" int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const f
     int dist, gate, rc;
     if ((rc = split_mode(mode, &dist, &gate, who))) return rc;
     if ((rc = check_dims(who, B, C, T, K, L, stride))) return rc;
-    if (stride != 1) {
-        ign_set_error("%s: stride %d not implemented (the reference uses stride 1 below seq_len 3000)", who, stride);
-        return IGN_E_UNSUP;
-    }
     if (!xn_bct || !w_kcl || !g_out || !tstar || !zmu || !d_save || !gw_kcl || !workspace ||
         (gate == GATE_LTS && (!p_out || !dmin_out))) {
         ign_set_error("%s: null pointer argument (d_save is required: run the forward with d_save)", who);
@@ -274,13 +312,13 @@ extern "C" int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const f
         ign_set_error("%s: cosine / pearson need xstat_save (from the forward) and wnorm_kc", who);
         return IGN_E_ARG;
     }
-    const int Tw = T - L + 1;
+    const int Tw = (T - L) / stride + 1;
     BwdPlan p;
-    if ((rc = plan_bwd(B, C, T, K, L, Tw, &p))) {
-        ign_set_error("%s: no launch plan for K=%d L=%d Tw=%d", who, K, L, Tw);
+    if ((rc = plan_bwd(B, C, T, K, L, Tw, stride, &p))) {
+        ign_set_error("%s: no launch plan for K=%d L=%d Tw=%d stride=%d", who, K, L, Tw, stride);
         return rc;
     }
-    shp_bwd_launch_t fn = ign_get_bwd_launcher(dist, p.JJ);
+    shp_bwd_launch_t fn = (stride > 1) ? ign_get_bwd_strided_launcher(dist) : ign_get_bwd_launcher(dist, p.JJ);
     if (!fn) {
         ign_set_error("%s: no kernel for JJ=%d dist=%d", who, p.JJ, dist);
         return IGN_E_UNSUP;
@@ -293,9 +331,10 @@ extern "C" int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const f
     a.B = B; a.C = C; a.T = T; a.K = K; a.L = L; a.Tw = Tw; a.ld = ld; a.col0 = col0;
     a.nbs = p.nbs; a.kb = p.kb; a.cpk = p.cpk; a.tc = p.tc; a.xs_len = p.xs_len; a.gate = gate;
     a.eps = eps; a.invL = 1.0f / (float)L;
+    a.stride = stride; a.njt = p.njt;
     {
         IgnScopedTimer tm("shp_bwd", (hipStream_t)stream);
-        fn(a, dim3((unsigned)C, (unsigned)p.nbs, (unsigned)p.nkt), dim3(p.threads), p.lds, (hipStream_t)stream);
+        fn(a, dim3((unsigned)C, (unsigned)p.nbs, (unsigned)(p.nkt * p.njt)), dim3(p.threads), p.lds, (hipStream_t)stream);
     }
     if ((rc = ign_check_launch("shp_bwd_kernel"))) return rc;
     IgnScopedTimer tm2("reduce_parts", (hipStream_t)stream);

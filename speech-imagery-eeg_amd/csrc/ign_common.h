@@ -62,11 +62,14 @@ struct ShpBwdArgs {
     int kb;               // shapelets per block (gridDim.z tiles)
     int cpk;              // j-chunks per shapelet = ceil(L/JJ)
     int tc;               // window positions staged per LDS chunk (multiple of 2*JJ)
-    int xs_len;           // floats of x staging per chunk = cpk*JJ + tc (multiple of 4)
+    int xs_len;           // floats of x staging per chunk = cpk*JJ + tc (multiple of 4); strided: cpk*JJ + (tc-1)*stride + 1
     int gate;
     float eps, invL;
+    int stride;           // window step (1 below seq_len 3000; int(log2 L) above: IGN/model/Shapelet.py:162)
+    int njt;              // strided kernel only: tiles of cpk*JJ shapelet positions per shapelet (L > 2048 needs > 1)
 };
 typedef void (*shp_bwd_launch_t)(const ShpBwdArgs&, dim3 grid, dim3 block, size_t lds, hipStream_t);
 shp_bwd_launch_t ign_get_bwd_launcher(int dist, int JJ);            // JJ in {4,8}
+shp_bwd_launch_t ign_get_bwd_strided_launcher(int dist);            // stride > 1: JJ = 4, generic window step
 
 void ign_launch_reduce_parts(const float* part, float* out, int nparts, size_t n, hipStream_t s);

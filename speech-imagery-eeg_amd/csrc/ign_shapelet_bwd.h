@@ -84,7 +84,12 @@ __device__ __forceinline__ void lds_load(float (&dst)[JJ], const float* p) {
     }
 }
 
-template <int JJ, int DIST>
+// STRIDED (window step > 1, the reference's rule once seq_len >= 3000): consecutive windows no longer share samples, so
+// the ping-pong register window is replaced by a plain loop -- per window position t the lane reads its JJ samples
+// x[t*stride + j] from the LDS chunk and A[k][t] as a broadcast.  A shapelet longer than 512*JJ positions is split over
+// `njt` blocks (blockIdx.z = k*njt + tile), each recomputing A for its shapelet (kb = 1).  Same staging, same fixed-order
+// reduction, same outputs; built for the long-sequence UEA sets (MotorImagery, EigenWorms), not for the benchmark shape.
+template <int JJ, int DIST, bool STRIDED = false>
 __global__ void __launch_bounds__(512, 7) shp_bwd_kernel(const ShpBwdArgs a) {
     static_assert(JJ % 4 == 0, "float4 LDS reads need 4-float alignment");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -94,7 +99,9 @@ __global__ void __launch_bounds__(512, 7) shp_bwd_kernel(const ShpBwdArgs a) {
     float* Par = Sp + a.kb * 8;              // [kb][8]       per-shapelet scalars of the current row (g, t*, 1/Z, mu, ...)
 
     const int c = blockIdx.x, bs = blockIdx.y;
-    const int kbase = blockIdx.z * a.kb;
+    const int ztile = STRIDED ? (int)blockIdx.z / a.njt : (int)blockIdx.z;
+    const int j0 = STRIDED ? ((int)blockIdx.z - ztile * a.njt) * a.cpk * JJ : 0;      // first shapelet position of this tile
+    const int kbase = ztile * a.kb;
     const int kcount = min(a.kb, a.K - kbase);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
@@ -102,13 +109,13 @@ __global__ void __launch_bounds__(512, 7) shp_bwd_kernel(const ShpBwdArgs a) {
     const int jc = tid - kl * a.cpk;
     const bool active = kl < kcount;
     if (!active) kl = kcount - 1;            // padding lanes shadow a valid shapelet: EXEC stays full in the hot loop
-    const int jbase = jc * JJ;
+    const int jbase = jc * JJ;                 // position inside the tile; the shapelet position is j0 + jbase + jj
 
     float wreg[JJ], acc[JJ];
     float ssum = 0.f;                        // S = sum_t A_t of this lane's shapelet over the batch slice (L1)
 #pragma unroll
     for (int jj = 0; jj < JJ; ++jj) {
-        const int j = jbase + jj;
+        const int j = j0 + jbase + jj;
         wreg[jj] = (j < a.L) ? a.w[((size_t)(kbase + kl) * a.C + c) * a.L + j] : INFINITY;
         acc[jj] = 0.f;
     }
@@ -132,7 +139,8 @@ __global__ void __launch_bounds__(512, 7) shp_bwd_kernel(const ShpBwdArgs a) {
 #pragma unroll
                 for (int u = 0; u < XB; ++u) {
                     const int i = i0 + u * nthr;
-                    xv[u] = (i < a.xs_len && t0 + i < a.T) ? row[t0 + i] : 0.f;
+                    const int src = (STRIDED ? t0 * a.stride + j0 : t0) + i;
+                    xv[u] = (i < a.xs_len && src < a.T) ? row[src] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < XB; ++u) {
@@ -247,6 +255,20 @@ __global__ void __launch_bounds__(512, 7) shp_bwd_kernel(const ShpBwdArgs a) {
                 for (int wv = 0; wv < nwave; ++wv) ssum += Sp[kl * 8 + wv];
             const float* Ak = As + kl * a.tc;
             const float* xl = xs + jbase;
+            if (STRIDED) {
+                for (int t = 0; t < a.tc; ++t) {             // A is 0 beyond Tw, x is 0 beyond T
+                    const float At = Ak[t];
+                    const float* xw = xl + t * a.stride;
+#pragma unroll
+                    for (int jj = 0; jj < JJ; ++jj) {
+                        const float xv = xw[jj];
+                        if (DIST == DIST_L1)       acc[jj] += (xv > wreg[jj]) ? At : 0.f;
+                        else if (DIST == DIST_MSE) acc[jj] = fmaf(At, xv - wreg[jj], acc[jj]);
+                        else                       acc[jj] = fmaf(At, xv, acc[jj]);
+                    }
+                }
+                continue;
+            }
             float Wa[JJ], Wb[JJ], A[JJ];
             lds_load<JJ>(Wa, xl);
             for (int t = 0; t < a.tc; t += 2 * JJ) {         // tc is a multiple of 2*JJ: two ping-pong steps
@@ -268,13 +290,18 @@ __global__ void __launch_bounds__(512, 7) shp_bwd_kernel(const ShpBwdArgs a) {
         float* out = a.part + (((size_t)bs * a.K + (kbase + kl)) * a.C + c) * a.L;
 #pragma unroll
         for (int jj = 0; jj < JJ; ++jj)
-            if (jbase + jj < a.L)
-                out[jbase + jj] = (DIST == DIST_L1) ? 2.f * acc[jj] - ssum
+            if (j0 + jbase + jj < a.L)
+                out[j0 + jbase + jj] = (DIST == DIST_L1) ? 2.f * acc[jj] - ssum
                                 : (DIST == DIST_MSE) ? acc[jj] : acc[jj] + wreg[jj] * ssum;
     }
 }
 
 template <int JJ, int DIST>
 static void shp_bwd_launch(const ShpBwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-    hipLaunchKernelGGL((shp_bwd_kernel<JJ, DIST>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((shp_bwd_kernel<JJ, DIST, false>), grid, block, lds, s, a);
+}
+
+template <int DIST>
+static void shp_bwd_strided_launch(const ShpBwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((shp_bwd_kernel<4, DIST, true>), grid, block, lds, s, a);
 }

@@ -18,6 +18,16 @@ shp_bwd_launch_t ign_get_bwd_launcher(int dist, int JJ) {
     return nullptr;
 }
 
+shp_bwd_launch_t ign_get_bwd_strided_launcher(int dist) {
+    switch (dist) {
+        case DIST_L1: return shp_bwd_strided_launch<DIST_L1>;
+        case DIST_MSE: return shp_bwd_strided_launch<DIST_MSE>;
+        case DIST_COS: return shp_bwd_strided_launch<DIST_COS>;
+        case DIST_PEARSON: return shp_bwd_strided_launch<DIST_PEARSON>;
+    }
+    return nullptr;
+}
+
 // out[i] = sum_{s < nparts} part[s][i], s ascending: bitwise reproducible.
 __global__ void __launch_bounds__(256) reduce_parts_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                            int nparts, size_t n) {

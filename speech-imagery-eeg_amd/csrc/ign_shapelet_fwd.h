@@ -322,5 +322,8 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
 
 template <int TT, int KT, int DIST>
 static void shp_fwd_launch(const ShpFwdArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024)      // long rows (EigenWorms: T = 17 984 = 72 KB): a CU of gfx950 has 160 KB of LDS, the default cap is 64
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&shp_fwd_kernel<TT, KT, DIST>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((shp_fwd_kernel<TT, KT, DIST>), grid, block, lds, s, a);
 }

@@ -652,13 +652,13 @@ def case_train_steps_r2(R):
     losses = _three_steps(m, lambda m, x, y: ce(m(x, torch.ones(8, 100), None, None), y), [(xs[i], ys[i]) for i in range(3)])
     nope = lambda d: {k: v for k, v in d.items() if not k.endswith("position_embedding.pe")}     # deterministic sin/cos table
     save("train_step_dnn_transformer", xs=npy(xs), ys=npy(ys), losses=losses, **nope(sd0), **nope(sd_np(m, "sd3.")))
-    # EEG-CNN (C=8, T=200, d_model 64): input (B,C,T), no mask
+    # EEG-CNN (C=8, T=200, d_model 128 = 8 heads x 16): input (B,C,T), no mask
     xe = torch.randn(3, 6, 8, 200, generator=g)
     ye = torch.randint(0, 3, (3, 6), generator=g)
     sink = io.StringIO()
     with contextlib.redirect_stdout(sink):
         torch.manual_seed(0)
-        m = R["eegcnn"].EEGCNNTransformer(cfg(enc_in=8, seq_len=200, num_class=3, c_out=3, d_model=64))
+        m = R["eegcnn"].EEGCNNTransformer(cfg(enc_in=8, seq_len=200, num_class=3, c_out=3, d_model=128))
         sd0 = {k: v for k, v in sd_np(m, "sd0.").items() if not k.endswith("pos_encoder.pe")}
         losses = _three_steps(m, lambda m, x, y: ce(m(x)[0], y), [(xe[i], ye[i]) for i in range(3)])
     sd3 = {k: v for k, v in sd_np(m, "sd3.").items() if not k.endswith("pos_encoder.pe")}

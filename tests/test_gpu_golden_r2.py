@@ -139,6 +139,9 @@ def _adam_trajectory_close(m, g, skip=()):
         if "sd3." + k not in g or any(s in k for s in skip) or not v.dtype.is_floating_point:
             continue
         a, b = v.detach().cpu().numpy().astype(np.float64), g["sd3." + k].astype(np.float64)
+        if k.endswith("in_proj_bias"):           # packed q|k|v bias: the k third has a true-zero gradient (see below)
+            third = a.shape[0] // 3
+            a, b = np.delete(a, np.s_[third:2 * third]), np.delete(b, np.s_[third:2 * third])
         diff = np.abs(a - b)
         bad = diff > (5e-4 + 5e-3 * np.abs(b))
         assert bad.mean() <= 0.05, f"{k}: {bad.mean():.3%} of entries outside tolerance"
@@ -162,7 +165,7 @@ def test_three_adam_steps_other_models(which):
         step = lambda x, y: F.cross_entropy(m(x, torch.ones(x.shape[0], x.shape[1], device=dev), None, None), y)
     else:
         from models.eegcnn import EEGCNNTransformer
-        m = EEGCNNTransformer(make_cfg(enc_in=8, seq_len=200, num_class=3, c_out=3, d_model=64))
+        m = EEGCNNTransformer(make_cfg(enc_in=8, seq_len=200, num_class=3, c_out=3, d_model=128))
         step = lambda x, y: F.cross_entropy(m(x)[0], y)
     m.load_state_dict(sd_from(g, "sd0."), strict=False)
     m.to(dev).train()
@@ -174,8 +177,9 @@ def test_three_adam_steps_other_models(which):
         opt.step()
         opt.zero_grad()
         parity(f"loss_step{i}", loss, np.float64(g["losses"][i]), kind="elem")
-    # EEG-CNN: block1_bn1.* have a (near-)zero true gradient (BN2 removes what BN1's affine adds) -> pure Adam noise
-    _adam_trajectory_close(m, g, skip=("block1_bn1.weight", "block1_bn1.bias", "num_batches_tracked"))
+    # True-zero gradients are pure Adam noise (+-lr per step) in every implementation and are left out: EEG-CNN's block1_bn1.*
+    # (BN2 removes what BN1's affine adds) and every key-projection bias (softmax scores are shift-invariant).
+    _adam_trajectory_close(m, g, skip=("block1_bn1.weight", "block1_bn1.bias", "num_batches_tracked", "key_projection.bias"))
 
 
 @pytest.mark.parametrize("name", ["ch_lts", "ch_cos", "strided_l1", "strided_lts"])

@@ -170,6 +170,63 @@ def test_strided_windows_forward():
     _close(dmin, do)
 
 
+@pytest.mark.parametrize("B,C,T,K,L,stride,mode", [
+    (2, 3, 3100, 4, 310, 8, 0),          # MotorImagery-like: T >= 3000 -> stride int(log2 L) (Shapelet.py:162)
+    (2, 3, 3100, 7, 155, 7, 0),          # K = 7: shapelet tiles of the strided kernel, odd stride
+    (2, 2, 3000, 3, 2400, 11, 0),        # 0.8 T: L > 2048 -> two j-tiles per shapelet
+    (1, 2, 17984, 2, 1799, 10, 0),       # EigenWorms row length: the forward stages 72 KB of LDS per row
+    (1, 2, 17984, 2, 8992, 13, 0),       # ... and its 0.5 T shapelets: five j-tiles
+    (2, 3, 3100, 3, 310, 8, 1),          # MSE
+    (2, 3, 3100, 3, 310, 8, 2),          # cosine
+    (2, 3, 3100, 3, 310, 8, 3),          # pearson
+])
+def test_strided_and_long_rows_forward_backward_vs_oracle(B, C, T, K, L, stride, mode):
+    """seq_len >= 3000: strided windows, forward AND backward (run_uea.sh's MotorImagery / EigenWorms cannot train
+    without it), including rows longer than the 64 KB default LDS window and shapelets longer than one block of lanes."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    from oracle import ign_oracle as O
+    g = torch.Generator().manual_seed(T + L + mode)
+    xn = torch.randn(B, C, T, generator=g)
+    w0 = torch.randn(K, C, L, generator=g)
+    r = torch.randn(B, K * C, generator=g)
+    wo = w0.clone().requires_grad_(True)
+    po, do = O.rbf_straight_through_max(O.window_distance(xn, wo, stride, mode, chunk=32), 1.0)
+    (po * r).sum().backward()
+    wg = w0.clone().to(dev).requires_grad_(True)
+    p, dmin = ops.shapelet_bank(xn.to(dev), [wg], 1.0, mode, strides=[stride])
+    (p * r.to(dev)).sum().backward()
+    _close(p, po, msg="p")
+    _close(dmin, do, msg="dmin")
+    _grad_close(wg.grad, wo.grad.numpy(), f"T{T} L{L} stride{stride} mode{mode}")
+
+
+def test_sbm_trains_at_seq_len_3100():
+    """The whole SBM at seq_len 3100 (stride rule applied by the model itself): forward, loss, backward against the oracle."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    import torch.nn.functional as F
+    from models.Shapelet import ShapeBottleneckModel
+    from oracle import ign_oracle as O
+    cfg = make_cfg(enc_in=3, seq_len=3100, num_class=3)
+    torch.manual_seed(0)
+    ref = O.OracleSBM(cfg, [3, 3], [0.05, 0.1])
+    m = ShapeBottleneckModel(cfg, [3, 3], [0.05, 0.1])
+    m.load_state_dict(ref.state_dict())
+    m.to(dev)
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(3, 3100, 3, generator=g), torch.tensor([0, 1, 2])
+    o_r, i_r = ref(x)
+    (F.cross_entropy(o_r, y) + i_r.loss.mean()).backward()
+    o, i = m(x.to(dev))
+    (F.cross_entropy(o, y.to(dev)) + i.loss.mean()).backward()
+    _close(o, o_r.detach(), msg="out")
+    _close(i.p, i_r.p.detach(), msg="p")
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        _grad_close(p.grad, q.grad.numpy(), n)
+
+
 def test_full_size_properties():
     """B=256, C=122, T=1000 (BASELINE config 1): size-independent checks the oracle cannot reach in seconds."""
     dev = _dev()
@@ -224,4 +281,5 @@ def test_abi_argument_errors():
     assert L.ign_shapelet_fwd(pp, pp, None, pp, pp, 4, 0, pp, pp, None, None, 1, 2, 8, 2, 3, 1, 1.0, 7, None) == -1001  # mode
     assert b"unknown mode" in L.ign_last_error()
     assert L.ign_shapelet_fwd(pp, pp, None, pp, pp, 4, 0, pp, pp, None, None, 1, 2, 8, 2, 3, 1, 1.0, 0x10, None) == -1001  # LTS, no thr
-    assert L.ign_shapelet_bwd_workspace_bytes(1, 2, 8, 2, 3, 2, 0) == 0
+    assert L.ign_shapelet_bwd_workspace_bytes(1, 2, 8, 2, 3, 2, 0) == 1 * 2 * 2 * 3 * 4      # strided plans exist since round 2
+    assert L.ign_shapelet_bwd_workspace_bytes(1, 2, 8, 2, 3, 0, 0) == 0
