@@ -2,16 +2,25 @@
 """Headline benchmark: epochs/sec of IGN 3-class training on synthetic CHISCO-shaped EEG
 (B=256 per GPU, C=122, T=1000; N_train=8192 samples per epoch) -- BASELINE.json's metric.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
 
-A step = one optimizer step of the training hot path (IGN/exp/experiment_classification.py:313-343) on one
-batch per rank: instance norm -> shapelet bank (HIP) -> SBM head || FCN expert (implicit-GEMM conv kernels, second HIP
-stream) -> gini gate -> 3-term loss -> backward (HIP shapelet / conv backward) -> gradient all-reduce over RCCL (N>1) -> Adam.  Inputs are resident in HBM
-before the timed region.  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`: WORLD_SIZE / RANK / LOCAL_RANK come from the environment) or, when WORLD_SIZE is not set, this
+script starts them itself as a child `torch.distributed.run` BEFORE anything here touches the GPU, relays rank 0's JSON line
+and exits with the child's code.
+
+A step = one optimizer step of the training hot path (IGN/exp/experiment_classification.py:313-343) on one batch per
+rank: instance norm -> shapelet bank (HIP) -> SBM head || FCN expert (implicit-GEMM conv kernels, second HIP stream) ->
+gini gate -> 3-term loss -> backward (HIP shapelet / conv backward) -> gradient all-reduce over RCCL (N>1) -> Adam.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.  At N = 1 the default run also times
+the two baselines of BASELINE.json configs 3 / 4 on the same tensors (`baselines` object) and the CPU oracle of each
+workload on the host cores (`cpu_baseline`).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from argparse import Namespace
@@ -25,6 +34,9 @@ import torch.nn.functional as F
 
 N_TRAIN = 8192          # samples per epoch
 PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md, "Peak FP32 (vector)"
+PEAK_FP32_MFMA_TFLOPS = 157.3     # fp32 matrix = the vector rate on gfx950
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 (never the 2:1-sparsity figure)
+MFMA_32x32x16_FLOP = 2 * 32 * 32 * 16
 
 
 def ch_config(model='InterpGN', dnn_type='FCN'):
@@ -32,7 +44,9 @@ def ch_config(model='InterpGN', dnn_type='FCN'):
                      memory_efficient=False, sbm_cls='linear', dropout=0.0, lambda_reg=0.1, lambda_div=0.1,
                      dnn_type=dnn_type, model=model, task_name='classification', pred_len=0, label_len=0,
                      output_attention=False, d_model=512, embed='timeF', freq='h', factor=1, n_heads=8, d_ff=2048,
-                     activation='gelu', e_layers=2)
+                     activation='gelu', e_layers=2,
+                     eegcnn_layers=2, eegcnn_pooling='mean', eegcnn_dropout1=0.0, eegcnn_dropout2=0.0, eegcnn_n_heads=8,
+                     eegcnn_d_ff=256)
 
 
 def synth_batches(n_batches, B, T, C, n_class, rank, world, device):
@@ -43,6 +57,26 @@ def synth_batches(n_batches, B, T, C, n_class, rank, world, device):
         g = torch.Generator().manual_seed(1234 + (i * world + rank))
         xs.append(torch.randn(B, T, C, generator=g).to(device))
         ys.append(torch.randint(0, n_class, (B,), generator=g).to(device))
+    return xs, ys
+
+
+def planted_batches(n_batches, B, T, C, n_class, rank, world, device):
+    """SURVEY 8(d)'s learnable variant: N(0,1) noise plus, per sample, a class-specific sine burst of length 200 (1, 2 or 3
+    periods, amplitude 2 sigma) on 4 random channels at a random offset (seed 4321).  Used only to show the loss falls at the
+    full benchmark size (`--planted`): never the headline."""
+    xs, ys = [], []
+    tt = torch.arange(200, dtype=torch.float32)
+    for i in range(n_batches):
+        g = torch.Generator().manual_seed(4321 + (i * world + rank))
+        x = torch.randn(B, T, C, generator=g)
+        y = torch.randint(0, n_class, (B,), generator=g)
+        off = torch.randint(0, T - 200, (B,), generator=g)
+        ch = torch.stack([torch.randperm(C, generator=g)[:4] for _ in range(B)])
+        for b in range(B):
+            burst = 2.0 * torch.sin(2 * torch.pi * (int(y[b]) + 1) * tt / 200)
+            x[b, off[b]:off[b] + 200, ch[b]] += burst[:, None]
+        xs.append(x.to(device))
+        ys.append(y.to(device))
     return xs, ys
 
 
@@ -65,6 +99,16 @@ def host_cores():
     return max(1, n)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def log(msg):
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
@@ -72,9 +116,21 @@ def log(msg):
 _T0 = time.perf_counter()
 
 
-def cpu_baseline(cfg, sample_b, threads):
-    """The CPU oracle (a restatement of the reference path, kind="port") timed on the host: one full training step
-    (fwd + bwd + Adam) on `sample_b` samples of the same synthetic distribution."""
+# --------------------------------------------------------------------------------------------------------- CPU baselines
+def _time_cpu_steps(step, sample_b, what, threads, timed=3):
+    """BASELINE.md section 3 / SURVEY 8(d): 1 warm-up step + `timed` timed steps (fwd + bwd + Adam), core count and CPU model
+    stated.  kind = "port": the oracle is a restatement of the reference path (the reference's files never travel)."""
+    step()
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        step()
+    dt = (time.perf_counter() - t0) / timed
+    return dict(value=(sample_b / dt) / N_TRAIN, unit="epochs/s", cores=threads, cpu=cpu_model(), kind="port",
+                sample=f"{what}: 1 warm-up + {timed} timed train steps (fwd+bwd+Adam) on {sample_b} samples of shape (1000,122): "
+                       f"{dt:.2f} s/step = {dt / sample_b:.3f} s/sample")
+
+
+def cpu_baseline_ign(cfg, sample_b, threads):
     from oracle import ign_oracle as O
     torch.set_num_threads(threads)
     torch.manual_seed(0)
@@ -84,15 +140,267 @@ def cpu_baseline(cfg, sample_b, threads):
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(sample_b, cfg.seq_len, cfg.enc_in, generator=g)
     y = torch.randint(0, cfg.num_class, (sample_b,), generator=g)
-    t0 = time.perf_counter()
-    out, info = m(x)
-    loss = O.train_loss('InterpGN', out, info, y)
-    loss.backward()
-    opt.step()
-    dt = time.perf_counter() - t0
-    return dict(value=(sample_b / dt) / N_TRAIN, unit="epochs/s", cores=threads, kind="port",
-                sample=f"1 train step (fwd+bwd+Adam) of the CPU oracle on {sample_b} samples of shape (1000,122): "
-                       f"{dt:.1f} s = {dt / sample_b:.2f} s/sample")
+
+    def step():
+        out, info = m(x)
+        loss = O.train_loss('InterpGN', out, info, y)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+    return _time_cpu_steps(step, sample_b, "CPU oracle of IGN(FCN) (oracle/ign_oracle.py)", threads)
+
+
+def cpu_baseline_baseline(config, cfg, state_dict, sample_b, threads):
+    """oracle/baselines_oracle.py on the product model's own initial weights (copied to the host)."""
+    from oracle import baselines_oracle as OB
+    torch.set_num_threads(threads)
+    p = {k: v.detach().float().cpu().clone() for k, v in state_dict.items()}
+    leaves = [v.requires_grad_(True) for k, v in p.items()
+              if v.dtype.is_floating_point and "running_" not in k and not k.endswith(".pe")]
+    opt = torch.optim.Adam(leaves, lr=5e-3)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(sample_b, cfg.seq_len, cfg.enc_in, generator=g)
+    y = torch.randint(0, cfg.num_class, (sample_b,), generator=g)
+    mask = torch.ones(sample_b, cfg.seq_len)
+
+    def step():
+        if config == "transformer":
+            out = OB.transformer_logits(p, x, mask, cfg.e_layers, cfg.n_heads)
+        else:
+            out = OB.eegcnn_logits(p, x.permute(0, 2, 1), training=True, n_layers=2, n_heads=8)
+        F.cross_entropy(out, y).backward()
+        opt.step()
+        opt.zero_grad()
+    return _time_cpu_steps(step, sample_b, f"CPU oracle of the {config} baseline (oracle/baselines_oracle.py)", threads)
+
+
+# ------------------------------------------------------------------------------------------------- self-launch for N > 1
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with no rendezvous environment: start N ranks with torch.distributed.run as a CHILD process
+    (this process has not touched the GPU and never does), relay rank 0's JSON line, propagate failure."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    log(f"starting {n} ranks: {' '.join(cmd)}")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc != 0:
+        raise SystemExit(f"bench.py: the {n}-rank child exited with code {rc}")
+    if line is None:
+        raise SystemExit("bench.py: the ranks finished without printing a result line")
+    print(line, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------- measurement
+class Bench:
+    """One workload (ign | eegcnn | transformer) resident on this rank's GPU: model, flat bucket, Adam, data, step()."""
+
+    def __init__(self, config, args, dev, rank, world, dist):
+        import speech_imagery_eeg_amd  # noqa: F401
+        from ign_hip import ops as ign_ops
+        from ign_hip.ddp import FlatAdam, FlatParamBucket
+        self.config, self.args, self.dev, self.rank, self.world, self.dist = config, args, dev, rank, world, dist
+        self.ops = ign_ops
+        cfg = ch_config(dnn_type=args.dnn)
+        if config == "ign" and args.dnn == "PatchTST":
+            cfg.d_model, cfg.d_ff, cfg.n_heads = 64, 128, 4
+        elif config == "ign" and args.dnn == "TimesNet":
+            cfg.d_model, cfg.d_ff, cfg.top_k, cfg.num_kernels = 32, 32, 3, 6
+        self.cfg = cfg
+        self.B, self.T, self.C = args.batch, cfg.seq_len, cfg.enc_in
+        torch.manual_seed(0)                       # same initial replica on every rank
+        if config == "ign":
+            from models.InterpGN import InterpGN
+            model = InterpGN(cfg) if args.groups == "4x5" else \
+                InterpGN(cfg, num_shapelet=[10] * 6, shapelet_len=[0.05, 0.1, 0.2, 0.3, 0.5, 0.8])
+        elif config == "eegcnn":
+            from models.eegcnn import EEGCNNTransformer
+            model = EEGCNNTransformer(cfg)
+        else:
+            from models.Transformer import Model as TransformerModel
+            model = TransformerModel(cfg)
+        self.state0 = {k: v.detach().clone() for k, v in model.state_dict().items()} if config != "ign" else None
+        self.model = model.to(dev).train()
+        self.bucket = FlatParamBucket(self.model, world)     # flat fp32 grad bucket: one RCCL all-reduce per step
+        self.use_graph = bool(args.graph and world == 1 and config == "ign")
+        self.opt = FlatAdam(self.bucket, lr=5e-3, capturable=self.use_graph)   # one ign_adam_step launch over the flat buffer
+        self.amp = args.precision == "bf16"
+        self.mask = torch.ones(self.B, self.T, device=dev)
+        self.graphed = None
+        self.ar_events = []
+
+    def load_data(self, n_batches):
+        self.n_batches = n_batches
+        make = planted_batches if self.args.planted else synth_batches
+        self.xs, self.ys = make(n_batches, self.B, self.T, self.C, self.cfg.num_class, self.rank, self.world, self.dev)
+
+    def loss_of(self, x, y):
+        """the loss composition of Experiment.train (exp:319-329)"""
+        model, mask, cfgname = self.model, self.mask, self.config
+        if self.amp:
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                if cfgname == "ign":
+                    out, info = model(x, mask, None, None)
+                    return F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y)
+                if cfgname == "eegcnn":
+                    out, info = model(x.permute(0, 2, 1).contiguous())
+                    return F.cross_entropy(out, y) + info.loss.mean()
+                return F.cross_entropy(model(x, mask, None, None), y)
+        if cfgname == "ign":
+            out, info = model(x, mask, None, None)
+            # = F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y), one launch
+            return self.ops.ign_loss(info.shapelet_preds, info.dnn_preds, y, 1.0)[0] + info.loss.mean()
+        if cfgname == "eegcnn":
+            out, info = model(x.permute(0, 2, 1).contiguous())        # (B,C,T), no mask (SURVEY D9)
+            return F.cross_entropy(out, y) + info.loss.mean()
+        return F.cross_entropy(model(x, mask, None, None), y)
+
+    def step_xy(self, x, y):
+        loss = self.loss_of(x, y)
+        loss.backward()
+        self.opt.step()
+        self.bucket.zero_grad()
+        return loss.detach()
+
+    def step(self, i, time_allreduce=False):
+        x, y = self.xs[i % self.n_batches], self.ys[i % self.n_batches]
+        if self.graphed is not None:
+            return self.graphed(x, y)
+        loss = self.loss_of(x, y)
+        loss.backward()
+        if time_allreduce and self.world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.bucket.allreduce()
+            e1.record()
+            self.ar_events.append((e0, e1))
+        else:
+            self.bucket.allreduce()
+        self.opt.step()
+        self.bucket.zero_grad()
+        return loss.detach()
+
+    def fence(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, steps, offset, time_allreduce=False):
+        """EXACTLY `steps` steps between barrier + synchronize fences; MAX over ranks."""
+        self.fence()
+        t0 = time.perf_counter()
+        last = None
+        for i in range(steps):
+            last = self.step(offset + i, time_allreduce)
+        self.fence()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            tt = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, last
+
+
+def attention_roofline(lib_timing, steps, Bh, Lq, E, layers, attn_math):
+    """Attention core: forward 4*Bh*L*S*E flop per layer (QK^T + PV), backward 2.5x (five products; S and dP are recomputed
+    for dQ, which is executed work, not algorithmic).  The split-bf16 kernels execute 48 (forward) and 192
+    (dQ 72 + dK 72 + dV 48) v_mfma_f32_32x32x16_bf16 per 32x32 tile: priced as EXECUTED bf16 flops against the dense bf16
+    peak; the fp32-MFMA kernels are priced as algorithmic fp32 flops against the fp32 matrix peak."""
+    f_fwd = 4.0 * Bh * Lq * Lq * E * layers
+    ms_f = lib_timing["attn_fwd"][0] / steps
+    ms_b = (lib_timing["attn_bwd_dkdv"][0] + lib_timing["attn_bwd_dq"][0]) / steps
+    tf_f = f_fwd / (ms_f * 1e-3) / 1e12 if ms_f > 0 else 0.0
+    tf_b = 2.5 * f_fwd / (ms_b * 1e-3) / 1e12 if ms_b > 0 else 0.0
+    if attn_math == "bf16x6" and E <= 64:
+        tiles = Bh * ((Lq + 31) // 32) ** 2 * layers
+        ex_f, ex_b = 48.0 * MFMA_32x32x16_FLOP * tiles * (E / 64.0), 192.0 * MFMA_32x32x16_FLOP * tiles * (E / 64.0)
+        ex_tf_f = ex_f / (ms_f * 1e-3) / 1e12 if ms_f > 0 else 0.0
+        ex_tf_b = ex_b / (ms_b * 1e-3) / 1e12 if ms_b > 0 else 0.0
+        return {"bound": "mfma", "kernel": "attn_bwd_x6 (dq + dk + dv kernels)", "achieved": ex_tf_b, "peak": PEAK_BF16_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": ex_tf_b / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "ms_per_step": ms_b,
+                "pricing": "executed bf16 MFMA flops (split-bf16: fp32 operands as 3 bf16 terms, 6 products) / dense bf16 peak",
+                "algorithmic_fp32_tflops": tf_b,
+                "fwd_kernel": {"kernel": "attn_fwd_x6", "achieved": ex_tf_f, "frac": ex_tf_f / PEAK_BF16_MFMA_TFLOPS,
+                               "algorithmic_fp32_tflops": tf_f, "ms_per_step": ms_f}}
+    return {"bound": "mfma", "kernel": "attn_bwd_dkdv_kernel+attn_bwd_dq_kernel", "achieved": tf_b, "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": tf_b / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "ms_per_step": ms_b,
+            "pricing": "algorithmic fp32 flops / fp32 matrix peak (v_mfma_f32_32x32x2_f32 kernels)",
+            "fwd_kernel": {"kernel": "attn_fwd_kernel", "achieved": tf_f, "frac": tf_f / PEAK_FP32_MFMA_TFLOPS, "ms_per_step": ms_f}}
+
+
+def gemm_groups(lib, steps, flops_by_label, x6):
+    """ms/step and pricing of the GEMM-shaped kernel groups (timer label -> algorithmic flops per step)."""
+    out = {}
+    for lab, fl in flops_by_label.items():
+        ms, n = lib.timing_read(lab)
+        ms /= steps
+        if ms <= 0:
+            continue
+        tf = fl / (ms * 1e-3) / 1e12
+        if x6:
+            out[lab] = {"ms_per_step": ms, "launches_per_step": n // steps, "algorithmic_fp32_tflops": tf,
+                        "executed_bf16_tflops": 6.0 * tf, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": 6.0 * tf / PEAK_BF16_MFMA_TFLOPS}
+        else:
+            out[lab] = {"ms_per_step": ms, "launches_per_step": n // steps, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "frac": tf / PEAK_FP32_MFMA_TFLOPS}
+    return out
+
+
+def other_kernels(lib, steps, labels):
+    out = {}
+    for lab in labels:
+        ms, n = lib.timing_read(lab)
+        if n:
+            out[lab] = {"ms_per_step": ms / steps, "launches_per_step": n // steps}
+    return out
+
+
+def baseline_result(b, lib, steps, dt, last, cpu_sample):
+    """The JSON fields of one baseline run (configs 3 / 4): throughput, roofline of its attention core (the MFMA path
+    north_star names for config 4), the GEMM / convolution kernel groups, and the CPU oracle of the same model."""
+    from ign_hip import ops as ign_ops
+    cfg, B, T, config = b.cfg, b.B, b.T, b.config
+    x6 = ign_ops.LINEAR_WGRAD == "bf16x6" and not b.amp
+    timing = {k: lib.timing_read(k) for k in ("attn_fwd", "attn_bwd_dkdv", "attn_bwd_dq")}
+    M = float(B * T)
+    if config == "transformer":
+        desc = "Transformer-encoder baseline (d_model 512, 8 heads, d_ff 2048, 2 layers)"
+        roof = attention_roofline(timing, steps, B * cfg.n_heads, T, cfg.d_model // cfg.n_heads, cfg.e_layers, ign_ops.ATTN_MATH)
+        lin = 2.0 * M * (4 * 512 * 512 + 2 * 512 * 2048) * cfg.e_layers        # Q,K,V,O + the two 1x1-conv FFN layers
+        emb = 2.0 * M * 512 * 122 * 3                                            # k=3 circular token embedding
+        groups = gemm_groups(lib, steps, {"clconv_fwd": lin + emb, "clconv_dgrad": lin, "clconv_wgrad": lin + emb}, x6)
+        others = other_kernels(lib, steps, ("layernorm_fwd", "layernorm_bwd", "head_fwd", "head_bwd_x", "head_bwd_w", "adam"))
+    else:
+        desc = "EEG-CNN baseline (CNN 8x8 filters k=125/25 + 2-layer encoder d_model 512, 8 heads, d_ff 256)"
+        S = T // 10
+        roof = attention_roofline(timing, steps, B * 8, S, cfg.d_model // 8, 2, ign_ops.ATTN_MATH)
+        Me = float(B * S)
+        lin = 2.0 * Me * (64 * 512 + 2 * (4 * 512 * 512 + 2 * 512 * 256))       # projection + 2 x (in_proj, out_proj, FFN)
+        groups = gemm_groups(lib, steps, {"clconv_fwd": lin, "clconv_dgrad": lin, "clconv_wgrad": lin}, x6)
+        others = other_kernels(lib, steps, ("eegcnn_b1_fwd", "eegcnn_b1_bwd", "eegcnn_b2_fwd", "eegcnn_b2_bwd", "eegcnn_apply",
+                                            "autocorr", "dwconv1d", "dwconv1d_bwd_w", "conv1_sumsq_fwd", "conv1_sumsq_bwd",
+                                            "layernorm_fwd", "layernorm_bwd", "adam"))
+    res = {"metric": f"epochs/sec (B=256, C=122, T=1000) {config} baseline 3-class",
+           "value": (steps * B * b.world / N_TRAIN) / dt, "unit": "epochs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+           "workload": f"Synthetic CHISCO-shape EEG (122ch x 1000, 3-class) {desc}, Adam lr 5e-3, fp32", "final_loss": float(last),
+           "roofline": roof, "gemm_kernels": groups, "other_kernels": others}
+    if b.world == 1 and cpu_sample > 0 and b.rank == 0:
+        log(f"cpu baseline ({config}) ...")
+        res["cpu_baseline"] = cpu_baseline_baseline(config, cfg, b.state0, 4 if config == "transformer" else 16, host_cores())
+    return res
 
 
 def main():
@@ -105,7 +413,10 @@ def main():
                     "GEMMs on the fp32-MFMA kernels instead of the split-bf16 ones (0 = skip)")
     ap.add_argument("--iso-steps", type=int, default=8, help="steps of the serial (one-stream) pass that measures isolated "
                     "kernel durations for the roofline object")
-    ap.add_argument("--cpu-sample", type=int, default=12, help="samples for the CPU baseline step (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=3, help="samples per step of the IGN CPU baseline (1 warm-up + 3 timed "
+                    "steps; 0 = skip every CPU baseline)")
+    ap.add_argument("--baseline-steps", type=int, default=6, help="timed steps of each baseline (configs 3 / 4) appended to the "
+                    "default single-GPU IGN run as the `baselines` object (0 = skip)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step (fwd + loss + bwd + Adam) as one captured hipGraph (single GPU; pays off in "
                          "launch-bound regimes such as --batch 32, the UEA setting of run_uea.sh)")
@@ -124,14 +435,19 @@ def main():
     ap.add_argument("--config", choices=["ign", "eegcnn", "transformer"], default="ign",
                     help="ign = BASELINE.json's headline (config 1 / 5); eegcnn / transformer = the baselines of "
                          "configs 3 / 4 on the same synthetic tensors")
+    ap.add_argument("--planted", action="store_true",
+                    help="SURVEY 8(d)'s learnable synthetic variant (class-specific sine bursts planted in the noise): shows the "
+                         "training loss falling at the full benchmark size; reported in config.loss_curve, never the headline")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])           # nothing above has touched the GPU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # IGN_BENCH_REHEARSAL=1: every rank uses cuda:0 and the collective runs over gloo -- a functional rehearsal of the N > 1
@@ -141,6 +457,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if rehearsal:
@@ -148,132 +465,56 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    torch.set_num_threads(host_cores())
+    torch.set_num_threads(max(1, host_cores() // world))
     import speech_imagery_eeg_amd  # noqa: F401
     from ign_hip import _lib
-    from ign_hip import ops as ign_ops
-    from ign_hip.ddp import FlatAdam, FlatParamBucket
-    from models.InterpGN import InterpGN
 
-    cfg = ch_config(dnn_type=args.dnn)
-    if args.dnn == "PatchTST":
-        cfg.d_model, cfg.d_ff, cfg.n_heads = 64, 128, 4
-    elif args.dnn == "TimesNet":
-        cfg.d_model, cfg.d_ff, cfg.top_k, cfg.num_kernels = 32, 32, 3, 6
-    B, T, C = args.batch, cfg.seq_len, cfg.enc_in
-    torch.manual_seed(0)                       # same initial replica on every rank
-    if args.config == "ign":
-        model = InterpGN(cfg) if args.groups == "4x5" else \
-            InterpGN(cfg, num_shapelet=[10] * 6, shapelet_len=[0.05, 0.1, 0.2, 0.3, 0.5, 0.8])
-    elif args.config == "eegcnn":
-        from models.eegcnn import EEGCNNTransformer
-        cfg.eegcnn_layers, cfg.eegcnn_pooling, cfg.eegcnn_dropout1, cfg.eegcnn_dropout2 = 2, 'mean', 0.0, 0.0
-        cfg.eegcnn_n_heads, cfg.eegcnn_d_ff = 8, 256
-        model = EEGCNNTransformer(cfg)
-    else:
-        from models.Transformer import Model as TransformerModel
-        model = TransformerModel(cfg)
-    model = model.to(dev).train()
-    bucket = FlatParamBucket(model, world)     # flat fp32 grad bucket: one RCCL all-reduce per step
-    use_graph = args.graph and world == 1 and args.config == "ign"
-    opt = FlatAdam(bucket, lr=5e-3, capturable=use_graph)   # one ign_adam_step launch over the flat parameter buffer
-
+    b = Bench(args.config, args, dev, rank, world, dist)
+    B, T, C, cfg = b.B, b.T, b.C, b.cfg
     n_batches = min(args.steps + args.warmup, max(1, N_TRAIN // (B * world)))
     log(f"generating {n_batches} synthetic batches on the host ...")
-    xs, ys = synth_batches(n_batches, B, T, C, cfg.num_class, rank, world, dev)
+    b.load_data(n_batches)
     log("warm-up ...")
-    mask = torch.ones(B, T, device=dev)
-
-    def step_xy(x, y):
-        out, info = model(x, mask, None, None)
-        loss = ign_ops.ign_loss(info.shapelet_preds, info.dnn_preds, y, 1.0)[0] + info.loss.mean()
-        loss.backward()
-        opt.step()
-        bucket.zero_grad()
-        return loss.detach()
-
-    graphed = None
-
-    amp = args.precision == "bf16"
-
-    def step(i):
-        x, y = xs[i % n_batches], ys[i % n_batches]
-        if graphed is not None:
-            return graphed(x, y)
-        if amp:
-            # the composition of Experiment.train inside the autocast region (exp:319-329)
-            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
-                if args.config == "ign":
-                    out, info = model(x, mask, None, None)
-                    loss = F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y)
-                elif args.config == "eegcnn":
-                    out, info = model(x.permute(0, 2, 1).contiguous())
-                    loss = F.cross_entropy(out, y) + info.loss.mean()
-                else:
-                    loss = F.cross_entropy(model(x, mask, None, None), y)
-        elif args.config == "ign":
-            out, info = model(x, mask, None, None)
-            # = F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y), as Experiment.train
-            loss = ign_ops.ign_loss(info.shapelet_preds, info.dnn_preds, y, 1.0)[0] + info.loss.mean()
-        elif args.config == "eegcnn":
-            out, info = model(x.permute(0, 2, 1).contiguous())        # (B,C,T), no mask
-            loss = F.cross_entropy(out, y) + info.loss.mean()
-        else:
-            loss = F.cross_entropy(model(x, mask, None, None), y)
-        loss.backward()
-        bucket.allreduce()
-        opt.step()
-        bucket.zero_grad()
-        return loss.detach()
-
-    if use_graph:
+    if b.use_graph:
         from ign_hip.graph import GraphedTrainStep
-        graphed = GraphedTrainStep(step_xy, (xs[0], ys[0]))
+        b.graphed = GraphedTrainStep(b.step_xy, (b.xs[0], b.ys[0]))
+    curve = []
     for i in range(args.warmup):
-        step(i)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        l = b.step(i)
+        if args.planted:
+            curve.append(l)
 
     log("timed region ...")
     _lib.timing_enable(True)
-    fence()
-    t0 = time.perf_counter()
-    last = None
-    for i in range(args.steps):
-        last = step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    if args.planted:             # the loss curve costs nothing inside the region: detached device scalars, read afterwards
+        b.fence()
+        t0 = time.perf_counter()
+        last = None
+        for i in range(args.steps):
+            last = b.step(args.warmup + i, True)
+            curve.append(last)
+        b.fence()
+        dt = time.perf_counter() - t0
+    else:
+        dt, last = b.timed(args.steps, args.warmup, time_allreduce=True)
     fwd_ms, fwd_n = _lib.timing_read("shp_fwd")
     bwd_ms, bwd_n = _lib.timing_read("shp_bwd")
+    ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in b.ar_events) / max(1, len(b.ar_events)) if b.ar_events else 0.0
+
+    if args.config != "ign":
+        res_b = baseline_result(b, _lib, args.steps, dt, last, args.cpu_sample)
 
     # The same K steps with the convolution GEMMs on the fp32-MFMA kernels (v_mfma_f32_32x32x2_f32), reported next to the
     # headline so that both arithmetic choices are measured in one run (results agree to ~1e-6).
     alt = None
-    if args.config == "ign" and args.alt_steps > 0:
+    if args.config == "ign" and args.alt_steps > 0 and not args.planted:
         from ign_hip import fcn as _fcn_alt
         if _fcn_alt.CONV_MATH == "bf16x6":
             _fcn_alt.CONV_MATH = "f32"
             try:
                 for i in range(2):
-                    step(i)
-                fence()
-                t1 = time.perf_counter()
-                for i in range(args.alt_steps):
-                    step(args.warmup + i)
-                fence()
-                dt_alt = time.perf_counter() - t1
-                if world > 1:
-                    tt = torch.tensor([dt_alt], device=dev, dtype=torch.float64)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    dt_alt = float(tt.item())
+                    b.step(i)
+                dt_alt, _ = b.timed(args.alt_steps, args.warmup)
                 alt = {"conv_math": "f32 (v_mfma_f32_32x32x2_f32)", "steps": args.alt_steps,
                        "ms_per_step": 1e3 * dt_alt / args.alt_steps,
                        "value": (args.alt_steps * B * world / N_TRAIN) / dt_alt, "unit": "epochs/s"}
@@ -288,13 +529,13 @@ def main():
         from models.InterpGN import InterpGN as _IGN
         was = _IGN.expert_streams
         _IGN.expert_streams = False
-        graphed = None                                   # the isolated pass runs eagerly
+        b.graphed = None                                   # the isolated pass runs eagerly
         try:
-            step(0)
+            b.step(0)
             torch.cuda.synchronize()
             _lib.timing_enable(True)                 # resets the registry
             for i in range(args.iso_steps):
-                step(args.warmup + i)
+                b.step(args.warmup + i)
             torch.cuda.synchronize()
             for lab in ("shp_fwd", "shp_bwd", "clconv_fwd", "clconv_dgrad", "clconv_wgrad"):
                 ms, n = _lib.timing_read(lab)
@@ -302,8 +543,9 @@ def main():
         finally:
             _IGN.expert_streams = was
 
-    attn = {k: _lib.timing_read(k) for k in ("attn_fwd", "attn_bwd_dkdv", "attn_bwd_dq")} if args.config != "ign" else {}
+    res = None
     if rank == 0:
+        amp = b.amp
         res = {
             "metric": "epochs/sec (B=256, C=122, T=1000) IGN 3-class" if args.config == "ign" else
                       f"epochs/sec (B=256, C=122, T=1000) {args.config} baseline 3-class",
@@ -320,21 +562,32 @@ def main():
         if args.config == "ign" and args.dnn != "FCN":
             res["metric"] += f" [deep expert {args.dnn}]"
         common = {"per_gpu_batch": B, "global_batch": B * world, "samples_per_epoch": N_TRAIN,
-                  "parallelism": f"dp{world}", "final_loss": float(last), "hipgraph": bool(use_graph)}
+                  "parallelism": f"dp{world}", "final_loss": float(last), "hipgraph": bool(b.use_graph)}
+        if world > 1:
+            common["collective"] = {"backend": "gloo (rehearsal)" if rehearsal else "nccl (RCCL over xGMI)", "ranks": world,
+                                    "bucket_bytes": b.bucket.nbytes, "allreduce_ms_per_step": ar_ms,
+                                    "what": "one all-reduce(sum) of the flat fp32 gradient bucket per optimizer step, then / ranks"}
         if rehearsal:
             common["rehearsal"] = "all ranks on cuda:0 over gloo: functional check of the N > 1 path, NOT a measurement"
+        if args.planted:
+            vals = [float(v) for v in curve]
+            common["data_variant"] = "planted class-specific sine bursts (SURVEY 8(d)); NOT the headline data"
+            common["loss_curve"] = {"first": vals[0], "last": vals[-1], "every_8th": vals[::8]}
         if args.config == "ign":
-            groups = [(s.n, s.length) for s in model.sbm.shapelets]
+            groups = [(s.n, s.length) for s in b.model.sbm.shapelets]
             f_fwd, f_bwd = shapelet_algorithmic_flops(B, C, T, groups)
             # dominant kernel: the shapelet backward (3E of the 5E shapelet flops).  One step issues one launch per
             # length group; `achieved` aggregates the G launches of a step (algorithmic flops / measured device time).
             bwd_tflops = (f_bwd * args.steps) / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
             fwd_tflops = (f_fwd * args.steps) / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
-            traffic = None
+            traffic, traffic_src = None, None
             try:    # HBM bytes per step of the dominant kernel, from the committed PMC passes (see profiles/traffic.json)
                 if args.groups != "4x5":
                     raise KeyError("the PMC passes were collected for the headline bank only")
-                traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["shp_bwd_kernel"]["bytes_per_step"]
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                traffic = tj["shp_bwd_kernel"]["bytes_per_step"]
+                traffic_src = ("NOT measured in this run: read from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                               "(profiles/traffic.json, " + str(tj.get("source", "see file")) + ")")
             except Exception:
                 pass
             from ign_hip import fcn as _fcn
@@ -347,7 +600,8 @@ def main():
                                                             if _fcn.CONV_MATH == "bf16x6" else ""))
             res["roofline"] = {"bound": "valu", "kernel": "shp_bwd_kernel", "achieved": bwd_tflops,
                                "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": bwd_tflops / PEAK_FP32_VALU_TFLOPS,
-                               "traffic": traffic, "ms_per_step": bwd_ms / max(1, args.steps), "launches": bwd_n,
+                               "traffic": traffic, "traffic_source": traffic_src,
+                               "ms_per_step": bwd_ms / max(1, args.steps), "launches": bwd_n,
                                "note": "timed region = two HIP streams (SBM expert || FCN expert): these brackets include "
                                        "time shared with the other expert's kernels; 'isolated' = the same kernels in a "
                                        "serial pass of --iso-steps steps right after the timed region",
@@ -365,12 +619,13 @@ def main():
                     # split-bf16: six bf16 MFMA products per algorithmic fp32 product, priced against the dense bf16 peak
                     if x6:
                         return {"ms_per_step": ms, "achieved": tf_alg, "unit": "TFLOP/s fp32-equivalent (algorithmic)",
-                                "executed_bf16_tflops": 6.0 * tf_alg, "peak": 2500.0, "frac": 6.0 * tf_alg / 2500.0}
+                                "executed_bf16_tflops": 6.0 * tf_alg, "peak": PEAK_BF16_MFMA_TFLOPS,
+                                "frac": 6.0 * tf_alg / PEAK_BF16_MFMA_TFLOPS}
                     if _fcn.CONV_MATH == "bf16":
                         # operands rounded to bf16, one product (the reference's autocast arithmetic): priced against the bf16 peak
                         return {"ms_per_step": ms, "achieved": tf_alg, "unit": "TFLOP/s bf16 (one product, fp32 accumulate)",
-                                "peak": 2500.0, "frac": tf_alg / 2500.0}
-                    return {"ms_per_step": ms, "achieved": tf_alg, "peak": 157.3, "frac": tf_alg / 157.3}
+                                "peak": PEAK_BF16_MFMA_TFLOPS, "frac": tf_alg / PEAK_BF16_MFMA_TFLOPS}
+                    return {"ms_per_step": ms, "achieved": tf_alg, "peak": PEAK_FP32_MFMA_TFLOPS, "frac": tf_alg / PEAK_FP32_MFMA_TFLOPS}
                 fcn_f = 2.0 * B * (993 * 128 * 976 + 989 * 256 * 640 + 987 * 128 * 768)
                 fcn_d = 2.0 * B * (993 * 128 * 1280 + 989 * 256 * 384)                          # data gradients of blocks 3, 2
                 # measured instruction-issue ceilings of the two inner loops in isolation (profiles/r1_valu_microbench.txt):
@@ -390,27 +645,35 @@ def main():
                        for nm, fl in (("fwd", fcn_f), ("dgrad", fcn_d), ("wgrad", fcn_f))},
                     "steps": args.iso_steps}
         else:
-            # attention core: fwd 4*B*H*L*S*E flop per layer (QK^T + PV); the two backward kernels execute 7 products
-            # (S and dP are recomputed for dQ) but the ALGORITHMIC count is 5 products = 2.5x forward.
-            if args.config == "transformer":
-                Bh, Lq, E_, layers, desc = B * cfg.n_heads, T, cfg.d_model // cfg.n_heads, cfg.e_layers, \
-                    "Transformer-encoder baseline (d_model 512, 8 heads, d_ff 2048, 2 layers)"
-            else:
-                Bh, Lq, E_, layers, desc = B * 8, T // 10, cfg.d_model // 8, 2, \
-                    "EEG-CNN baseline (CNN 8x8 filters k=125/25 + 2-layer encoder d_model 512, 8 heads, d_ff 256)"
-            f_attn_fwd = 4.0 * Bh * Lq * Lq * E_ * layers
-            ms_f, ms_b = attn["attn_fwd"][0], attn["attn_bwd_dkdv"][0] + attn["attn_bwd_dq"][0]
-            tf_f = f_attn_fwd * args.steps / (ms_f * 1e-3) / 1e12 if ms_f > 0 else 0.0
-            tf_b = 2.5 * f_attn_fwd * args.steps / (ms_b * 1e-3) / 1e12 if ms_b > 0 else 0.0
-            res["config"] = dict(common, workload=f"Synthetic CHISCO-shape EEG (122ch x 1000, 3-class) {desc}, Adam lr 5e-3, fp32")
-            res["roofline"] = {"bound": "mfma", "kernel": "attn_bwd_dkdv_kernel+attn_bwd_dq_kernel", "achieved": tf_b,
-                               "peak": 157.3, "unit": "TFLOP/s", "frac": tf_b / 157.3, "traffic": None,
-                               "ms_per_step": ms_b / max(1, args.steps),
-                               "fwd_kernel": {"kernel": "attn_fwd_kernel", "achieved": tf_f, "frac": tf_f / 157.3,
-                                              "ms_per_step": ms_f / max(1, args.steps)}}
+            res["config"] = dict(common, workload=res_b["workload"])
+            res["roofline"] = res_b["roofline"]
+            res["gemm_kernels"], res["other_kernels"] = res_b["gemm_kernels"], res_b["other_kernels"]
+            if "cpu_baseline" in res_b:
+                res["cpu_baseline"] = res_b["cpu_baseline"]
+
+    # ---- configs 3 / 4 in the same run (single GPU, default invocation): a few timed steps each, own roofline + CPU oracle
+    if world == 1 and args.config == "ign" and args.baseline_steps > 0 and not args.planted and args.dnn == "FCN" \
+            and args.groups == "4x5" and not b.amp:
+        del b
+        torch.cuda.empty_cache()
+        baselines = {}
+        for name in ("eegcnn", "transformer"):
+            log(f"baseline {name} ...")
+            bb = Bench(name, args, dev, rank, world, dist)
+            bb.load_data(min(4, N_TRAIN // B))
+            for i in range(3):
+                bb.step(i)
+            _lib.timing_enable(True)
+            dtb, lastb = bb.timed(args.baseline_steps, 3)
+            baselines[name] = baseline_result(bb, _lib, args.baseline_steps, dtb, lastb, args.cpu_sample)
+            del bb
+            torch.cuda.empty_cache()
+        res["baselines"] = baselines
+
+    if rank == 0:
         if world == 1 and args.cpu_sample > 0 and args.config == "ign":
-            log("cpu baseline ...")
-            res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, host_cores())
+            log("cpu baseline (ign) ...")
+            res["cpu_baseline"] = cpu_baseline_ign(cfg, args.cpu_sample, host_cores())
         print(json.dumps(res), flush=True)
     _lib.timing_enable(False)
     if world > 1:

@@ -179,7 +179,8 @@ def test_three_adam_steps_other_models(which):
         parity(f"loss_step{i}", loss, np.float64(g["losses"][i]), kind="elem")
     # True-zero gradients are pure Adam noise (+-lr per step) in every implementation and are left out: EEG-CNN's block1_bn1.*
     # (BN2 removes what BN1's affine adds) and every key-projection bias (softmax scores are shift-invariant).
-    _adam_trajectory_close(m, g, skip=("block1_bn1.weight", "block1_bn1.bias", "num_batches_tracked", "key_projection.bias"))
+    _adam_trajectory_close(m, g, skip=("block1_bn1.weight", "block1_bn1.bias", "block1_bn2.running_mean", "num_batches_tracked",
+                                       "key_projection.bias"))        # bn2.running_mean absorbs the noise-driven bn1.bias one-for-one
 
 
 @pytest.mark.parametrize("name", ["ch_lts", "ch_cos", "strided_l1", "strided_lts"])
