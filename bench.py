@@ -399,7 +399,7 @@ def baseline_result(b, lib, steps, dt, last, cpu_sample):
            "roofline": roof, "gemm_kernels": groups, "other_kernels": others}
     if b.world == 1 and cpu_sample > 0 and b.rank == 0:
         log(f"cpu baseline ({config}) ...")
-        res["cpu_baseline"] = cpu_baseline_baseline(config, cfg, b.state0, 4 if config == "transformer" else 16, host_cores())
+        res["cpu_baseline"] = cpu_baseline_baseline(config, cfg, b.state0, 16 if config == "transformer" else 64, host_cores())
     return res
 
 
@@ -413,7 +413,7 @@ def main():
                     "GEMMs on the fp32-MFMA kernels instead of the split-bf16 ones (0 = skip)")
     ap.add_argument("--iso-steps", type=int, default=8, help="steps of the serial (one-stream) pass that measures isolated "
                     "kernel durations for the roofline object")
-    ap.add_argument("--cpu-sample", type=int, default=3, help="samples per step of the IGN CPU baseline (1 warm-up + 3 timed "
+    ap.add_argument("--cpu-sample", type=int, default=8, help="samples per step of the IGN CPU baseline (1 warm-up + 3 timed "
                     "steps; 0 = skip every CPU baseline)")
     ap.add_argument("--baseline-steps", type=int, default=6, help="timed steps of each baseline (configs 3 / 4) appended to the "
                     "default single-GPU IGN run as the `baselines` object (0 = skip)")

@@ -113,6 +113,12 @@ class Experiment(object):
               f"world={self.world} seq_len={args.seq_len} enc_in={args.enc_in} num_class={args.num_class} "
               f"train/val/test={len(self.train_data)}/{len(self.val_data)}/{len(self.test_data)}")
 
+    def _sync_buffers(self, src=0):
+        """floating-point buffers (BatchNorm running mean / variance) of rank `src` -> every rank"""
+        for buf in self.model.buffers():
+            if buf.dtype.is_floating_point:
+                dist.broadcast(buf.data, src=src)
+
     def _prefetch(self, loader):
         transform = standardise_raw_batch if getattr(loader, 'device_transform', None) == 'standardise_raw' else None
         if self.device.type != 'cuda' and transform is None:
@@ -233,7 +239,17 @@ class Experiment(object):
             if not losses:
                 continue
             train_loss = torch.stack(losses).mean().item()      # one host sync per epoch (the reference syncs per step)
+            if self.distributed:
+                # BatchNorm running statistics are per rank (each rank saw its own shards); the model that is validated,
+                # early-stopped on and checkpointed is rank 0's, so every rank evaluates THAT one ...
+                self._sync_buffers(0)
             val_loss, val_acc = self.validation()
+            if self.distributed:
+                # ... and the stopping decision is taken from one (val_loss, val_acc) pair: ranks that disagreed by one
+                # flipped argmax would leave the epoch loop at different times and dead-lock in the next all-reduce
+                t = torch.tensor([val_loss, val_acc], dtype=torch.float64, device=self.device)
+                dist.broadcast(t, src=0)
+                val_loss, val_acc = float(t[0]), float(t[1])
             remain = (time.time() - t_start) * (a.train_epochs - epoch) / (epoch + 1)
             if (epoch + 1) % a.log_interval == 0 and self.rank == 0:
                 print(f"Epoch {epoch + 1}/{a.train_epochs} | Train Loss {train_loss:.4f} | Val Loss {val_loss:.4f} | "

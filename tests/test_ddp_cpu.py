@@ -131,3 +131,43 @@ def _harness_worker(rank, world, port, tmp):
 
 def test_experiment_under_gloo(tmp_path):
     mp.spawn(_harness_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def _early_stop_worker(rank, world, port, tmp):
+    """A BatchNorm model (IGN with the FCN expert) whose per-rank running statistics differ, trained until early stopping
+    fires: every rank must take the same stopping decision in the same epoch and end with the same weights AND buffers."""
+    _init(rank, world, port)
+    os.chdir(tmp)
+    import run
+    from exp.experiment_classification import Experiment
+    from oracle import ign_oracle as O
+    Experiment.model_dict['InterpGN'] = lambda cfg: O.OracleIGN(cfg)
+    a = run.get_args(["--model", "InterpGN", "--data", "SYNTH", "--synthetic", "64,3,40,3", "--train_epochs", "12",
+                      "--batch_size", "8", "--seed", "0", "--amp", "--log_interval", "1", "--patience", "1", "--min_epochs", "0",
+                      "--lr", "0.02"])
+    run.set_seed(0)
+    e = Experiment(a)
+    seen = []
+    orig = e.validation
+
+    def rec():
+        # per-rank running statistics really differ before the sync would be needed: record what THIS rank computes
+        r = orig()
+        seen.append(r)
+        return r
+    e.validation = rec
+    e.train()
+    info = [None] * world
+    dist.all_gather_object(info, dict(stop=e.epoch_stop, n_val=len(seen), vals=seen,
+                                      sd={k: v.cpu().numpy() for k, v in e.model.state_dict().items()}))
+    assert info[0]["stop"] == info[1]["stop"] and info[0]["n_val"] == info[1]["n_val"]
+    assert info[0]["stop"] < 11, "early stopping never fired: the test would not cover the divergence"
+    assert info[0]["vals"] == info[1]["vals"]                   # same model evaluated on every rank (buffers synced)
+    for k in info[0]["sd"]:
+        np.testing.assert_array_equal(info[0]["sd"][k], info[1]["sd"][k], err_msg=k)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_early_stopping_is_one_decision_for_all_ranks(tmp_path):
+    mp.spawn(_early_stop_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
