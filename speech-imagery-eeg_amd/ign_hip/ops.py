@@ -9,9 +9,7 @@ from . import _lib
 import os
 
 DIST_L1, DIST_MSE, DIST_COS, DIST_PEARSON = 0, 1, 2, 3
-LINEAR_IMPL = os.environ.get("IGN_LINEAR", "hip")      # "torch": route ops.linear to hipBLASLt (A/B measurements)
 ATTN_MATH = os.environ.get("IGN_ATTN_MATH", "bf16x6")          # "f32": attention core on the fp32-MFMA kernels
-LAYERNORM_IMPL = os.environ.get("IGN_LAYERNORM", "hip")          # "torch": nn.LayerNorm's own kernels (A/B runs)
 LAYERNORM_MIN_ROWS = 65536
 LINEAR_WGRAD = os.environ.get("IGN_LINEAR_WGRAD", "bf16x6")   # "f32": weight gradient of ops.linear on the fp32-MFMA TN kernel
 GATE_RBF, GATE_LTS = 0x00, 0x10
@@ -373,7 +371,7 @@ def linear(x, w, bias=None):
         raise _lib.IgnError(f"linear: tensor on {x.device}; the product path runs on the MI355X only (no CPU fallback)")
     if (x.dtype != torch.float32 or w.dtype != torch.float32
             or w.shape[0] % 4 or x.numel() == 0 or x.shape[-1] != w.shape[1]
-            or x.numel() // x.shape[-1] >= (1 << 30) or LINEAR_IMPL != "hip"):
+            or x.numel() // x.shape[-1] >= (1 << 30)):
         return torch.nn.functional.linear(x, w, bias)
     return LinearFn.apply(x, w, bias)
 
@@ -424,7 +422,7 @@ def layer_norm(x, norm):
     # 25 600 rows, 8.34 vs 8.50 ms/step); above, torch's kernels fall off the memory roofline (Transformer: 256 000 rows of 512,
     # 96.9 -> 94.9 ms/step; PatchTST: 3.9 M rows of 64, 123.9 -> 79.4 ms/step)
     if (not x.is_cuda or x.dtype != torch.float32 or norm.weight is None or len(norm.normalized_shape) != 1 or D % 4 or D > 2048
-            or x.numel() < LAYERNORM_MIN_ROWS * D or LAYERNORM_IMPL != "hip"):
+            or x.numel() < LAYERNORM_MIN_ROWS * D):
         return norm(x)
     return LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
 

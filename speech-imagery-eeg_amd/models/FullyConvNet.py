@@ -6,18 +6,12 @@ loader's (B, T, C) batch IS the GEMM operand (the im2col row of (b, t) is x[b, t
 come out of the GEMM epilogue and BatchNorm's affine + ReLU are applied while the next GEMM stages its operand.
 Inside a ``torch.autocast(bfloat16)`` region (the reference's default mode: ``--amp`` switches it OFF) the same kernels run with
 their operands rounded to bf16 and ONE product per MFMA step (``fcn.CONV_MATH`` "bf16"), activations and BatchNorm stay fp32.
-``IGN_FCN_MIOPEN=1`` routes the convolutions through torch's MIOpen backend instead (A/B measurements only).
+(The MIOpen A/B comparison of round 1 lives in tests/diag_conv_speed.py; the product module has no library route.)
 """
-import os
-
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ign_hip import fcn, ops
-
-# IGN_FCN_MIOPEN=1 routes the convolutions through torch's MIOpen backend instead (A/B measurements only)
-_USE_CLCONV = os.environ.get("IGN_FCN_MIOPEN", "0") != "1"
 
 
 class FullyConvNetwork(nn.Module):
@@ -30,27 +24,12 @@ class FullyConvNetwork(nn.Module):
         self.pooling = nn.AdaptiveAvgPool1d(1)
         self.fc = nn.Linear(128, configs.num_class)
 
-    @staticmethod
-    def _block(block, h):
-        conv, bn = block[0], block[1]
-        h = F.conv2d(h, conv.weight.unsqueeze(2), conv.bias)
-        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-        h = F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training or not bn.track_running_stats,
-                         bn.momentum, bn.eps)
-        return F.relu(h)
-
     def forward(self, x, x_mark_enc=None, x_dec=None, x_mark_dec=None, mask=None, x_bct=None):
         if not x.is_cuda:
             raise ops._lib.IgnError(f"FCN expert: tensor on {x.device}; the deep experts run on the MI355X only (no CPU fallback)")
         if x.dtype == torch.float32:
-            if _USE_CLCONV:
-                # x (B,T,C) is already the channels-last operand of the implicit GEMM: no transpose, no im2col
-                pooled = fcn.fcn_body(x, [(b[0], b[1]) for b in (self.block1, self.block2, self.block3)])
-            else:
-                h = x.permute(0, 2, 1).unsqueeze(2)              # (B,C,1,T) view, channels-last strides, no copy
-                h = self._block(self.block3, self._block(self.block2, self._block(self.block1, h)))
-                pooled = h.mean(dim=(2, 3))
+            # x (B,T,C) is already the channels-last operand of the implicit GEMM: no transpose, no im2col
+            pooled = fcn.fcn_body(x, [(b[0], b[1]) for b in (self.block1, self.block2, self.block3)])
         else:
             h = x_bct if x_bct is not None else x.permute(0, 2, 1)
             h = self.block3(self.block2(self.block1(h)))
