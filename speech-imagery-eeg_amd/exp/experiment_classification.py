@@ -318,9 +318,10 @@ class Experiment(object):
             p: list = field(default_factory=list)
             d: list = field(default_factory=list)
             eta: list = field(default_factory=list)
+            t: list = field(default_factory=list)
             loss: list = field(default_factory=list)
 
-        buf = Buffer()
+        buf = Buffer()       # accumulators stay ON THE DEVICE; one host copy per field after the loop
         self.model.eval()
         with torch.no_grad():
             for batch_x, label, padding_mask in self.test_loader:
@@ -337,21 +338,24 @@ class Experiment(object):
                     loss = F.cross_entropy(logits, label, reduction='none')
                     if a.model != 'DNN':
                         loss = loss + info.loss.mean()
-                buf.loss.append(loss.flatten().float().cpu())
-                buf.x_data.append(batch_x.cpu())
-                buf.trues.append(label.cpu())
-                buf.preds.append(logits.float().cpu())
+                buf.loss.append(loss.flatten().float())
+                buf.x_data.append(batch_x)
+                buf.trues.append(label)
+                buf.preds.append(logits.float())
                 if a.model in ('InterpGN', 'SBM', 'LTS'):
-                    buf.p.append(info.p.cpu())
-                    buf.d.append(info.d.cpu())
-                    buf.shapelet_preds.append(info.shapelet_preds.float().cpu())
+                    buf.p.append(info.p)
+                    buf.d.append(info.d)
+                    buf.shapelet_preds.append(info.shapelet_preds.float())
+                    if getattr(info, 't', None) is not None:
+                        buf.t.append(info.t)
                     if a.model == 'InterpGN':
-                        buf.eta.append(info.eta.float().cpu())
-                        buf.dnn_preds.append(info.dnn_preds.float().cpu())
+                        buf.eta.append(info.eta.float())
+                        buf.dnn_preds.append(info.dnn_preds.float())
         if not buf.trues:
             return float('inf'), None, None
-        trues = torch.cat(buf.trues).flatten()
-        logits = torch.cat(buf.preds)
+        host = lambda parts: torch.cat(parts).cpu()
+        trues = host(buf.trues).flatten()
+        logits = host(buf.preds)
         predictions = logits.argmax(dim=1)
         accuracy = accuracy_score(predictions.numpy(), trues.numpy())
         test_loss = torch.cat(buf.loss).mean().item()
@@ -359,17 +363,22 @@ class Experiment(object):
             base = 100.0 / a.num_class
             print(f"Test: n={len(trues)} loss={test_loss:.6f} acc={accuracy:.4f} ({accuracy * 100:.2f}%; "
                   f"random baseline {base:.2f}%)")
-        res = ClassificationResult(x_data=torch.cat(buf.x_data), trues=trues, preds=predictions, loss=test_loss,
+        res = ClassificationResult(x_data=host(buf.x_data), trues=trues, preds=predictions, loss=test_loss,
                                    accuracy=accuracy)
         if buf.p:
-            res.p, res.d = torch.cat(buf.p), torch.cat(buf.d)
-            res.shapelet_preds = torch.cat(buf.shapelet_preds)
+            res.p, res.d = host(buf.p), host(buf.d)
+            res.shapelet_preds = host(buf.shapelet_preds)
             sbm = self.model.sbm if a.model == 'InterpGN' else self.model
             res.w = sbm.output_layer.weight.detach().cpu()
             res.shapelets = sbm.get_shapelets()
+            if buf.t and hasattr(sbm, 'match_layout'):
+                # where each shapelet matched each series: the forward kernel's arg-max window, as sample ranges
+                stride, length = sbm.match_layout()
+                res.t = host(buf.t)
+                res.match_start, res.match_len = res.t * stride.unsqueeze(0), length
             if a.model == 'InterpGN':
-                res.eta = torch.cat(buf.eta)
-                res.dnn_preds = torch.cat(buf.dnn_preds)
+                res.eta = host(buf.eta)
+                res.dnn_preds = host(buf.dnn_preds)
         test_df = None
         if save_csv and result_dir is not None and self.rank == 0:
             test_df = self._write_summary(res, result_dir)

@@ -62,9 +62,12 @@ def standardise_nct_to_btc(x_nct, eps=1e-8):
 class ShapeletBankFn(torch.autograd.Function):
     """All length groups of a shapelet bank in one autograd node.
 
-    forward(xn, eps, mode, stride_list, n_groups, w_0..w_{G-1}[, thr_0..thr_{G-1}]) -> (P, Dmin), both (B, sum_g K_g*C)
-    with the reference's feature order g*K*C + k*C + c (IGN/model/Shapelet.py:84,195-196).
+    forward(xn, eps, mode, stride_list, n_groups, w_0..w_{G-1}[, thr_0..thr_{G-1}]) -> (P, Dmin, Tstar), all
+    (B, sum_g K_g*C) with the reference's feature order g*K*C + k*C + c (IGN/model/Shapelet.py:84,195-196).
     Dmin is non-differentiable (the training loss never reads it: IGN/exp/experiment_classification.py:325-329).
+    Tstar (int32) is the WINDOW INDEX of the best match -- arg-max_t p for the RBF gate, arg-min_t d for LTS, first index on
+    ties; the match covers samples [Tstar*stride, Tstar*stride + L) -- which is what the reference's shapelet plots need
+    (IGN/utils/shapelet_util.py:153 recomputes it on the host by sliding every shapelet over every series).
     """
 
     @staticmethod
@@ -96,13 +99,14 @@ class ShapeletBankFn(torch.autograd.Function):
                                           float(eps), int(mode), _stream()), "ign_shapelet_fwd")
             saved.append((tstar, zmu, dsave, col0, stride, xstat))
             col0 += K * C
-        ctx.mark_non_differentiable(D)
+        Tstar = torch.cat([sv[0].reshape(B, -1) for sv in saved], dim=1) if len(saved) > 1 else saved[0][0].reshape(B, -1)
+        ctx.mark_non_differentiable(D, Tstar)
         ctx.meta = (float(eps), int(mode), n_groups, saved, need_grad)
         ctx.save_for_backward(xn, P, D, *ws, *[t for t in thrs if t is not None])
-        return P, D
+        return P, D, Tstar
 
     @staticmethod
-    def backward(ctx, gP, gD):
+    def backward(ctx, gP, gD, gT):
         eps, mode, G, saved, had_grad = ctx.meta
         if not had_grad:
             raise _lib.IgnError("shapelet backward called but the forward ran without saving distances")
@@ -133,7 +137,8 @@ class ShapeletBankFn(torch.autograd.Function):
         return (None, None, None, None, None, *grads_w, *grads_t)
 
 
-def shapelet_bank(xn, weights, eps, mode=DIST_L1 | GATE_RBF, strides=None, thresholds=None):
+def shapelet_bank(xn, weights, eps, mode=DIST_L1 | GATE_RBF, strides=None, thresholds=None, return_tstar=False):
+    """-> (P, Dmin) or, with return_tstar, (P, Dmin, Tstar): see ShapeletBankFn."""
     G = len(weights)
     if (mode & 0xf) == DIST_PEARSON:
         # pearson_corrcoef centres both operands (Shapelet.py:11-19).  <x - mean x, w_c> == <x, w_c> for a centred w_c,
@@ -141,7 +146,8 @@ def shapelet_bank(xn, weights, eps, mode=DIST_L1 | GATE_RBF, strides=None, thres
         weights = [w - w.mean(dim=-1, keepdim=True) for w in weights]
     strides = strides or [1] * G
     params = list(weights) + (list(thresholds) if (mode & GATE_LTS) else [])
-    return ShapeletBankFn.apply(xn, eps, mode, tuple(strides), G, *params)
+    P, D, Tstar = ShapeletBankFn.apply(xn, eps, mode, tuple(strides), G, *params)
+    return (P, D, Tstar) if return_tstar else (P, D)
 
 
 def _bl_strides(t, name):

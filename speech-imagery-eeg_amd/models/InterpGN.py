@@ -83,7 +83,7 @@ class InterpGN(nn.Module):
         # the SBM expert has just evaluated the regularisers on the same weights (IGN/model/Shapelet.py:206-210); the
         # reference recomputes them here (InterpGN.py:54-60) -- same value, same gradient, a dozen kernel launches less
         return out, ModelInfo(d=info.d, p=info.p, eta=eta, shapelet_preds=sbm_out, dnn_preds=deep_out,
-                              preds=out, loss=info.loss)
+                              preds=out, loss=info.loss, t=info.t)
 
     def loss(self):
         return self.sbm.loss()

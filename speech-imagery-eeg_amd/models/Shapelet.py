@@ -135,7 +135,7 @@ class ShapeBottleneckModel(nn.Module):
         first = self.shapelets[0]
         thr = [s.threshold for s in self.shapelets] if first.gate == ops.GATE_LTS else None
         return ops.shapelet_bank(xn, [s.weights for s in self.shapelets], first.eps, first.mode(),
-                                 [s.stride for s in self.shapelets], thr)
+                                 [s.stride for s in self.shapelets], thr, return_tstar=True)
 
     def head(self, p):
         cls = self.configs.sbm_cls
@@ -146,9 +146,15 @@ class ShapeBottleneckModel(nn.Module):
         return self.output_layer(self.dropout(self.attention(p)))
 
     def forward(self, x, *args, xn=None, **kwargs):
-        p, d = self.shapelet_features(x, xn)
+        p, d, t = self.shapelet_features(x, xn)
         out = self.head(p)
-        return out, ModelInfo(d=d, p=p, shapelet_preds=out, preds=out, loss=self.loss().unsqueeze(0))
+        return out, ModelInfo(d=d, p=p, shapelet_preds=out, preds=out, loss=self.loss().unsqueeze(0), t=t)
+
+    def match_layout(self):
+        """per feature column (g*K*C + k*C + c): (window stride, shapelet length) -- turns ModelInfo.t into sample ranges"""
+        stride = torch.cat([torch.full((s.n * self.num_channel,), s.stride, dtype=torch.int32) for s in self.shapelets])
+        length = torch.cat([torch.full((s.n * self.num_channel,), s.length, dtype=torch.int32) for s in self.shapelets])
+        return stride, length
 
     # -- regularisers / utilities -----------------------------------------------------------------
     def step(self):

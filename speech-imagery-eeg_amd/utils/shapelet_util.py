@@ -19,6 +19,8 @@ class ModelInfo:
     dnn_preds: Optional[torch.Tensor] = None        # (B, N) deep expert logits
     preds: Optional[torch.Tensor] = None            # (B, N) mixture logits
     loss: Optional[torch.Tensor] = None             # (1,) model regulariser
+    # extension (appended, default None: code written against the reference's seven fields is unaffected):
+    t: Optional[torch.Tensor] = None                # (B, G*K*C) int32 window index of each shapelet's best match
 
 
 @dataclass
@@ -35,3 +37,9 @@ class ClassificationResult:
     eta: Optional[torch.Tensor] = None
     loss: Optional[float] = None
     accuracy: Optional[float] = None
+    # extension: where each shapelet matched each test series -- window index per (sample, shapelet) in p's column order,
+    # and the (start, length) in samples it corresponds to.  The reference's visualize_shapelets re-derives this on the host
+    # (IGN/utils/shapelet_util.py:153); the forward kernel already has it.
+    t: Optional[torch.Tensor] = None
+    match_start: Optional[torch.Tensor] = None      # (n, G*K*C) first sample of the best-matching window
+    match_len: Optional[torch.Tensor] = None        # (G*K*C,)   shapelet length per column

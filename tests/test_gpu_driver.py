@@ -84,6 +84,10 @@ def test_harness_hip_vs_oracle(tmp_path, monkeypatch, capsys, model):
     assert abs(lg - lr) < 5e-3 * max(1.0, abs(lr)), (lg, lr)
     loss, res, _ = e.test(result_dir=str(tmp_path / "result"))
     assert res.preds.shape == (24,) and np.isfinite(loss)
+    # interpretability outputs: where each shapelet matched (window index -> sample range inside the series)
+    assert res.t.shape == res.p.shape and res.t.dtype == torch.int32
+    assert res.match_start.shape == res.p.shape and res.match_len.shape == (res.p.shape[1],)
+    assert int((res.match_start + res.match_len.unsqueeze(0)).max()) <= 100 and int(res.match_start.min()) >= 0
     assert os.path.exists(os.path.join(tmp_path, e.checkpoint_dir, "checkpoint.pth"))
 
 

@@ -227,6 +227,36 @@ def test_sbm_trains_at_seq_len_3100():
         _grad_close(p.grad, q.grad.numpy(), n)
 
 
+@pytest.mark.parametrize("B,C,T,K,L,stride,lts", [(3, 6, 100, 5, 20, 1, False), (2, 4, 1300, 3, 10, 1, False),
+                                                   (2, 3, 3100, 3, 310, 8, False), (3, 5, 120, 4, 30, 1, True)])
+def test_match_location_is_the_argmax_window(B, C, T, K, L, stride, lts):
+    """Tstar (ModelInfo.t): the window index the straight-through max selects -- arg-max_t p (first index on ties, like
+    torch.argmax: IGN/model/Shapelet.py:79) for the RBF gate, arg-min_t d for LTS (:101) -- bit-exact against the oracle's
+    distances; its sample range is what IGN/utils/shapelet_util.py:153 plots."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    from oracle import ign_oracle as O
+    g = torch.Generator().manual_seed(B + T + L)
+    xn = torch.randn(B, C, T, generator=g)
+    w = torch.randn(K, C, L, generator=g)
+    thr = torch.rand(1, K, C, generator=g)
+    d = O.window_distance(xn, w, stride, 0, chunk=16)                       # (B, Tw, K, C)
+    want = (d.argmin(dim=1) if lts else torch.exp(-d.pow(2)).argmax(dim=1)).reshape(B, K * C)
+    mode = ops.DIST_L1 | (ops.GATE_LTS if lts else 0)
+    with torch.no_grad():
+        p, dmin, t = ops.shapelet_bank(xn.to(dev), [w.to(dev)], 1.0, mode, strides=[stride],
+                                       thresholds=[thr.to(dev)] if lts else None, return_tstar=True)
+    assert t.dtype == torch.int32 and t.shape == p.shape
+    t = t.cpu().long()
+    # a window whose distance ties the optimum to the last bit may be picked instead: compare through the distances
+    picked = d.reshape(B, -1, K * C).gather(1, t.unsqueeze(1)).squeeze(1)
+    best = d.reshape(B, -1, K * C).gather(1, want.unsqueeze(1)).squeeze(1)
+    assert float((picked - best).abs().max()) <= 1e-6
+    assert float((t != want).float().mean()) <= 0.01
+    assert int(t.max()) * stride + L <= T
+
+
 def test_full_size_properties():
     """B=256, C=122, T=1000 (BASELINE config 1): size-independent checks the oracle cannot reach in seconds."""
     dev = _dev()
