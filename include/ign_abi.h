@@ -223,6 +223,31 @@ size_t ign_dwconv1d_bwd_weight_workspace_bytes(int B, int C, int k);
 int ign_dwconv1d_bwd_weight(const float* x, const float* dy, float* dw, void* workspace, int B, int C, int T, int k,
                             int pad_left, void* stream);
 
+/* EEG-CNN block, the ops around the depthwise temporal convolutions (IGN/model/eegcnn.py:67-108), (B, channels, T) layout.
+ * Channel contraction u[b,o,t] = sum_c W[o,c] x[b,c,t]: the depthwise SPATIAL conv (eegcnn.py:71,92; Conv2d(F1, D*F1, (C,1),
+ * groups=F1) applied after the temporal conv commutes with it, see csrc/ign_eegcnn.hip) and the POINTWISE conv (:79,100).
+ *   wt_ci64: W^T zero-padded to (Ci, 64) floats (Co <= 64, Ci <= 128).  The input gradient is the same call with W in place of
+ *   W^T; bwd_weight: dW[o,c] = sum_{b,t} du[b,o,t] x[b,c,t] (workspace: ign_chan_contract_bwd_weight_workspace_bytes()).     */
+int ign_chan_contract_fwd(const float* x_bct, const float* wt_ci64, float* u_bot, int B, int Ci, int Co, int T, void* stream);
+size_t ign_chan_contract_bwd_weight_workspace_bytes(int B, int Ci, int Co, int T);
+int ign_chan_contract_bwd_weight(const float* du_bot, const float* x_bct, float* dw_oc, void* workspace, int B, int Ci, int Co,
+                                 int T, void* stream);
+
+/* BatchNorm2d with batch statistics + ELU + AvgPool2d((1,P)) as one op (eegcnn.py:72-74,93-95 / :80-82,101-103).
+ *   ign_chan_stats: sums_c2 (C,2) DOUBLES = per-channel sum v, sum v^2 over (b,t)  (workspace: ign_chan_stats_workspace_bytes()).
+ *   ign_affine_elu_pool_fwd: out[b,c,tp] = mean_{i<P} ELU(scale[c] v[b,c,tp P+i] + shift[c]); the caller folds BatchNorm (and the
+ *     affine map in front of it) into scale / shift; Tp = T / P.
+ *   backward: ign_bn_elu_pool_bwd_sums -> (C,2) doubles S1 = sum dz, S2 = sum dz (v - mean[c]) with dz = ELU'(.) dout / P;
+ *     ign_bn_elu_pool_bwd_apply: dv = ka[c] dz + kb[c] + kc[c] v (the BatchNorm backward as three per-channel coefficients).  */
+size_t ign_chan_stats_workspace_bytes(int B, int C);
+int ign_chan_stats(const float* v_bct, double* sums_c2, void* workspace, int B, int C, int T, void* stream);
+int ign_affine_elu_pool_fwd(const float* v_bct, const float* scale_c, const float* shift_c, float* out, int B, int C, int T, int P,
+                            void* stream);
+int ign_bn_elu_pool_bwd_sums(const float* v_bct, const float* dout, const float* scale_c, const float* shift_c, const float* mean_c,
+                             double* sums_c2, void* workspace, int B, int C, int T, int P, void* stream);
+int ign_bn_elu_pool_bwd_apply(const float* v_bct, const float* dout, const float* scale_c, const float* shift_c, const float* ka_c,
+                              const float* kb_c, const float* kc_c, float* dv_bct, int B, int C, int T, int P, void* stream);
+
 /* ---- FCN expert: channels-last 1-D convolution as an implicit GEMM on the fp32 matrix cores, BatchNorm + ReLU
  * folded into the GEMM prologues / epilogues (csrc/ign_clconv_{f32,x6}.hip, ign_bn.hip).  Replaces IGN/model/FullyConvNet.py:31-59
  * (3 x [Conv1d -> BatchNorm1d -> ReLU] -> AdaptiveAvgPool1d) and its autograd.  Activations are (B, T, C) row-major

@@ -51,6 +51,14 @@ SIGNATURES = {
     "ign_dwconv1d_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "ign_dwconv1d_bwd_weight_workspace_bytes": (sz, [ci, ci, ci]),
     "ign_dwconv1d_bwd_weight": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ign_chan_contract_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
+    "ign_chan_contract_bwd_weight_workspace_bytes": (sz, [ci, ci, ci, ci]),
+    "ign_chan_contract_bwd_weight": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "ign_chan_stats_workspace_bytes": (sz, [ci, ci]),
+    "ign_chan_stats": (ci, [vp, vp, vp, ci, ci, ci, vp]),
+    "ign_affine_elu_pool_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "ign_bn_elu_pool_bwd_sums": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "ign_bn_elu_pool_bwd_apply": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "ign_clconv_mtiles": (ll, [ll]),
     "ign_clconv_pack_weights": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "ign_clconv_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),

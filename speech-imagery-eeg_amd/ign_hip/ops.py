@@ -660,6 +660,183 @@ def dwconv1d(x, w, pad_left):
     return DwConv1dFn.apply(x, w, pad_left)
 
 
+class ChanContractFn(torch.autograd.Function):
+    """u[b,o,t] = sum_c W[o,c] x[b,c,t]  (ign_chan_contract_*): the EEG-CNN's electrode contraction and pointwise convolution
+    (IGN/model/eegcnn.py:71,79) on (B, channels, T) tensors.  Co <= 64, Ci <= 128."""
+
+    @staticmethod
+    def _pad64(w_t):                       # (Ci, Co) -> (Ci, 64), zero columns
+        return w_t.contiguous() if w_t.shape[1] == 64 else torch.nn.functional.pad(w_t, (0, 64 - w_t.shape[1])).contiguous()
+
+    @staticmethod
+    def _run(x, w_oc):
+        B, Ci, T = x.shape
+        Co = w_oc.shape[0]
+        u = torch.empty(B, Co, T, device=x.device, dtype=torch.float32)
+        wt = ChanContractFn._pad64(w_oc.t())
+        _lib.check(_lib.lib().ign_chan_contract_fwd(_ptr(x), _ptr(wt), _ptr(u), B, Ci, Co, T, _stream()), "ign_chan_contract_fwd")
+        return u
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _need_gpu("chan_contract", x, w)
+        if w.shape[0] > 64 or w.shape[1] > 128 or w.shape[1] != x.shape[1]:
+            raise _lib.IgnError(f"chan_contract: W {tuple(w.shape)} on x {tuple(x.shape)} (Co <= 64, Ci <= 128)")
+        x, w = x.contiguous(), w.contiguous()
+        ctx.save_for_backward(x, w)
+        return ChanContractFn._run(x, w)
+
+    @staticmethod
+    def backward(ctx, gu):
+        x, w = ctx.saved_tensors
+        gu = gu.contiguous()
+        B, Ci, T = x.shape
+        Co = w.shape[0]
+        L = _lib.lib()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            if Ci > 64:
+                raise _lib.IgnError("chan_contract: input gradient needs Ci <= 64 (the electrode axis is data and takes none)")
+            gx = ChanContractFn._run(gu, w.t().contiguous())
+        if ctx.needs_input_grad[1]:
+            ws = torch.empty(L.ign_chan_contract_bwd_weight_workspace_bytes(B, Ci, Co, T) // 4, device=x.device, dtype=torch.float32)
+            gw = torch.empty_like(w)
+            _lib.check(L.ign_chan_contract_bwd_weight(_ptr(gu), _ptr(x), _ptr(gw), _ptr(ws), B, Ci, Co, T, _stream()),
+                       "ign_chan_contract_bwd_weight")
+        return gx, gw
+
+
+def chan_contract(x_bct, w_oc):
+    return ChanContractFn.apply(x_bct, w_oc)
+
+
+class BnEluPoolFn(torch.autograd.Function):
+    """AvgPool_P(ELU(BatchNorm_train(alpha * v + c))) for v (B, C, T) -- BatchNorm2d + ELU + AvgPool2d((1,P)) of the EEG-CNN
+    block (IGN/model/eegcnn.py:72-74,80-82) as one op over the hand-written kernels, with the per-channel affine map in FRONT
+    of the BatchNorm (block 1: BatchNorm-1 folded behind the electrode contraction) absorbed analytically:
+
+        y = alpha v + c;  var_y = alpha^2 var_v;  r = rsqrt(var_y + eps);  z = gamma alpha r (v - mean_v) + beta
+        (c cancels in the normalisation: its gradient is exactly 0 -- returned as None; it only enters the running mean)
+
+    backward (dz = ELU'(z) dout / P;  S1 = sum dz,  S2 = sum dz (v - mean_v);  n = B T):
+        dgamma = alpha r S2,  dbeta = S1,  dv = gamma alpha r (dz - S1/n - alpha^2 r^2 (v - mean_v) S2 / n),
+        dalpha = gamma r^3 eps S2          (the only path: BatchNorm is scale-invariant up to eps)
+    Returns (out, mean_y, var_y_biased): the statistics are detached extras for the running-average update."""
+
+    @staticmethod
+    def forward(ctx, v, alpha, cshift, gamma, beta, P, eps):
+        _need_gpu("bn_elu_pool", v, gamma, beta)
+        v = v.contiguous()
+        B, C, T = v.shape
+        n = B * T
+        L = _lib.lib()
+        sums = torch.empty(C, 2, device=v.device, dtype=torch.float64)
+        ws = torch.empty(L.ign_chan_stats_workspace_bytes(B, C) // 8, device=v.device, dtype=torch.float64)
+        _lib.check(L.ign_chan_stats(_ptr(v), _ptr(sums), _ptr(ws), B, C, T, _stream()), "ign_chan_stats")
+        mean_v = sums[:, 0] / n
+        var_v = (sums[:, 1] / n - mean_v * mean_v).clamp_min(0.0)
+        a64 = alpha.double() if alpha is not None else torch.ones_like(mean_v)
+        r = torch.rsqrt(a64 * a64 * var_v + eps)
+        scale = (gamma.double() * a64 * r)
+        shift = beta.double() - scale * mean_v
+        scale32, shift32 = scale.float().contiguous(), shift.float().contiguous()
+        out = torch.empty(B, C, T // P, device=v.device, dtype=torch.float32)
+        _lib.check(L.ign_affine_elu_pool_fwd(_ptr(v), _ptr(scale32), _ptr(shift32), _ptr(out), B, C, T, int(P), _stream()),
+                   "ign_affine_elu_pool_fwd")
+        ctx.save_for_backward(v, scale32, shift32, mean_v, r, a64, gamma)
+        ctx.P, ctx.eps, ctx.has_alpha = int(P), float(eps), alpha is not None
+        mean_y = a64 * mean_v + (cshift.double() if cshift is not None else 0.0)
+        var_y = a64 * a64 * var_v
+        ctx.mark_non_differentiable(mean_y, var_y)
+        return out, mean_y, var_y
+
+    @staticmethod
+    def backward(ctx, gout, _gm, _gv):
+        v, scale32, shift32, mean_v, r, a64, gamma = ctx.saved_tensors
+        gout = gout.contiguous()
+        B, C, T = v.shape
+        n = B * T
+        L = _lib.lib()
+        mean32 = mean_v.float().contiguous()
+        sums = torch.empty(C, 2, device=v.device, dtype=torch.float64)
+        ws = torch.empty(L.ign_chan_stats_workspace_bytes(B, C) // 8, device=v.device, dtype=torch.float64)
+        _lib.check(L.ign_bn_elu_pool_bwd_sums(_ptr(v), _ptr(gout), _ptr(scale32), _ptr(shift32), _ptr(mean32), _ptr(sums), _ptr(ws),
+                                              B, C, T, ctx.P, _stream()), "ign_bn_elu_pool_bwd_sums")
+        S1, S2 = sums[:, 0], sums[:, 1]
+        g64 = gamma.double()
+        k0 = g64 * a64 * r                                    # dz coefficient (= scale)
+        kc = -k0 * a64 * a64 * r * r * S2 / n                 # coefficient of (v - mean_v)
+        kb = -k0 * S1 / n - kc * mean_v
+        ka32, kb32, kc32 = k0.float().contiguous(), kb.float().contiguous(), kc.float().contiguous()
+        dv = None
+        if ctx.needs_input_grad[0]:
+            dv = torch.empty_like(v)
+            _lib.check(L.ign_bn_elu_pool_bwd_apply(_ptr(v), _ptr(gout), _ptr(scale32), _ptr(shift32), _ptr(ka32), _ptr(kb32), _ptr(kc32),
+                                                   _ptr(dv), B, C, T, ctx.P, _stream()), "ign_bn_elu_pool_bwd_apply")
+        dgamma = (a64 * r * S2).float()
+        dbeta = S1.float()
+        dalpha = (g64 * r * r * r * ctx.eps * S2).float() if ctx.has_alpha else None
+        return dv, dalpha, None, dgamma, dbeta, None, None
+
+
+def bn_elu_pool(v, bn, P, alpha=None, cshift=None):
+    """BatchNorm2d module `bn` (its weight / bias / running statistics / momentum / eps) + ELU + AvgPool((1,P)) on v (B,C,T);
+    `alpha`, `cshift`: per-channel affine map y = alpha v + cshift applied in front of the BatchNorm (see BnEluPoolFn).
+    Training mode uses batch statistics and updates the running ones like nn.BatchNorm2d; eval mode uses the running ones."""
+    _need_gpu("bn_elu_pool", v)
+    if bn.training or not bn.track_running_stats:
+        out, mean_y, var_y = BnEluPoolFn.apply(v, alpha, cshift, bn.weight, bn.bias, P, bn.eps)
+        if bn.training and bn.track_running_stats:
+            with torch.no_grad():
+                n = v.shape[0] * v.shape[2]
+                bn.num_batches_tracked.add_(1)
+                m = bn.momentum
+                bn.running_mean.mul_(1 - m).add_(mean_y.float(), alpha=m)
+                bn.running_var.mul_(1 - m).add_((var_y * (n / max(n - 1, 1))).float(), alpha=m)
+        return out
+    # eval: z = gamma (alpha v + c - running_mean) / sqrt(running_var + eps) + beta -- an affine map, then the apply kernel
+    r = torch.rsqrt(bn.running_var + bn.eps)
+    a = alpha if alpha is not None else torch.ones_like(r)
+    c = cshift if cshift is not None else torch.zeros_like(r)
+    scale = (bn.weight * a * r).contiguous()
+    shift = (bn.weight * (c - bn.running_mean) * r + bn.bias).contiguous()
+    return AffineEluPoolFn.apply(v, scale, shift, P)
+
+
+class AffineEluPoolFn(torch.autograd.Function):
+    """AvgPool_P(ELU(scale[c] v + shift[c])) with gradients to v, scale and shift (the eval-mode form of bn_elu_pool)."""
+
+    @staticmethod
+    def forward(ctx, v, scale, shift, P):
+        _need_gpu("affine_elu_pool", v, scale, shift)
+        v, scale, shift = v.contiguous(), scale.contiguous(), shift.contiguous()
+        B, C, T = v.shape
+        out = torch.empty(B, C, T // P, device=v.device, dtype=torch.float32)
+        _lib.check(_lib.lib().ign_affine_elu_pool_fwd(_ptr(v), _ptr(scale), _ptr(shift), _ptr(out), B, C, T, int(P), _stream()),
+                   "ign_affine_elu_pool_fwd")
+        ctx.save_for_backward(v, scale, shift)
+        ctx.P = int(P)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        v, scale, shift = ctx.saved_tensors
+        gout = gout.contiguous()
+        B, C, T = v.shape
+        L = _lib.lib()
+        zero = torch.zeros_like(scale)
+        sums = torch.empty(C, 2, device=v.device, dtype=torch.float64)
+        ws = torch.empty(L.ign_chan_stats_workspace_bytes(B, C) // 8, device=v.device, dtype=torch.float64)
+        _lib.check(L.ign_bn_elu_pool_bwd_sums(_ptr(v), _ptr(gout), _ptr(scale), _ptr(shift), _ptr(zero), _ptr(sums), _ptr(ws),
+                                              B, C, T, ctx.P, _stream()), "ign_bn_elu_pool_bwd_sums")
+        dv = None
+        if ctx.needs_input_grad[0]:
+            dv = torch.empty_like(v)
+            _lib.check(L.ign_bn_elu_pool_bwd_apply(_ptr(v), _ptr(gout), _ptr(scale), _ptr(shift), _ptr(scale), _ptr(zero), _ptr(zero),
+                                                   _ptr(dv), B, C, T, ctx.P, _stream()), "ign_bn_elu_pool_bwd_apply")
+        return dv, sums[:, 1].float(), sums[:, 0].float(), None
+
+
 class DiversityFn(torch.autograd.Function):
     """mean_{c,i,j} exp(-||w_i - w_j + 1e-6||) (1 - delta_ij) of one shapelet group (IGN/model/Shapelet.py:223-230);
     the kernel produces the loss and its gradient together, backward only scales the saved gradient."""

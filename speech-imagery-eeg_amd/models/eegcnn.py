@@ -119,8 +119,9 @@ class EEGcnn(nn.Module):
     def forward(self, x):
         """(B, C, T) -> (B, F2, T / (P1*P2)).  GPU path: block 1 is evaluated as
         y2 = a_f * (w1[f] (*) (W2 x)) + b_f * rowsum(W2)  (see csrc/ign_eegcnn.hip), block 2 as a depthwise HIP convolution +
-        a 64x64 channel GEMM; BatchNorm-1's batch variance comes from ign_conv1_sumsq_* so the (B,F1,C,T) tensor of the
-        reference (eegcnn.py:90-91) is never formed."""
+        the 64x64 pointwise contraction, both BatchNorm+ELU+AvgPool stages as fused two-pass ops (csrc/ign_eegcnn_fused.hip);
+        BatchNorm-1's batch variance is a quadratic form over the input's lag sums, so the (B,F1,C,T) tensor of the reference
+        (eegcnn.py:90-91) is never formed."""
         if not x.is_cuda:
             raise ops._lib.IgnError(f"EEG-CNN: tensor on {x.device}; the product path runs on the MI355X only (no CPU fallback)")
         if torch.is_autocast_enabled():
@@ -161,15 +162,19 @@ class EEGcnn(nn.Module):
             mu1, var1 = bn1.running_mean, bn1.running_var
         a1 = bn1.weight * torch.rsqrt(var1 + bn1.eps)
         b1 = bn1.bias - a1 * mu1
-        u = torch.einsum('oc,bct->bot', w2, x)                                                 # channel contraction first
+        # Block 1 behind the electrode contraction (csrc/ign_eegcnn.hip): y2 = a_f (w1[f] (*) (W2 x)) + b_f rowsum(W2).  The
+        # affine map (a_f, b_f rowsum) goes INTO the BatchNorm-2 op (ops.bn_elu_pool absorbs it analytically), so the chain is
+        # contraction -> depthwise temporal conv -> [stats pass + apply pass: BN2, ELU, AvgPool] with no element-wise glue.
+        u = ops.chan_contract(x, w2)                                                           # (B, F1*D, T)
         v = ops.dwconv1d(u, w1.repeat_interleave(D, dim=0), pl1)
-        y2 = v * a1.repeat_interleave(D).view(1, -1, 1) + (b1.repeat_interleave(D) * w2.sum(dim=1)).view(1, -1, 1)
-        h = F.avg_pool1d(F.elu(self._bn_apply(self.block1_bn2, y2)), self.block1_pool.kernel_size[1])
+        h = ops.bn_elu_pool(v, self.block1_bn2, self.block1_pool.kernel_size[1], alpha=a1.repeat_interleave(D),
+                            cshift=b1.repeat_interleave(D) * w2.sum(dim=1))
         h = self.block1_drop(h)
+        # Block 2: depthwise temporal conv -> pointwise 64 -> 64 (the same contraction kernel) -> [BN3, ELU, AvgPool]
         w3 = self.block2_conv1.weight.reshape(self.block2_conv1.weight.shape[0], -1)           # (F1*D, k2)
-        g = ops.dwconv1d(h, w3, (w3.shape[1] - 1) // 2)
-        g = torch.einsum('oi,bit->bot', self.block2_conv2.weight.reshape(self.block2_conv2.weight.shape[0], -1), g)
-        g = F.avg_pool1d(F.elu(self._bn_apply(self.block2_bn, g)), self.block2_pool.kernel_size[1])
+        q = ops.dwconv1d(h, w3, (w3.shape[1] - 1) // 2)
+        g = ops.chan_contract(q, self.block2_conv2.weight.reshape(self.block2_conv2.weight.shape[0], -1))
+        g = ops.bn_elu_pool(g, self.block2_bn, self.block2_pool.kernel_size[1])
         return self.block2_drop(g)
 
     def _forward_reference_ops(self, x):
