@@ -239,6 +239,10 @@ int ign_chan_contract_bwd_weight(const float* du_bot, const float* x_bct, float*
  *     affine map in front of it) into scale / shift; Tp = T / P.
  *   backward: ign_bn_elu_pool_bwd_sums -> (C,2) doubles S1 = sum dz, S2 = sum dz (v - mean[c]) with dz = ELU'(.) dout / P;
  *     ign_bn_elu_pool_bwd_apply: dv = ka[c] dz + kb[c] + kc[c] v (the BatchNorm backward as three per-channel coefficients).  */
+ *   ign_bn_fold_fwd / _bwd: the per-channel algebra between the two passes in one launch each -- forward: moments of v, the
+ *     affine map y = alpha v + c in front of the BatchNorm (NULL: identity), gamma, beta -> scale / shift of the apply pass,
+ *     fold_c2 (C,2) doubles {mean_v, r = rsqrt(alpha^2 var_v + eps)} kept for the backward, and the nn.BatchNorm running-statistics
+ *     update (momentum, unbiased variance; NULL pointers: skipped); backward: (S1, S2) -> ka / kb / kc and dgamma, dbeta, dalpha. */
 size_t ign_chan_stats_workspace_bytes(int B, int C);
 int ign_chan_stats(const float* v_bct, double* sums_c2, void* workspace, int B, int C, int T, void* stream);
 int ign_affine_elu_pool_fwd(const float* v_bct, const float* scale_c, const float* shift_c, float* out, int B, int C, int T, int P,
@@ -247,6 +251,11 @@ int ign_bn_elu_pool_bwd_sums(const float* v_bct, const float* dout, const float*
                              double* sums_c2, void* workspace, int B, int C, int T, int P, void* stream);
 int ign_bn_elu_pool_bwd_apply(const float* v_bct, const float* dout, const float* scale_c, const float* shift_c, const float* ka_c,
                               const float* kb_c, const float* kc_c, float* dv_bct, int B, int C, int T, int P, void* stream);
+int ign_bn_fold_fwd(const double* sums_c2, const float* alpha_c, const float* cshift_c, const float* gamma_c, const float* beta_c,
+                    float* scale_c, float* shift_c, double* fold_c2, float* running_mean, float* running_var, int C, long long n,
+                    float eps, float momentum, void* stream);
+int ign_bn_fold_bwd(const double* sums_c2, const double* fold_c2, const float* alpha_c, const float* gamma_c, float* ka_c, float* kb_c,
+                    float* kc_c, float* dgamma_c, float* dbeta_c, float* dalpha_c, int C, long long n, float eps, void* stream);
 
 /* ---- FCN expert: channels-last 1-D convolution as an implicit GEMM on the fp32 matrix cores, BatchNorm + ReLU
  * folded into the GEMM prologues / epilogues (csrc/ign_clconv_{f32,x6}.hip, ign_bn.hip).  Replaces IGN/model/FullyConvNet.py:31-59

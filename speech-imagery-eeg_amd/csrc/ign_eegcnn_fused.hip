@@ -203,6 +203,53 @@ __global__ void __launch_bounds__(256) bn_elu_pool_bwd_apply_kernel(const float*
     dv[(size_t)r * T + tt] = fmaf(ka[c], dz, fmaf(kc[c], a, kb[c]));
 }
 
+// The per-channel algebra between the passes, as ONE tiny launch each way instead of ~25 float64 torch element-wise kernels:
+// forward: moments -> (scale, shift) of the apply pass, the saved (mean_v, r) and the running-statistics update;
+// backward: (S1, S2) -> the three coefficients of the apply pass and the parameter gradients.   y = alpha v + c.
+__global__ void bn_fold_fwd_kernel(const double* __restrict__ sums, const float* __restrict__ alpha, const float* __restrict__ cshift,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale,
+                                   float* __restrict__ shift, double* __restrict__ fold /* (C,2): mean_v, r */,
+                                   float* __restrict__ run_mean, float* __restrict__ run_var, int C, double n, double eps,
+                                   double momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[2 * c] / n;
+    double var = sums[2 * c + 1] / n - m * m;
+    var = var > 0.0 ? var : 0.0;
+    const double a = alpha ? (double)alpha[c] : 1.0;
+    const double r = 1.0 / sqrt(a * a * var + eps);
+    const double sc = (double)gamma[c] * a * r;
+    scale[c] = (float)sc;
+    shift[c] = (float)((double)beta[c] - sc * m);
+    fold[2 * c] = m;
+    fold[2 * c + 1] = r;
+    if (run_mean) {
+        const double mean_y = a * m + (cshift ? (double)cshift[c] : 0.0);
+        const double var_y = a * a * var * (n > 1.0 ? n / (n - 1.0) : 1.0);           // running_var holds the unbiased estimate
+        run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + momentum * mean_y);
+        run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + momentum * var_y);
+    }
+}
+
+__global__ void bn_fold_bwd_kernel(const double* __restrict__ sums /* (C,2): S1, S2 */, const double* __restrict__ fold,
+                                   const float* __restrict__ alpha, const float* __restrict__ gamma, float* __restrict__ ka,
+                                   float* __restrict__ kb, float* __restrict__ kc, float* __restrict__ dgamma,
+                                   float* __restrict__ dbeta, float* __restrict__ dalpha, int C, double n, double eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double S1 = sums[2 * c], S2 = sums[2 * c + 1];
+    const double m = fold[2 * c], r = fold[2 * c + 1];
+    const double a = alpha ? (double)alpha[c] : 1.0, g = (double)gamma[c];
+    const double k0 = g * a * r;
+    const double kcc = -k0 * a * a * r * r * S2 / n;
+    ka[c] = (float)k0;
+    kc[c] = (float)kcc;
+    kb[c] = (float)(-k0 * S1 / n - kcc * m);
+    dgamma[c] = (float)(a * r * S2);
+    dbeta[c] = (float)S1;
+    if (dalpha) dalpha[c] = (float)(g * r * r * r * eps * S2);
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 static int cc_check(const char* who, const void* a, const void* b, const void* c, int B, int Ci, int Co, int T) {
     if (!a || !b || !c || B <= 0 || Ci <= 0 || Co <= 0 || T <= 0) {
@@ -328,4 +375,29 @@ extern "C" int ign_bn_elu_pool_bwd_apply(const float* v_bct, const float* dout, 
     hipLaunchKernelGGL(bn_elu_pool_bwd_apply_kernel, dim3((unsigned)(B * Cc), (unsigned)((T + 255) / 256)), dim3(256), 0, s, v_bct, dout,
                        scale_c, shift_c, ka_c, kb_c, kc_c, dv_bct, Cc, T, P, T / P);
     return ign_check_launch("bn_elu_pool_bwd_apply_kernel");
+}
+
+extern "C" int ign_bn_fold_fwd(const double* sums_c2, const float* alpha_c, const float* cshift_c, const float* gamma_c,
+                               const float* beta_c, float* scale_c, float* shift_c, double* fold_c2, float* running_mean,
+                               float* running_var, int C, long long n, float eps, float momentum, void* stream) {
+    if (!sums_c2 || !gamma_c || !beta_c || !scale_c || !shift_c || !fold_c2 || C <= 0 || n <= 0 || (!running_mean) != (!running_var)) {
+        ign_set_error("ign_bn_fold_fwd: null pointer or bad dimension (C=%d n=%lld)", C, n);
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sums_c2, alpha_c, cshift_c,
+                       gamma_c, beta_c, scale_c, shift_c, fold_c2, running_mean, running_var, C, (double)n, (double)eps, (double)momentum);
+    return ign_check_launch("bn_fold_fwd_kernel");
+}
+
+extern "C" int ign_bn_fold_bwd(const double* sums_c2, const double* fold_c2, const float* alpha_c, const float* gamma_c, float* ka_c,
+                               float* kb_c, float* kc_c, float* dgamma_c, float* dbeta_c, float* dalpha_c, int C, long long n, float eps,
+                               void* stream) {
+    if (!sums_c2 || !fold_c2 || !gamma_c || !ka_c || !kb_c || !kc_c || !dgamma_c || !dbeta_c || C <= 0 || n <= 0 ||
+        (!alpha_c) != (!dalpha_c)) {
+        ign_set_error("ign_bn_fold_bwd: null pointer or bad dimension (C=%d n=%lld)", C, n);
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sums_c2, fold_c2, alpha_c,
+                       gamma_c, ka_c, kb_c, kc_c, dgamma_c, dbeta_c, dalpha_c, C, (double)n, (double)eps);
+    return ign_check_launch("bn_fold_bwd_kernel");
 }

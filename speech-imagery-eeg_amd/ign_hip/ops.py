@@ -721,62 +721,56 @@ class BnEluPoolFn(torch.autograd.Function):
     backward (dz = ELU'(z) dout / P;  S1 = sum dz,  S2 = sum dz (v - mean_v);  n = B T):
         dgamma = alpha r S2,  dbeta = S1,  dv = gamma alpha r (dz - S1/n - alpha^2 r^2 (v - mean_v) S2 / n),
         dalpha = gamma r^3 eps S2          (the only path: BatchNorm is scale-invariant up to eps)
-    Returns (out, mean_y, var_y_biased): the statistics are detached extras for the running-average update."""
+    The per-channel algebra runs in ign_bn_fold_fwd / _bwd (one launch each, float64), which also applies the running-statistics
+    update (momentum, unbiased variance) of nn.BatchNorm2d in place when `run_mean` / `run_var` are given."""
 
     @staticmethod
-    def forward(ctx, v, alpha, cshift, gamma, beta, P, eps):
+    def forward(ctx, v, alpha, cshift, gamma, beta, P, eps, run_mean, run_var, momentum):
         _need_gpu("bn_elu_pool", v, gamma, beta)
         v = v.contiguous()
         B, C, T = v.shape
-        n = B * T
         L = _lib.lib()
-        sums = torch.empty(C, 2, device=v.device, dtype=torch.float64)
-        ws = torch.empty(L.ign_chan_stats_workspace_bytes(B, C) // 8, device=v.device, dtype=torch.float64)
+        dev = v.device
+        f32 = lambda t: None if t is None else t.detach().float().contiguous()
+        alpha32, cshift32, gamma32, beta32 = f32(alpha), f32(cshift), f32(gamma), f32(beta)
+        sums = torch.empty(C, 2, device=dev, dtype=torch.float64)
+        ws = torch.empty(L.ign_chan_stats_workspace_bytes(B, C) // 8, device=dev, dtype=torch.float64)
         _lib.check(L.ign_chan_stats(_ptr(v), _ptr(sums), _ptr(ws), B, C, T, _stream()), "ign_chan_stats")
-        mean_v = sums[:, 0] / n
-        var_v = (sums[:, 1] / n - mean_v * mean_v).clamp_min(0.0)
-        a64 = alpha.double() if alpha is not None else torch.ones_like(mean_v)
-        r = torch.rsqrt(a64 * a64 * var_v + eps)
-        scale = (gamma.double() * a64 * r)
-        shift = beta.double() - scale * mean_v
-        scale32, shift32 = scale.float().contiguous(), shift.float().contiguous()
-        out = torch.empty(B, C, T // P, device=v.device, dtype=torch.float32)
+        scale32 = torch.empty(C, device=dev, dtype=torch.float32)
+        shift32 = torch.empty(C, device=dev, dtype=torch.float32)
+        fold = torch.empty(C, 2, device=dev, dtype=torch.float64)            # (mean_v, r)
+        _lib.check(L.ign_bn_fold_fwd(_ptr(sums), _ptr(alpha32), _ptr(cshift32), _ptr(gamma32), _ptr(beta32), _ptr(scale32),
+                                     _ptr(shift32), _ptr(fold), _ptr(run_mean), _ptr(run_var), C, B * T, float(eps),
+                                     float(momentum if momentum is not None else 0.0), _stream()), "ign_bn_fold_fwd")
+        out = torch.empty(B, C, T // P, device=dev, dtype=torch.float32)
         _lib.check(L.ign_affine_elu_pool_fwd(_ptr(v), _ptr(scale32), _ptr(shift32), _ptr(out), B, C, T, int(P), _stream()),
                    "ign_affine_elu_pool_fwd")
-        ctx.save_for_backward(v, scale32, shift32, mean_v, r, a64, gamma)
-        ctx.P, ctx.eps, ctx.has_alpha = int(P), float(eps), alpha is not None
-        mean_y = a64 * mean_v + (cshift.double() if cshift is not None else 0.0)
-        var_y = a64 * a64 * var_v
-        ctx.mark_non_differentiable(mean_y, var_y)
-        return out, mean_y, var_y
+        ctx.save_for_backward(v, scale32, shift32, fold, alpha32, gamma32)
+        ctx.P, ctx.eps = int(P), float(eps)
+        return out
 
     @staticmethod
-    def backward(ctx, gout, _gm, _gv):
-        v, scale32, shift32, mean_v, r, a64, gamma = ctx.saved_tensors
+    def backward(ctx, gout):
+        v, scale32, shift32, fold, alpha32, gamma32 = ctx.saved_tensors
         gout = gout.contiguous()
         B, C, T = v.shape
-        n = B * T
         L = _lib.lib()
-        mean32 = mean_v.float().contiguous()
-        sums = torch.empty(C, 2, device=v.device, dtype=torch.float64)
-        ws = torch.empty(L.ign_chan_stats_workspace_bytes(B, C) // 8, device=v.device, dtype=torch.float64)
+        dev = v.device
+        mean32 = fold[:, 0].float().contiguous()
+        sums = torch.empty(C, 2, device=dev, dtype=torch.float64)
+        ws = torch.empty(L.ign_chan_stats_workspace_bytes(B, C) // 8, device=dev, dtype=torch.float64)
         _lib.check(L.ign_bn_elu_pool_bwd_sums(_ptr(v), _ptr(gout), _ptr(scale32), _ptr(shift32), _ptr(mean32), _ptr(sums), _ptr(ws),
                                               B, C, T, ctx.P, _stream()), "ign_bn_elu_pool_bwd_sums")
-        S1, S2 = sums[:, 0], sums[:, 1]
-        g64 = gamma.double()
-        k0 = g64 * a64 * r                                    # dz coefficient (= scale)
-        kc = -k0 * a64 * a64 * r * r * S2 / n                 # coefficient of (v - mean_v)
-        kb = -k0 * S1 / n - kc * mean_v
-        ka32, kb32, kc32 = k0.float().contiguous(), kb.float().contiguous(), kc.float().contiguous()
+        coef = torch.empty(6, C, device=dev, dtype=torch.float32)            # ka, kb, kc, dgamma, dbeta, dalpha
+        _lib.check(L.ign_bn_fold_bwd(_ptr(sums), _ptr(fold), _ptr(alpha32), _ptr(gamma32), _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]),
+                                     _ptr(coef[3]), _ptr(coef[4]), _ptr(coef[5]) if alpha32 is not None else None, C, B * T, ctx.eps,
+                                     _stream()), "ign_bn_fold_bwd")
         dv = None
         if ctx.needs_input_grad[0]:
             dv = torch.empty_like(v)
-            _lib.check(L.ign_bn_elu_pool_bwd_apply(_ptr(v), _ptr(gout), _ptr(scale32), _ptr(shift32), _ptr(ka32), _ptr(kb32), _ptr(kc32),
-                                                   _ptr(dv), B, C, T, ctx.P, _stream()), "ign_bn_elu_pool_bwd_apply")
-        dgamma = (a64 * r * S2).float()
-        dbeta = S1.float()
-        dalpha = (g64 * r * r * r * ctx.eps * S2).float() if ctx.has_alpha else None
-        return dv, dalpha, None, dgamma, dbeta, None, None
+            _lib.check(L.ign_bn_elu_pool_bwd_apply(_ptr(v), _ptr(gout), _ptr(scale32), _ptr(shift32), _ptr(coef[0]), _ptr(coef[1]),
+                                                   _ptr(coef[2]), _ptr(dv), B, C, T, ctx.P, _stream()), "ign_bn_elu_pool_bwd_apply")
+        return dv, (coef[5] if alpha32 is not None else None), None, coef[3], coef[4], None, None, None, None, None
 
 
 def bn_elu_pool(v, bn, P, alpha=None, cshift=None):
@@ -785,15 +779,11 @@ def bn_elu_pool(v, bn, P, alpha=None, cshift=None):
     Training mode uses batch statistics and updates the running ones like nn.BatchNorm2d; eval mode uses the running ones."""
     _need_gpu("bn_elu_pool", v)
     if bn.training or not bn.track_running_stats:
-        out, mean_y, var_y = BnEluPoolFn.apply(v, alpha, cshift, bn.weight, bn.bias, P, bn.eps)
-        if bn.training and bn.track_running_stats:
-            with torch.no_grad():
-                n = v.shape[0] * v.shape[2]
-                bn.num_batches_tracked.add_(1)
-                m = bn.momentum
-                bn.running_mean.mul_(1 - m).add_(mean_y.float(), alpha=m)
-                bn.running_var.mul_(1 - m).add_((var_y * (n / max(n - 1, 1))).float(), alpha=m)
-        return out
+        track = bn.training and bn.track_running_stats
+        if track:
+            bn.num_batches_tracked.add_(1)
+        return BnEluPoolFn.apply(v, alpha, cshift, bn.weight, bn.bias, P, bn.eps, bn.running_mean if track else None,
+                                 bn.running_var if track else None, bn.momentum)
     # eval: z = gamma (alpha v + c - running_mean) / sqrt(running_var + eps) + beta -- an affine map, then the apply kernel
     r = torch.rsqrt(bn.running_var + bn.eps)
     a = alpha if alpha is not None else torch.ones_like(r)
