@@ -238,7 +238,7 @@ int ign_chan_contract_bwd_weight(const float* du_bot, const float* x_bct, float*
  *   ign_affine_elu_pool_fwd: out[b,c,tp] = mean_{i<P} ELU(scale[c] v[b,c,tp P+i] + shift[c]); the caller folds BatchNorm (and the
  *     affine map in front of it) into scale / shift; Tp = T / P.
  *   backward: ign_bn_elu_pool_bwd_sums -> (C,2) doubles S1 = sum dz, S2 = sum dz (v - mean[c]) with dz = ELU'(.) dout / P;
- *     ign_bn_elu_pool_bwd_apply: dv = ka[c] dz + kb[c] + kc[c] v (the BatchNorm backward as three per-channel coefficients).  */
+ *     ign_bn_elu_pool_bwd_apply: dv = ka[c] dz + kb[c] + kc[c] v (the BatchNorm backward as three per-channel coefficients).
  *   ign_bn_fold_fwd / _bwd: the per-channel algebra between the two passes in one launch each -- forward: moments of v, the
  *     affine map y = alpha v + c in front of the BatchNorm (NULL: identity), gamma, beta -> scale / shift of the apply pass,
  *     fold_c2 (C,2) doubles {mean_v, r = rsqrt(alpha^2 var_v + eps)} kept for the backward, and the nn.BatchNorm running-statistics
