@@ -116,11 +116,15 @@ static int check_dims(const char* who, int B, int C, int T, int K, int L, int st
 }
 
 // ------------------------------------------------------------------------------------------ forward
-extern "C" int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const float* thr_kc, float* p_out,
-                                float* dmin_out, int ld, int col0, int32_t* tstar, float* zmu, float* d_save,
-                                float* xstat_save, int B, int C, int T, int K, int L, int stride, float eps, int mode,
-                                void* stream) {
-    static const char* who = "ign_shapelet_fwd";
+struct FwdPlan {
+    ShpFwdArgs a;
+    int TT, wpb, dist;
+    size_t lds;
+};
+
+static int plan_fwd(const char* who, const float* xn_bct, const float* w_kcl, const float* thr_kc, float* p_out, float* dmin_out,
+                    int ld, int col0, int32_t* tstar, float* zmu, float* d_save, float* xstat_save, int B, int C, int T, int K,
+                    int L, int stride, float eps, int mode, FwdPlan* pl) {
     int dist, gate, rc;
     if ((rc = split_mode(mode, &dist, &gate, who))) return rc;
     if ((rc = check_dims(who, B, C, T, K, L, stride))) return rc;
@@ -140,40 +144,114 @@ extern "C" int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const f
     xs_len = (xs_len + 3) & ~3;
     int wpb = 1;      // one wave per block: waves share nothing, and the epilogue's __syncthreads() stays wave-local
     const size_t park = (npass > 1) ? (size_t)5 * 5 * 64 * 4 : 0;     // per wave: 5 stats x KT<=5 x 64 lanes
-    while (wpb > 1 && (size_t)wpb * (xs_len * 4 + park) > 64 * 1024) wpb >>= 1;
     const size_t lds = (size_t)wpb * (xs_len * 4 + park);
     if (lds > 160 * 1024) {       // the whole LDS of a gfx950 CU: rows up to T ~ 40 000 (the longest UEA set is 17 984)
         ign_set_error("%s: a row needs %zu bytes of LDS staging (T=%d L=%d stride=%d)", who, lds, T, L, stride);
         return IGN_E_TOOBIG;
     }
-    ShpFwdArgs a;
+    ShpFwdArgs& a = pl->a;
     a.xn = xn_bct; a.w = w_kcl; a.thr = thr_kc; a.p_out = p_out; a.dmin_out = dmin_out; a.tstar = tstar; a.zmu = zmu;
     a.d = d_save;
     a.xstat = (dist >= DIST_COS) ? xstat_save : nullptr;
     a.B = B; a.C = C; a.T = T; a.K = K; a.L = L; a.Tw = Tw; a.stride = stride; a.ld = ld; a.col0 = col0;
     a.npass = npass; a.xs_len = xs_len; a.gate = gate; a.eps = eps; a.invL = 1.0f / (float)L;
-    const int nbg = (B + wpb - 1) / wpb;
+    a.k0 = 0;
+    pl->TT = TT; pl->wpb = wpb; pl->dist = dist; pl->lds = lds;
+    return 0;
+}
+
+static int launch_fwd_group(const char* who, FwdPlan& pl, void* stream) {
+    ShpFwdArgs& a = pl.a;
+    const int nbg = (a.B + pl.wpb - 1) / pl.wpb;
     // shapelets in tiles of 5, then 2, then 1 (each tile shares the x registers across its shapelets)
-    int k0 = 0;
+    int k0 = 0, rc;
     static const int tiles[3] = {5, 2, 1};
     for (int ti = 0; ti < 3; ++ti) {
         const int KT = tiles[ti];
-        const int n = (K - k0) / KT;
+        const int n = (a.K - k0) / KT;
         if (n <= 0) continue;
-        shp_fwd_launch_t fn = ign_get_fwd_launcher(dist, TT, KT);
+        shp_fwd_launch_t fn = ign_get_fwd_launcher(pl.dist, pl.TT, KT);
         if (!fn) {
-            ign_set_error("%s: no kernel for TT=%d KT=%d", who, TT, KT);
+            ign_set_error("%s: no kernel for TT=%d KT=%d", who, pl.TT, KT);
             return IGN_E_UNSUP;
         }
         a.k0 = k0;
         {
             IgnScopedTimer tm("shp_fwd", (hipStream_t)stream);
-            fn(a, dim3((unsigned)C * nbg, (unsigned)n), dim3(wpb * 64), lds, (hipStream_t)stream);
+            fn(a, dim3((unsigned)a.C * nbg, (unsigned)n), dim3(pl.wpb * 64), pl.lds, (hipStream_t)stream);
         }
         if ((rc = ign_check_launch("shp_fwd_kernel"))) return rc;
         k0 += n * KT;
     }
     return 0;
+}
+
+extern "C" int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const float* thr_kc, float* p_out,
+                                float* dmin_out, int ld, int col0, int32_t* tstar, float* zmu, float* d_save,
+                                float* xstat_save, int B, int C, int T, int K, int L, int stride, float eps, int mode,
+                                void* stream) {
+    static const char* who = "ign_shapelet_fwd";
+    FwdPlan pl;
+    int rc;
+    if ((rc = plan_fwd(who, xn_bct, w_kcl, thr_kc, p_out, dmin_out, ld, col0, tstar, zmu, d_save, xstat_save, B, C, T, K, L, stride,
+                       eps, mode, &pl))) return rc;
+    return launch_fwd_group(who, pl, stream);
+}
+
+// All G length groups of a bank (IGN/model/Shapelet.py:190-196: the loop over self.shapelets) in ONE launch when every group
+// is on the headline path (L1 distance, K a multiple of 5, stride 1, one pass per row); otherwise group by group as above.
+extern "C" int ign_shapelet_fwd_bank(const float* xn_bct, int G, const float* const* w_kcl, const float* const* thr_kc, float* p_out,
+                                     float* dmin_out, int ld, const int* col0, int32_t* const* tstar, float* const* zmu,
+                                     float* const* d_save, float* const* xstat_save, int B, int C, int T, const int* K, const int* L,
+                                     const int* stride, float eps, int mode, void* stream) {
+    static const char* who = "ign_shapelet_fwd_bank";
+    if (G <= 0 || G > SHP_MAX_GROUPS || !w_kcl || !col0 || !tstar || !zmu || !K || !L || !stride) {
+        ign_set_error("%s: G=%d outside 1..%d or null table", who, G, SHP_MAX_GROUPS);
+        return IGN_E_ARG;
+    }
+    FwdPlan pl[SHP_MAX_GROUPS];
+    int rc;
+    bool one_launch = true;
+    for (int g = 0; g < G; ++g) {
+        if ((rc = plan_fwd(who, xn_bct, w_kcl[g], thr_kc ? thr_kc[g] : nullptr, p_out, dmin_out, ld, col0[g], tstar[g], zmu[g],
+                           d_save ? d_save[g] : nullptr, xstat_save ? xstat_save[g] : nullptr, B, C, T, K[g], L[g], stride[g], eps,
+                           mode, &pl[g]))) return rc;
+        one_launch = one_launch && pl[g].dist == DIST_L1 && K[g] % 5 == 0 && stride[g] == 1 && pl[g].a.npass == 1 && pl[g].wpb == 1;
+    }
+    if (!one_launch || G == 1) {
+        for (int g = 0; g < G; ++g)
+            if ((rc = launch_fwd_group(who, pl[g], stream))) return rc;
+        return 0;
+    }
+    // heaviest blocks first: work per block ~ Tw * L
+    int order[SHP_MAX_GROUPS];
+    for (int g = 0; g < G; ++g) order[g] = g;
+    std::sort(order, order + G, [&](int x, int y) {
+        return (long long)pl[x].a.Tw * pl[x].a.L > (long long)pl[y].a.Tw * pl[y].a.L;
+    });
+    ShpFwdMulti m;
+    size_t lds = 0;
+    long long nblocks = 0;
+    for (int q = 0; q < G; ++q) {
+        const FwdPlan& p = pl[order[q]];
+        m.g[q] = p.a;
+        m.tt[q] = p.TT;
+        m.gridx[q] = C * B;
+        m.start[q] = (int)nblocks;
+        nblocks += (long long)C * B * (p.a.K / 5);
+        lds = std::max(lds, p.lds);
+    }
+    m.start[G] = (int)nblocks;
+    m.ng = G;
+    if (nblocks > 2147483647LL) {
+        ign_set_error("%s: %lld blocks exceed the grid limit", who, nblocks);
+        return IGN_E_TOOBIG;
+    }
+    {
+        IgnScopedTimer tm("shp_fwd", (hipStream_t)stream);
+        ign_launch_shp_fwd_multi(m, (int)nblocks, lds, (hipStream_t)stream);
+    }
+    return ign_check_launch("shp_fwd_multi_kernel");
 }
 
 // ------------------------------------------------------------------------------------------ backward

@@ -55,19 +55,20 @@ __device__ __forceinline__ float wave_bcast_l63(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// The body of one block: (bx, by) play the role of blockIdx.x / .y so that the single-group kernel and the bank kernel
+// (ign_shapelet_fwd_multi.hip: all length groups of a bank in ONE launch) share it.
 template <int TT, int KT, int DIST>
-__global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
+__device__ __forceinline__ void shp_fwd_body(const ShpFwdArgs& a, const int bx, const int by, float* smem) {
     constexpr int J = FwdJ<TT>::J;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wpb = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nbg = (a.B + wpb - 1) / wpb;
-    const int c = blockIdx.x / nbg;                 // block-uniform: every wave of the block shares w[:,c,:]
-    const int bg = blockIdx.x - c * nbg;
+    const int c = bx / nbg;                         // block-uniform: every wave of the block shares w[:,c,:]
+    const int bg = bx - c * nbg;
     int b = bg * wpb + wave;
     const bool row_ok = b < a.B;
     if (!row_ok) b = a.B - 1;
-    const int k0 = a.k0 + blockIdx.y * KT;
+    const int k0 = a.k0 + by * KT;
 
     float* xs = smem + wave * a.xs_len;
     {
@@ -318,6 +319,12 @@ __global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
             }
         }
     }
+}
+
+template <int TT, int KT, int DIST>
+__global__ void __launch_bounds__(256, 4) shp_fwd_kernel(const ShpFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    shp_fwd_body<TT, KT, DIST>(a, blockIdx.x, blockIdx.y, smem);
 }
 
 template <int TT, int KT, int DIST>

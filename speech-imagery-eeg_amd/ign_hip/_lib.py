@@ -22,6 +22,7 @@ SIGNATURES = {
     "ign_instnorm_fwd": (ci, [vp, vp, vp, ci, ci, ci, cf, vp]),
     "ign_standardise_nct_to_btc": (ci, [vp, vp, vp, ci, ci, ci, cf, vp]),
     "ign_shapelet_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),
+    "ign_shapelet_fwd_bank": (ci, [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, cf, ci, vp]),
     "ign_shapelet_bwd_workspace_bytes": (sz, [ci, ci, ci, ci, ci, ci, ci]),
     "ign_layernorm_parts": (ll, [ll, ci]),
     "ign_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ll, ci, cf, vp]),

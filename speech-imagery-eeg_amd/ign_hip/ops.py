@@ -94,11 +94,24 @@ class ShapeletBankFn(torch.autograd.Function):
             dsave = torch.empty(B, C, K, Tw, device=xn.device, dtype=torch.float32) if need_grad else None
             xstat = torch.empty(B, C, Tw, device=xn.device, dtype=torch.float32) \
                 if (need_grad and (mode & 0xf) >= DIST_COS) else None
-            _lib.check(L.ign_shapelet_fwd(_ptr(xn), _ptr(w), _ptr(thrs[g]), _ptr(P), _ptr(D), ld, col0,
-                                          _ptr(tstar), _ptr(zmu), _ptr(dsave), _ptr(xstat), B, C, T, K, Lg, stride,
-                                          float(eps), int(mode), _stream()), "ign_shapelet_fwd")
             saved.append((tstar, zmu, dsave, col0, stride, xstat))
             col0 += K * C
+        G = len(ws)
+        if G <= 8:
+            # the whole bank in one call: one launch for all length groups on the headline path (ign_shapelet_fwd_bank)
+            vpa, ia = ctypes.c_void_p * G, ctypes.c_int * G
+            pv = lambda ts: vpa(*[(t.data_ptr() if t is not None else None) for t in ts])
+            _lib.check(L.ign_shapelet_fwd_bank(
+                _ptr(xn), G, pv(ws), pv(thrs), _ptr(P), _ptr(D), ld, ia(*[sv[3] for sv in saved]), pv([sv[0] for sv in saved]),
+                pv([sv[1] for sv in saved]), pv([sv[2] for sv in saved]), pv([sv[5] for sv in saved]), B, C, T,
+                ia(*[w.shape[0] for w in ws]), ia(*[w.shape[2] for w in ws]), ia(*[sv[4] for sv in saved]), float(eps), int(mode),
+                _stream()), "ign_shapelet_fwd_bank")
+        else:
+            for g, w in enumerate(ws):
+                tstar, zmu, dsave, c0, stride, xstat = saved[g]
+                _lib.check(L.ign_shapelet_fwd(_ptr(xn), _ptr(w), _ptr(thrs[g]), _ptr(P), _ptr(D), ld, c0, _ptr(tstar), _ptr(zmu),
+                                              _ptr(dsave), _ptr(xstat), B, C, T, w.shape[0], w.shape[2], stride, float(eps), int(mode),
+                                              _stream()), "ign_shapelet_fwd")
         Tstar = torch.cat([sv[0].reshape(B, -1) for sv in saved], dim=1) if len(saved) > 1 else saved[0][0].reshape(B, -1)
         ctx.mark_non_differentiable(D, Tstar)
         ctx.meta = (float(eps), int(mode), n_groups, saved, need_grad)

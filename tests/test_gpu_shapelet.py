@@ -257,6 +257,31 @@ def test_match_location_is_the_argmax_window(B, C, T, K, L, stride, lts):
     assert int(t.max()) * stride + L <= T
 
 
+@pytest.mark.parametrize("B,C,T,Ks,Ls", [(5, 7, 1000, (5, 5, 5, 5), (100, 200, 300, 500)),      # the driver-default bank
+                                         (3, 6, 100, (10, 5, 10), (5, 30, 80)),                    # K = 10: two tiles per row
+                                         (2, 4, 200, (5, 3), (20, 50))])                            # K = 3: falls back per group
+def test_bank_in_one_launch_is_bitwise_the_per_group_result(B, C, T, Ks, Ls):
+    """ign_shapelet_fwd_bank: all length groups as ONE grid (heaviest blocks first) must reproduce the per-group launches
+    bit for bit -- outputs, arg-max windows and, through the saved distances / statistics, the gradients."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    g = torch.Generator().manual_seed(sum(Ls))
+    xn = torch.randn(B, C, T, generator=g).to(dev)
+    ws = [torch.randn(K, C, L, generator=g).to(dev).requires_grad_(True) for K, L in zip(Ks, Ls)]
+    r = torch.randn(B, sum(Ks) * C, generator=g).to(dev)
+    p, d, t = ops.shapelet_bank(xn, ws, 0.9, return_tstar=True)
+    gw = torch.autograd.grad((p * r).sum(), ws)
+    col = 0
+    for i, w in enumerate(ws):
+        n = Ks[i] * C
+        pi, di, ti = ops.shapelet_bank(xn, [w], 0.9, return_tstar=True)
+        gi, = torch.autograd.grad((pi * r[:, col:col + n]).sum(), [w])
+        assert torch.equal(pi, p[:, col:col + n]) and torch.equal(di, d[:, col:col + n]) and torch.equal(ti, t[:, col:col + n])
+        assert torch.equal(gi, gw[i])
+        col += n
+
+
 def test_full_size_properties():
     """B=256, C=122, T=1000 (BASELINE config 1): size-independent checks the oracle cannot reach in seconds."""
     dev = _dev()
