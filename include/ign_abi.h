@@ -73,10 +73,8 @@ int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const float* thr_k
                      int B, int C, int T, int K, int L, int stride, float eps, int mode, void* stream);
 
 /* All G (<= 8) length groups of a bank -- the loop over `self.shapelets` of IGN/model/Shapelet.py:190-196 -- in one call: the
- * per-group arguments of ign_shapelet_fwd as tables of G entries (host arrays; the outputs share p_out / dmin_out / ld).  When
- * every group is on the headline path (L1 distance, K a multiple of 5, stride 1, T - L + 1 <= 1024) the blocks of all groups
- * form ONE grid ordered by work per block, so a step pays one scheduling tail instead of G; results are bitwise those of the
- * per-group calls, which is also what this entry falls back to otherwise.                                                    */
+ * per-group arguments of ign_shapelet_fwd as tables of G entries (host arrays; the outputs share p_out / dmin_out / ld).  Every
+ * group is validated before the first launch; results are bitwise those of G ign_shapelet_fwd calls.                         */
 int ign_shapelet_fwd_bank(const float* xn_bct, int G, const float* const* w_kcl, const float* const* thr_kc, float* p_out,
                           float* dmin_out, int ld, const int* col0, int32_t* const* tstar, float* const* zmu,
                           float* const* d_save, float* const* xstat_save, int B, int C, int T, const int* K, const int* L,

@@ -198,8 +198,11 @@ extern "C" int ign_shapelet_fwd(const float* xn_bct, const float* w_kcl, const f
     return launch_fwd_group(who, pl, stream);
 }
 
-// All G length groups of a bank (IGN/model/Shapelet.py:190-196: the loop over self.shapelets) in ONE launch when every group
-// is on the headline path (L1 distance, K a multiple of 5, stride 1, one pass per row); otherwise group by group as above.
+// All G length groups of a bank (IGN/model/Shapelet.py:190-196: the loop over self.shapelets) in one call, launched group by
+// group.  A single grid over the blocks of all groups (heaviest first, one scheduling tail per step instead of G) was built and
+// measured in round 2 (shp_fwd_multi_kernel: the same shp_fwd_body behind a wave-uniform switch over TT): 4.07 ms against 3.97 ms
+// for the four separate launches at the benchmark shape on the same box -- the merged kernel carries the largest body's scratch
+// and register allocation into every block -- so it was removed again (tests/diag_fwd_bank.py keeps the A/B harness).
 extern "C" int ign_shapelet_fwd_bank(const float* xn_bct, int G, const float* const* w_kcl, const float* const* thr_kc, float* p_out,
                                      float* dmin_out, int ld, const int* col0, int32_t* const* tstar, float* const* zmu,
                                      float* const* d_save, float* const* xstat_save, int B, int C, int T, const int* K, const int* L,
@@ -211,47 +214,13 @@ extern "C" int ign_shapelet_fwd_bank(const float* xn_bct, int G, const float* co
     }
     FwdPlan pl[SHP_MAX_GROUPS];
     int rc;
-    bool one_launch = true;
-    for (int g = 0; g < G; ++g) {
+    for (int g = 0; g < G; ++g)          // validate every group before the first launch
         if ((rc = plan_fwd(who, xn_bct, w_kcl[g], thr_kc ? thr_kc[g] : nullptr, p_out, dmin_out, ld, col0[g], tstar[g], zmu[g],
                            d_save ? d_save[g] : nullptr, xstat_save ? xstat_save[g] : nullptr, B, C, T, K[g], L[g], stride[g], eps,
                            mode, &pl[g]))) return rc;
-        one_launch = one_launch && pl[g].dist == DIST_L1 && K[g] % 5 == 0 && stride[g] == 1 && pl[g].a.npass == 1 && pl[g].wpb == 1;
-    }
-    if (!one_launch || G == 1) {
-        for (int g = 0; g < G; ++g)
-            if ((rc = launch_fwd_group(who, pl[g], stream))) return rc;
-        return 0;
-    }
-    // heaviest blocks first: work per block ~ Tw * L
-    int order[SHP_MAX_GROUPS];
-    for (int g = 0; g < G; ++g) order[g] = g;
-    std::sort(order, order + G, [&](int x, int y) {
-        return (long long)pl[x].a.Tw * pl[x].a.L > (long long)pl[y].a.Tw * pl[y].a.L;
-    });
-    ShpFwdMulti m;
-    size_t lds = 0;
-    long long nblocks = 0;
-    for (int q = 0; q < G; ++q) {
-        const FwdPlan& p = pl[order[q]];
-        m.g[q] = p.a;
-        m.tt[q] = p.TT;
-        m.gridx[q] = C * B;
-        m.start[q] = (int)nblocks;
-        nblocks += (long long)C * B * (p.a.K / 5);
-        lds = std::max(lds, p.lds);
-    }
-    m.start[G] = (int)nblocks;
-    m.ng = G;
-    if (nblocks > 2147483647LL) {
-        ign_set_error("%s: %lld blocks exceed the grid limit", who, nblocks);
-        return IGN_E_TOOBIG;
-    }
-    {
-        IgnScopedTimer tm("shp_fwd", (hipStream_t)stream);
-        ign_launch_shp_fwd_multi(m, (int)nblocks, lds, (hipStream_t)stream);
-    }
-    return ign_check_launch("shp_fwd_multi_kernel");
+    for (int g = 0; g < G; ++g)
+        if ((rc = launch_fwd_group(who, pl[g], stream))) return rc;
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------ backward

@@ -40,16 +40,7 @@ struct ShpFwdArgs {
     float eps, invL;
 };
 
-// All length groups of a bank in one launch (ign_shapelet_fwd_multi.hip): L1 distance, shapelet tiles of 5, one pass per row.
-constexpr int SHP_MAX_GROUPS = 8;
-struct ShpFwdMulti {
-    ShpFwdArgs g[SHP_MAX_GROUPS];
-    int start[SHP_MAX_GROUPS + 1];   // first block of each group in launch order (heaviest blocks first)
-    int gridx[SHP_MAX_GROUPS];       // blocks along x per group (channels x rows); y = K / 5 tiles
-    int tt[SHP_MAX_GROUPS];          // windows per lane of each group
-    int ng;
-};
-void ign_launch_shp_fwd_multi(const ShpFwdMulti& m, int nblocks, size_t lds, hipStream_t s);
+constexpr int SHP_MAX_GROUPS = 8;      // groups per ign_shapelet_fwd_bank call
 
 // launchers generated per (DIST, TT, KT); defined in ign_shapelet_fwd_*.hip
 typedef void (*shp_fwd_launch_t)(const ShpFwdArgs&, dim3 grid, dim3 block, size_t lds, hipStream_t);

@@ -260,9 +260,9 @@ def test_match_location_is_the_argmax_window(B, C, T, K, L, stride, lts):
 @pytest.mark.parametrize("B,C,T,Ks,Ls", [(5, 7, 1000, (5, 5, 5, 5), (100, 200, 300, 500)),      # the driver-default bank
                                          (3, 6, 100, (10, 5, 10), (5, 30, 80)),                    # K = 10: two tiles per row
                                          (2, 4, 200, (5, 3), (20, 50))])                            # K = 3: falls back per group
-def test_bank_in_one_launch_is_bitwise_the_per_group_result(B, C, T, Ks, Ls):
-    """ign_shapelet_fwd_bank: all length groups as ONE grid (heaviest blocks first) must reproduce the per-group launches
-    bit for bit -- outputs, arg-max windows and, through the saved distances / statistics, the gradients."""
+def test_bank_call_is_bitwise_the_per_group_result(B, C, T, Ks, Ls):
+    """ign_shapelet_fwd_bank (all length groups in one ABI call, column offsets into shared outputs) must reproduce separate
+    single-group banks bit for bit -- outputs, arg-max windows and, through the saved distances / statistics, the gradients."""
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
     from ign_hip import ops
