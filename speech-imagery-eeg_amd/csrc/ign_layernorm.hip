@@ -6,16 +6,18 @@
 // d(gamma), d(beta) over all rows a lane sees (its columns never change), folds them through LDS per block and a fixed-order
 // second pass -- bitwise reproducible, no atomics.  torch's kernels for D = 64 run one row per block-sized unit: 3.9 / 6.3 ms
 // per call at 3.9 M rows (PatchTST), where these take the HBM time.
+#include <algorithm>
 #include "ign_common.h"
 
 constexpr int LN_MAXV = 16;                   // float4 pieces per lane: D <= 64 * 4 * 16 = 4096
-constexpr int LN_ITERS = 32;                  // row groups per wave
+constexpr int LN_ITERS_MAX = 32;              // row groups per wave (fewer when that would leave the chip under-filled)
 
 struct LnArgs {
     const float *x, *gy, *gamma, *beta, *mean_in, *rstd_in;
     float *y, *gx, *mean, *rstd, *part;       // part: (nblocks, 2, D)
     long long R;
     int D, G, nv;                             // lanes per row, float4 pieces per lane
+    int iters;                                // row groups per wave
     float eps;
 };
 
@@ -37,8 +39,8 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const LnArgs a) {
         gm[v] = c < D4 ? reinterpret_cast<const float4*>(a.gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         bt[v] = (c < D4 && a.beta) ? reinterpret_cast<const float4*>(a.beta)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const long long row0 = ((long long)blockIdx.x * 4 + wave) * LN_ITERS * rpw;
-    for (int it = 0; it < LN_ITERS; ++it) {
+    const long long row0 = ((long long)blockIdx.x * 4 + wave) * a.iters * rpw;
+    for (int it = 0; it < a.iters; ++it) {
         const long long r = row0 + (long long)it * rpw + sub;
         if (row0 + (long long)it * rpw >= a.R) break;               // wave-uniform
         const bool ok = r < a.R;
@@ -90,8 +92,8 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const LnArgs a) {
         gm[v] = c < D4 ? reinterpret_cast<const float4*>(a.gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         dg[v] = db[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const long long row0 = ((long long)blockIdx.x * 4 + wave) * LN_ITERS * rpw;
-    for (int it = 0; it < LN_ITERS; ++it) {
+    const long long row0 = ((long long)blockIdx.x * 4 + wave) * a.iters * rpw;
+    for (int it = 0; it < a.iters; ++it) {
         const long long r = row0 + (long long)it * rpw + sub;
         if (row0 + (long long)it * rpw >= a.R) break;               // wave-uniform
         const bool ok = r < a.R;
@@ -147,26 +149,41 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const LnArgs a) {
     }
 }
 
-// dgamma / dbeta[col] = sum over blocks (ascending) of part[block][which][col]
+// dgamma / dbeta[col] = sum over blocks of part[block][which][col]: 64 columns x 4 block-slices per workgroup, every slice summed
+// in ascending order with 8 loads in flight, the 4 slice sums combined in a fixed order (bitwise reproducible).  One thread per
+// column walking ALL blocks (the first version) took 158 us at 2000 blocks: a serial chain of dependent loads.
 __global__ void __launch_bounds__(256) layernorm_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, int nblk, int D) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * D) return;
-    const int which = i / D, col = i - which * D;
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= nblk; b += 4) {
-        t0 += part[((size_t)b * 2 + which) * D + col];
-        t1 += part[((size_t)(b + 1) * 2 + which) * D + col];
-        t2 += part[((size_t)(b + 2) * 2 + which) * D + col];
-        t3 += part[((size_t)(b + 3) * 2 + which) * D + col];
+    __shared__ float sm[4][64];
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;                    // index into (which, col), 2*D in total
+    const int per = (nblk + 3) / 4;
+    const int b0 = sl * per, b1 = min(nblk, b0 + per);
+    float s = 0.f;
+    if (i < 2 * D) {
+        const int which = i / D, col = i - which * D;
+        const float* p = part + (size_t)which * D + col;
+        const size_t pitch = (size_t)2 * D;
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(b + u) * pitch];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < b1; ++b) s += p[(size_t)b * pitch];
     }
-    for (; b < nblk; ++b) t0 += part[((size_t)b * 2 + which) * D + col];
-    float* out = which == 0 ? dgamma : dbeta;
-    if (out) out[col] = (t0 + t1) + (t2 + t3);
+    sm[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && i < 2 * D) {
+        const int which = i / D, col = i - which * D;
+        float* out = which == 0 ? dgamma : dbeta;
+        if (out) out[col] = ((sm[0][o] + sm[1][o]) + sm[2][o]) + sm[3][o];
+    }
 }
 
-static int ln_geometry(const char* who, long long R, int D, int* G, int* nv, long long* nblk) {
+static int ln_geometry(const char* who, long long R, int D, int* G, int* nv, long long* nblk, int* iters) {
     if (R <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * LN_MAXV) {
         ign_set_error("%s: needs R > 0, D %% 4 == 0, D <= %d (R=%lld D=%d)", who, 64 * 4 * LN_MAXV, R, D);
         return IGN_E_ARG;
@@ -175,14 +192,19 @@ static int ln_geometry(const char* who, long long R, int D, int* G, int* nv, lon
     while (g < 64 && g < D / 4) g <<= 1;
     *G = g;
     *nv = (D / 4 + g - 1) / g;
-    const long long rows_per_block = 4LL * LN_ITERS * (64 / g);
+    // 32 row groups per wave amortise the gamma / beta loads and keep the d(gamma) partials few -- but 25 600 rows of 512 (the
+    // EEG-CNN encoder) would then be 200 blocks on 256 CUs (55 / 95 us per call, torch 34 / 97): aim for >= 2048 blocks
+    const long long groups = (R + (64 / g) - 1) / (64 / g);              // wave-iterations in total
+    int it = (int)std::min<long long>(LN_ITERS_MAX, std::max<long long>(1, groups / (4 * 2048)));
+    *iters = it;
+    const long long rows_per_block = 4LL * it * (64 / g);
     *nblk = (R + rows_per_block - 1) / rows_per_block;
     return 0;
 }
 
 extern "C" long long ign_layernorm_parts(long long R, int D) {
-    int G, nv; long long nblk;
-    if (ln_geometry("ign_layernorm_parts", R, D, &G, &nv, &nblk)) return 0;
+    int G, nv, iters; long long nblk;
+    if (ln_geometry("ign_layernorm_parts", R, D, &G, &nv, &nblk, &iters)) return 0;
     return nblk;
 }
 
@@ -202,7 +224,7 @@ extern "C" int ign_layernorm_fwd(const float* x, const float* gamma, const float
     LnArgs a = {};
     long long nblk;
     int rc;
-    if ((rc = ln_geometry(who, R, D, &a.G, &a.nv, &nblk))) return rc;
+    if ((rc = ln_geometry(who, R, D, &a.G, &a.nv, &nblk, &a.iters))) return rc;
     a.x = x; a.gamma = gamma; a.beta = beta; a.y = y; a.mean = mean; a.rstd = rstd; a.R = R; a.D = D; a.eps = eps;
     IgnScopedTimer tm("layernorm_fwd", (hipStream_t)stream);
     IGN_LN_DISPATCH(layernorm_fwd_kernel, a.nv, dim3((unsigned)nblk), 0, (hipStream_t)stream, a);
@@ -217,7 +239,7 @@ extern "C" int ign_layernorm_bwd(const float* x, const float* gy, const float* g
     LnArgs a = {};
     long long nblk;
     int rc;
-    if ((rc = ln_geometry(who, R, D, &a.G, &a.nv, &nblk))) return rc;
+    if ((rc = ln_geometry(who, R, D, &a.G, &a.nv, &nblk, &a.iters))) return rc;
     a.x = x; a.gy = gy; a.gamma = gamma; a.mean_in = mean; a.rstd_in = rstd; a.gx = gx; a.part = part; a.R = R; a.D = D;
     const size_t lds = (size_t)4 * (64 / a.G) * 2 * D * sizeof(float);
     if (lds > 64 * 1024) { ign_set_error("%s: D=%d needs %zu bytes of LDS", who, D, lds); return IGN_E_TOOBIG; }
@@ -228,7 +250,7 @@ extern "C" int ign_layernorm_bwd(const float* x, const float* gy, const float* g
     }
     if ((rc = ign_check_launch("layernorm_bwd_kernel"))) return rc;
     if (dgamma || dbeta) {
-        hipLaunchKernelGGL(layernorm_reduce_kernel, dim3((unsigned)((2 * D + 255) / 256)), dim3(256), 0, s, part, dgamma, dbeta,
+        hipLaunchKernelGGL(layernorm_reduce_kernel, dim3((unsigned)((2 * D + 63) / 64)), dim3(256), 0, s, part, dgamma, dbeta,
                            (int)nblk, D);
         return ign_check_launch("layernorm_reduce_kernel");
     }

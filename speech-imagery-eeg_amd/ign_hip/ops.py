@@ -10,7 +10,7 @@ import os
 
 DIST_L1, DIST_MSE, DIST_COS, DIST_PEARSON = 0, 1, 2, 3
 ATTN_MATH = os.environ.get("IGN_ATTN_MATH", "bf16x6")          # "f32": attention core on the fp32-MFMA kernels
-LAYERNORM_MIN_ROWS = 65536
+LAYERNORM_MIN_ROWS = 0        # round 1 kept torch below 64k rows; with the row-count-aware grid and the parallel reduce the HIP kernels win everywhere
 LINEAR_WGRAD = os.environ.get("IGN_LINEAR_WGRAD", "bf16x6")   # "f32": weight gradient of ops.linear on the fp32-MFMA TN kernel
 GATE_RBF, GATE_LTS = 0x00, 0x10
 
@@ -437,9 +437,9 @@ def layer_norm(x, norm):
     """Apply an nn.LayerNorm module (normalised over the last dimension, affine) on the hand-written kernels; shapes they do not
     cover go through the module itself (torch on the GPU)."""
     D = x.shape[-1]
-    # below ~64k rows the op is launch-bound and torch's single fused backward wins by a few microseconds per call (EEG-CNN:
-    # 25 600 rows, 8.34 vs 8.50 ms/step); above, torch's kernels fall off the memory roofline (Transformer: 256 000 rows of 512,
-    # 96.9 -> 94.9 ms/step; PatchTST: 3.9 M rows of 64, 123.9 -> 79.4 ms/step)
+    # torch's kernels fall off the memory roofline for many narrow rows (Transformer: 256 000 rows of 512, 96.9 -> 94.9 ms/step;
+    # PatchTST: 3.9 M rows of 64, 123.9 -> 79.4 ms/step); for few rows (EEG-CNN: 25 600 rows of 512) the grid is sized by the row
+    # count and the d(gamma) partials are reduced in parallel: 22 / 37 us per call against torch's 34 / 97 (7.52 -> 7.36 ms/step)
     if (not x.is_cuda or x.dtype != torch.float32 or norm.weight is None or len(norm.normalized_shape) != 1 or D % 4 or D > 2048
             or x.numel() < LAYERNORM_MIN_ROWS * D):
         return norm(x)
