@@ -12,4 +12,4 @@ out = collections.defaultdict(lambda: collections.defaultdict(float))
 for path in sys.argv[2:]:
     for r in csv.DictReader(open(path)):
         out[family(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"]) / steps
-print(json.dumps({k: dict(v) for k, v in out.items() if k.startswith(("shp_", "instnorm", "attn_", "head_", "adam", "reduce_parts", "clconv_", "bn_", "wgrad_reduce", "gather_flat"))}, indent=1, sort_keys=True))
+print(json.dumps({k: dict(v) for k, v in out.items() if k.startswith(("shp_", "instnorm", "attn_", "head_", "adam", "reduce_parts", "clconv_", "bn_", "wgrad_reduce", "gather_flat", "chan_", "affine_", "dwconv", "autocorr", "layernorm"))}, indent=1, sort_keys=True))
