@@ -314,13 +314,6 @@ int ign_clconv_dgrad_x6(const float* dyp, const void* wt3_dgrad, const float* y_
 size_t ign_clconv_wgrad_x6_workspace_bytes(int B, int Tin, int Ci, int Co, int k);
 int ign_clconv_wgrad_x6(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
                         float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream);
-/* A stacked Linear layer: y_j = x W_j^T + b_j for j < nsplit as ONE split-bf16 GEMM with N = Co (the three projections of
- * IGN/layers/SelfAttention_Family.py:195-197 with their weights concatenated along the output axis); y_smn is
- * (nsplit, M, Co / nsplit): every projection in its own contiguous matrix.  wt3 from ign_clconv_pack_weights_x3(Co, Ci, 1).
- * bf16 != 0: operands rounded to bf16, one product (the autocast arithmetic).                                              */
-int ign_linear_fwd_split_x6(const float* x, const void* wt3, const float* bias, float* y_smn, long long M, int Ci, int Co,
-                            int nsplit, int bf16, void* stream);
-
 /* The three split-bf16 GEMMs with ONE product per step: operands rounded to bf16 (round-to-nearest-even), products and sums in
  * fp32 -- the arithmetic of the reference's default bf16-autocast mode (IGN/exp/experiment_classification.py:319; `--amp`
  * switches it OFF).  Same packed weights (plane 0 is read), same arguments, same workspace as the *_x6 entry points.        */

@@ -57,8 +57,6 @@ struct GemmNTArgs {
     const float* ey; const float* ea; const float* eb; const float* emean; const float* einv;
     int mtiles, ntiles;
     const unsigned short* B3; int Kp;          // split-bf16 kernels: Bt as 3 bf16 planes (3, N, Kp), Kp = K rounded up to 8
-    int csplit; long long cstride;             // csplit > 0: C is N/csplit separate dense (M, csplit) matrices `cstride` floats apart
-                                               // (a stacked q/k/v projection writing three contiguous outputs); 0: one (M, N) matrix
 };
 
 // ---- epilogue shared by the fp32 and the split-bf16 kernels.  Lane (l31, h) of accumulator (i, j) holds column
@@ -77,8 +75,6 @@ __device__ __forceinline__ void nt_epilogue_body(const GemmNTArgs& a, const f32x
         const bool n_ok = FULL || n < a.N;
         const int nc = n_ok ? n : a.N - 1;
         const float bv = (EPI == EPI_BIAS_STATS && a.bias) ? a.bias[nc] : 0.f;
-        float* const ccol = a.csplit ? a.C + (long long)(nc / a.csplit) * a.cstride + (nc % a.csplit) : a.C + nc;
-        const long long ldc = a.csplit ? a.csplit : a.N;
         float ea = 0.f, eb = 0.f, em = 0.f, ei = 0.f;
         if (EPI == EPI_MASK_STATS) { ea = a.ea[nc]; eb = a.eb[nc]; em = a.emean[nc]; ei = a.einv[nc]; }
 #pragma unroll
@@ -105,7 +101,7 @@ __device__ __forceinline__ void nt_epilogue_body(const GemmNTArgs& a, const f32x
                     v = (fmaf(ea, yv[r], eb) > 0.f) ? v : 0.f;
                     if (ok) { s1[j] += v; s2[j] = fmaf(v, (yv[r] - em) * ei, s2[j]); }
                 }
-                if (ok) ccol[(long long)m * ldc] = v;
+                if (ok) a.C[(long long)m * a.N + n] = v;
             }
         }
     }

@@ -328,8 +328,7 @@ extern "C" int ign_clconv_pack_weights(const float* w_oik, float* wt_fwd, float*
 
 // x6: 0 = fp32 MFMA, 6 = split bf16 (six products), 1 = operands rounded to bf16 (one product)
 static int clconv_fwd_impl(const char* who, int x6, const float* x, const void* wt, const float* bias, const float* pro_a,
-                           const float* pro_b, float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream,
-                           int nsplit = 1) {
+                           const float* pro_b, float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream) {
     const int Tout = Tin - k + 1;
     if (!x || !wt || !y || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || ((pro_a == nullptr) != (pro_b == nullptr))) {
         ign_set_error("%s: bad argument (B=%d Tin=%d Ci=%d Co=%d k=%d)", who, B, Tin, Ci, Co, k);
@@ -343,10 +342,6 @@ static int clconv_fwd_impl(const char* who, int x6, const float* x, const void* 
     a.B3 = x6 ? (const unsigned short*)wt : nullptr; a.Kp = 0;
     a.pro_a = pro_a; a.pro_b = pro_b; a.pro_c = Ci; a.part = stat_part;
     a.mtiles = (int)((M + TM - 1) / TM); a.ntiles = (Co + TN - 1) / TN;
-    if (nsplit > 1) {
-        if (Co % nsplit) { ign_set_error("%s: Co=%d is not a multiple of nsplit=%d", who, Co, nsplit); return IGN_E_ARG; }
-        a.csplit = Co / nsplit; a.cstride = M * (long long)(Co / nsplit);
-    }
     IgnScopedTimer tm("clconv_fwd", (hipStream_t)stream);
     if (x6) {
         if (k > 16) { ign_set_error("%s: k=%d > 16 taps", who, k); return IGN_E_UNSUP; }
@@ -368,16 +363,6 @@ extern "C" int ign_clconv_fwd(const float* x, const float* wt, const float* bias
 extern "C" int ign_clconv_fwd_x6(const float* x, const void* wt3, const float* bias, const float* pro_a, const float* pro_b,
                                  float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream) {
     return clconv_fwd_impl("ign_clconv_fwd_x6", 6, x, wt3, bias, pro_a, pro_b, y, stat_part, B, Tin, Ci, Co, k, stream);
-}
-
-// A stacked Linear layer y_j = x W_j^T + b_j, j < nsplit (the q / k / v projections of IGN/layers/SelfAttention_Family.py:195-197
-// as ONE GEMM with N = nsplit * Co_j): y is (nsplit, M, Co / nsplit) -- every projection lands in its own contiguous matrix, so
-// the attention kernels read q, k, v exactly as from three separate GEMMs.  bf16 != 0: the single-product autocast form.
-extern "C" int ign_linear_fwd_split_x6(const float* x, const void* wt3, const float* bias, float* y_smn, long long M, int Ci, int Co,
-                                       int nsplit, int bf16, void* stream) {
-    if (M <= 0 || M > 0x3fffffffLL || nsplit < 1) { ign_set_error("ign_linear_fwd_split_x6: bad M=%lld / nsplit=%d", M, nsplit); return IGN_E_ARG; }
-    return clconv_fwd_impl("ign_linear_fwd_split_x6", bf16 ? 1 : 6, x, wt3, bias, nullptr, nullptr, y_smn, nullptr, 1, (int)M, Ci, Co, 1,
-                           stream, nsplit);
 }
 
 extern "C" int ign_clconv_fwd_bf16(const float* x, const void* wt3, const float* bias, const float* pro_a, const float* pro_b,

@@ -266,93 +266,6 @@ def attention_packed(qkv, scale):
     return PackedAttentionFn.apply(qkv, scale)
 
 
-class QKVAttentionFn(torch.autograd.Function):
-    """Self-attention block front end as ONE autograd node: the three projections of AttentionLayer
-    (IGN/layers/SelfAttention_Family.py:195-197) as one stacked GEMM whose epilogue writes q, k, v into three CONTIGUOUS
-    matrices (ign_linear_fwd_split_x6), the fused attention core on them (:56-75), and in the backward the three attention
-    gradients written token-major into one (M, 3 d) buffer (ign_attn_bwd_x6_strided) that feeds ONE input-gradient GEMM with
-    K = 3 d and ONE weight / bias-gradient pass.  Against three separate Linear nodes this removes two GEMM launches each way at
-    the layer's least efficient shape (N = 512), the two `dx_q + dx_k + dx_v` accumulation passes of autograd, and keeps the
-    attention kernels' reads as dense as before (a packed (M, 3, d) projection output, the round-1 experiment, made them stream
-    K / V rows three times further apart: 100.7 vs 98.5 ms/step).  Parameters stay the reference's three modules."""
-
-    @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, n_heads, scale):
-        _need_gpu("qkv_attention", x, wq, wk, wv)
-        L_ = _lib.lib()
-        B, Lq, d = x.shape
-        H, E = n_heads, wq.shape[0] // n_heads
-        x2 = x.reshape(-1, d)
-        x2 = x2 if x2.is_contiguous() else x2.contiguous()
-        M, Co = x2.shape[0], 3 * wq.shape[0]
-        w = torch.cat([wq, wk, wv], dim=0).contiguous()
-        b = torch.cat([bq, bk, bv], dim=0).contiguous()
-        dev = x.device
-        need_dx = ctx.needs_input_grad[0]
-        wt3 = torch.empty(int(L_.ign_clconv_x3_elems(Co, d, 1)), device=dev, dtype=torch.bfloat16)
-        wd3 = torch.empty(int(L_.ign_clconv_x3_elems(d, Co, 1)), device=dev, dtype=torch.bfloat16) if need_dx else None
-        _lib.check(L_.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt3), _ptr(wd3), Co, d, 1, _stream()), "ign_clconv_pack_weights_x3")
-        ctx.bf16 = torch.is_autocast_enabled()
-        y3 = torch.empty(3, B, Lq, H, E, device=dev, dtype=torch.float32)
-        _lib.check(L_.ign_linear_fwd_split_x6(_ptr(x2), _ptr(wt3), _ptr(b), _ptr(y3), M, d, Co, 3, 1 if ctx.bf16 else 0, _stream()),
-                   "ign_linear_fwd_split_x6")
-        q, k, v = y3[0], y3[1], y3[2]
-        out = torch.empty(B, Lq, H, E, device=dev, dtype=torch.float32)
-        lse = torch.empty(B, H, Lq, device=dev, dtype=torch.float32)
-        sb, sl = q.stride(0), q.stride(1)
-        fwd = L_.ign_attn_fwd_bf16 if ctx.bf16 else L_.ign_attn_fwd_x6
-        _lib.check(fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, Lq, Lq, H, E, sb, sl, sb, sl, sb, sl, float(scale), _stream()),
-                   "ign_attn_fwd_x6")
-        ctx.save_for_backward(x2, y3, out, lse)
-        ctx.wd3, ctx.scale, ctx.xshape = wd3, float(scale), x.shape
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        L_ = _lib.lib()
-        x2, y3, out, lse = ctx.saved_tensors
-        _, B, Lq, H, E = y3.shape
-        M, d = x2.shape
-        Co = 3 * H * E
-        q, k, v = y3[0], y3[1], y3[2]
-        gout = gout.contiguous()
-        dev = x2.device
-        g = torch.empty(B, Lq, 3, H, E, device=dev, dtype=torch.float32)              # token-major: one (M, 3 d) GEMM operand
-        delta = torch.empty(B, H, Lq, device=dev, dtype=torch.float32)
-        sb, sl = q.stride(0), q.stride(1)
-        _lib.check(L_.ign_attn_bwd_x6_strided(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(gout), _ptr(g[:, :, 0]),
-                                              _ptr(g[:, :, 1]), _ptr(g[:, :, 2]), _ptr(delta), B, Lq, Lq, H, E, sb, sl, sb, sl, sb, sl,
-                                              ctx.scale, _stream(), g.stride(0), g.stride(1), 1 if ctx.bf16 else 0),
-                   "ign_attn_bwd_x6_strided")
-        g2 = g.view(M, Co)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, d, device=dev, dtype=torch.float32)
-            _lib.check(_gemm(L_, ctx.bf16)[0](_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, 1, M, Co, d, 1, _stream()),
-                       "ign_clconv_fwd_x6(dx)")
-            dx = dx.view(ctx.xshape)
-        dw = torch.empty(Co, d, device=dev, dtype=torch.float32)
-        db = torch.empty(Co, device=dev, dtype=torch.float32)
-        ws = torch.empty(int(L_.ign_clconv_wgrad_x6_workspace_bytes(1, M, d, Co, 1)) // 4, device=dev, dtype=torch.float32)
-        fn = L_.ign_linear_wgrad_bf16 if ctx.bf16 else L_.ign_linear_wgrad_x6
-        _lib.check(fn(_ptr(g2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(ws), M, d, Co, _stream()), "ign_linear_wgrad_x6")
-        n = H * E
-        return dx, dw[:n], db[:n], dw[n:2 * n], db[n:2 * n], dw[2 * n:], db[2 * n:], None, None
-
-
-def qkv_attention_supported(x, wq, wk, wv, bq, bk, bv, n_heads):
-    d = x.shape[-1]
-    E = wq.shape[0] // max(n_heads, 1)
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and ATTN_MATH == "bf16x6" and LINEAR_WGRAD == "bf16x6"
-            and wq.shape == wk.shape == wv.shape and wq.shape[1] == d and d % 4 == 0 and wq.shape[0] % 32 == 0
-            and E in (16, 32, 64) and wq.shape[0] == n_heads * E and None not in (bq, bk, bv))
-
-
-def qkv_attention(x, wq, bq, wk, bk, wv, bv, n_heads, scale):
-    """softmax(scale (x Wq^T + bq)(x Wk^T + bk)^T)(x Wv^T + bv) per head, (B, L, d) -> (B, L, H, E): see QKVAttentionFn."""
-    return QKVAttentionFn.apply(x, wq, bq, wk, bk, wv, bv, n_heads, scale)
-
-
 class HeadLinearFn(torch.autograd.Function):
     """Skinny expert-head GEMM x (B,F) @ W(N,F)^T + bias -> (B,N) on ign_head_fwd/bwd."""
 
