@@ -13,12 +13,6 @@ import torch.nn as nn
 
 from ign_hip import ops
 
-# IGN_FUSED_QKV=1: one stacked q/k/v projection GEMM + packed attention.  Measured at the Transformer baseline's shape
-# (B=256, L=1000, d=512): 100.7 vs 98.5 ms/step -- the attention kernels stream K / V rows three times further apart in the
-# packed buffer, which costs more than the two saved GEMM launches and adds return -- so the default stays three projections.
-_FUSED_QKV = __import__("os").environ.get("IGN_FUSED_QKV", "0") == "1"
-
-
 class FullAttention(nn.Module):
     def __init__(self, mask_flag=True, factor=5, scale=None, attention_dropout=0.1, output_attention=False):
         super().__init__()
@@ -52,19 +46,8 @@ class AttentionLayer(nn.Module):
         B, L, _ = queries.shape
         S, H = keys.shape[1], self.n_heads
         lin = lambda m, t: ops.linear(t, m.weight, m.bias)
-        inner = self.inner_attention
-        if (_FUSED_QKV and queries is keys and keys is values and queries.is_cuda and isinstance(inner, FullAttention)
-                and not (inner.mask_flag or inner.output_attention or (inner.training and inner.dropout.p > 0))
-                and self.query_projection.out_features == self.value_projection.out_features):
-            # self-attention: ONE projection GEMM with the three weight matrices stacked (the parameters stay separate, as in the
-            # reference's state dict; autograd splits the gradient of the concatenation), one input-gradient GEMM instead of three
-            # plus two adds, and the attention gradients written straight into the packed buffer
-            w = torch.cat([self.query_projection.weight, self.key_projection.weight, self.value_projection.weight], dim=0)
-            b = torch.cat([self.query_projection.bias, self.key_projection.bias, self.value_projection.bias], dim=0)
-            qkv = ops.linear(queries, w, b).view(B, L, 3, H, -1)
-            E = qkv.shape[-1]
-            out = ops.attention_packed(qkv, inner.scale or 1. / sqrt(E))
-            return lin(self.out_projection, out.reshape(B, L, -1)), None
+        # (a stacked q/k/v projection was built twice -- packed output in round 1, three contiguous outputs + one K = 3d
+        # input-gradient GEMM in round 2 -- and lost both times at this shape: DESIGN.md 4.4 / 4.4b)
         q = lin(self.query_projection, queries).view(B, L, H, -1)
         k = lin(self.key_projection, keys).view(B, S, H, -1)
         v = lin(self.value_projection, values).view(B, S, H, -1)
