@@ -310,6 +310,147 @@ __global__ void __launch_bounds__(256) dwconv1d_bwd_w_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------ round 2: register-tiled forms
+// The two kernels above read LDS once or twice per FMA (dwconv1d_kernel: x and w from LDS for 4 outputs; dwconv1d_bwd_w_kernel and
+// autocorr_kernel: both operands from LDS for ONE FMA) and ran at 8-13 T FMA/s.  These keep the operands in registers:
+//   dwconv1d_wave_kernel : one wave per (b, channel) row, lane <-> TT consecutive outputs with a sliding register window, the taps
+//                          wave-uniform SGPR operands (the shapelet forward's main loop with an FMA): 1 LDS read per TT FMAs;
+//   xcorr_kernel         : out[g][j] = sum_{rows of group g} sum_t a[r,t] * bpad[r, t + j]  -- the depthwise weight gradient (a = dy,
+//                          b = x, group = channel) and the input's lag sums (a = b = x, one group).  Lane <-> 4 consecutive t, lags
+//                          in tiles of 32: 128 FMAs per 10 ds_read_b128, all NT*32 accumulators live across the block's rows, ONE
+//                          butterfly reduction per block.  Partials per block, added in ascending order afterwards.
+template <int TT, bool FLIP>
+__global__ void __launch_bounds__(64) dwconv1d_wave_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float* __restrict__ y, int Cc, int T, int k, int pl, int xs_len) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    typedef const __attribute__((address_space(4))) float* cfp;
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const int ch = r % Cc;
+    const float* row = x + (size_t)r * T;
+    for (int i = lane; i < xs_len; i += 64) {
+        const int s = i - pl;
+        xs[i] = (s >= 0 && s < T) ? row[s] : 0.f;
+    }
+    __syncthreads();
+    const cfp wk = (cfp)(uintptr_t)(w + (size_t)ch * k);
+    const float* xl = xs + lane * TT;
+    float acc[TT], xw[TT + 3];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc[t] = 0.f;
+#pragma unroll
+    for (int i = 0; i < TT - 1; ++i) xw[i] = xl[i];
+    int j0 = 0;
+    for (; j0 + 4 <= k; j0 += 4) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) xw[TT - 1 + jj] = xl[j0 + TT - 1 + jj];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const float wv = FLIP ? wk[k - 1 - (j0 + jj)] : wk[j0 + jj];             // wave-uniform: s_load, SGPR operand
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc[t] = fmaf(wv, xw[t + jj], acc[t]);
+        }
+#pragma unroll
+        for (int i = 0; i < TT - 1; ++i) xw[i] = xw[i + 4];
+    }
+    for (; j0 < k; ++j0) {
+        xw[TT - 1] = xl[j0 + TT - 1];
+        const float wv = FLIP ? wk[k - 1 - j0] : wk[j0];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) acc[t] = fmaf(wv, xw[t], acc[t]);
+#pragma unroll
+        for (int i = 0; i < TT - 1; ++i) xw[i] = xw[i + 1];
+    }
+    // lane-major registers -> time-major LDS -> coalesced stores (the row is no longer needed)
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TT; ++t) xs[lane * TT + t] = acc[t];
+    __syncthreads();
+    float* yo = y + (size_t)r * T;
+    for (int i = lane; i < T; i += 64) yo[i] = xs[i];
+}
+
+constexpr int XC_ROWS = 32;                        // rows per block and group
+template <int NT>
+__global__ void __launch_bounds__(256) xcorr_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part,
+                                                    int nrows_g /* rows per group */, int Cc, int T, int K, int pl, int lpr, int T4,
+                                                    int BL) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int rpp = 256 / lpr;                      // rows per pass
+    float* as_ = sm;                                // [rpp][T4]
+    float* bs_ = sm + rpp * T4;                     // [rpp][BL]   bs_[i] = b[i - pl] (0 outside the row)
+    const int ch = blockIdx.x, bsl = blockIdx.y;
+    const int tid = threadIdx.x, slot = tid / lpr, li = tid - slot * lpr;
+    const int u0 = 4 * li;
+    const int r0 = bsl * XC_ROWS, r1 = min(nrows_g, r0 + XC_ROWS);
+    float acc[NT][32];
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc[q][j] = 0.f;
+    for (int rb = r0; rb < r1; rb += rpp) {
+        __syncthreads();
+        for (int i = tid; i < rpp * T4; i += 256) {
+            const int sl = i / T4, u = i - sl * T4;
+            const int rr = rb + sl;
+            as_[i] = (rr < r1 && u < T) ? a[((size_t)rr * Cc + ch) * T + u] : 0.f;
+        }
+        for (int i = tid; i < rpp * BL; i += 256) {
+            const int sl = i / BL, u = i - sl * BL - pl;
+            const int rr = rb + sl;
+            bs_[i] = (rr < r1 && u >= 0 && u < T) ? b[((size_t)rr * Cc + ch) * T + u] : 0.f;
+        }
+        __syncthreads();
+        if (u0 < T4) {
+            const float4 av = *reinterpret_cast<const float4*>(as_ + slot * T4 + u0);
+            const float aq[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                float wv[36];
+                const float* wp = bs_ + slot * BL + u0 + 32 * q;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(wp + 4 * i);
+                    wv[4 * i] = t4.x; wv[4 * i + 1] = t4.y; wv[4 * i + 2] = t4.z; wv[4 * i + 3] = t4.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 32; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[q][j] = fmaf(aq[e], wv[e + j], acc[q][j]);
+            }
+        }
+    }
+    // one reduction per block: butterfly inside each wave (fixed pattern), then the four waves in ascending order
+    __syncthreads();
+    float* red = sm;                                // [4][NT*32]
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            float v = acc[q][j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) red[wave * NT * 32 + q * 32 + j] = v;
+        }
+    __syncthreads();
+    if (tid < NT * 32 && tid < K)
+        part[((size_t)bsl * Cc + ch) * K + tid] = ((red[tid] + red[NT * 32 + tid]) + red[2 * NT * 32 + tid]) + red[3 * NT * 32 + tid];
+}
+
+// launch geometry of xcorr_kernel for rows of T samples and K lags; returns 0 when the shape is outside its tile
+static int xcorr_geometry(int T, int K, int* lpr, int* T4, int* BL, int* NT, size_t* lds) {
+    if (T > 1024 || K > 128 || T < 1 || K < 1) return 0;
+    *T4 = (T + 3) & ~3;
+    int l = 1;
+    while (l < *T4 / 4) l <<= 1;
+    *lpr = l;
+    *NT = K <= 32 ? 1 : 4;
+    *BL = 4 * l + 32 * (*NT) + 8;                   // the last lane's last window: u0 + 32 (NT-1) + 36 <= 4 lpr + 32 NT + 4
+    const int rpp = 256 / l;
+    *lds = std::max((size_t)rpp * (*T4 + *BL), (size_t)4 * (*NT) * 32) * sizeof(float);
+    return 1;
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 static int conv1_check(const char* who, const void* x, const void* w1, const void* mu, const void* out, const void* ws,
                        int rows, int T, int F1, int k1, int pl) {
@@ -401,10 +542,25 @@ extern "C" int ign_dwconv1d_fwd(const float* x, const float* w, float* y, int B,
                                 int flip, void* stream) {
     int rc;
     if ((rc = dw_check("ign_dwconv1d_fwd", x, w, y, B, Cc, T, k, pad_left))) return rc;
-    const int xs_len = (T + k + 8 + 3) & ~3;
-    const size_t lds = ((size_t)xs_len + k) * 4;
     hipStream_t s = (hipStream_t)stream;
     IgnScopedTimer tm("dwconv1d", s);
+    if (T <= 1024) {
+        // one wave per row, TT = 4 / 8 / 16 outputs per lane (the smallest that covers T)
+        const int TT = T <= 256 ? 4 : T <= 512 ? 8 : 16;
+        const int xl = (64 * TT + k + 3) & ~3;
+        const size_t l2 = (size_t)xl * 4;
+        const dim3 grid((unsigned)B * Cc), block(64);
+#define IGN_DW(TTV)                                                                                                                 \
+        do {                                                                                                                        \
+            if (flip) hipLaunchKernelGGL((dwconv1d_wave_kernel<TTV, true>), grid, block, l2, s, x, w, y, Cc, T, k, pad_left, xl);   \
+            else      hipLaunchKernelGGL((dwconv1d_wave_kernel<TTV, false>), grid, block, l2, s, x, w, y, Cc, T, k, pad_left, xl);  \
+        } while (0)
+        if (TT == 4) IGN_DW(4); else if (TT == 8) IGN_DW(8); else IGN_DW(16);
+#undef IGN_DW
+        return ign_check_launch("dwconv1d_wave_kernel");
+    }
+    const int xs_len = (T + k + 8 + 3) & ~3;
+    const size_t lds = ((size_t)xs_len + k) * 4;
     if (flip) hipLaunchKernelGGL(dwconv1d_kernel<true>, dim3((unsigned)B * Cc), dim3(256), lds, s, x, w, y, B * Cc, Cc, T, k, pad_left, xs_len);
     else      hipLaunchKernelGGL(dwconv1d_kernel<false>, dim3((unsigned)B * Cc), dim3(256), lds, s, x, w, y, B * Cc, Cc, T, k, pad_left, xs_len);
     return ign_check_launch("dwconv1d_kernel");
@@ -421,10 +577,27 @@ extern "C" int ign_dwconv1d_bwd_weight(const float* x, const float* dy, float* d
     int rc;
     if ((rc = dw_check("ign_dwconv1d_bwd_weight", x, dy, dw, B, Cc, T, k, pad_left))) return rc;
     if (!workspace) { ign_set_error("ign_dwconv1d_bwd_weight: null workspace"); return IGN_E_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    {
+        int lpr, T4, BL, NT; size_t l2;
+        if (xcorr_geometry(T, k, &lpr, &T4, &BL, &NT, &l2)) {
+            // dw[ch][j] = sum_{b,t} dy[b,ch,t] xpad[b,ch,t+j]: the cross-correlation kernel, group = channel, 32 samples per block
+            const int nsl = (B + XC_ROWS - 1) / XC_ROWS;              // <= min(B, 32): fits the workspace
+            {
+                IgnScopedTimer tm("dwconv1d_bwd_w", s);
+                if (NT == 1) hipLaunchKernelGGL(xcorr_kernel<1>, dim3(Cc, nsl), dim3(256), l2, s, dy, x, (float*)workspace, B, Cc, T, k,
+                                                pad_left, lpr, T4, BL);
+                else         hipLaunchKernelGGL(xcorr_kernel<4>, dim3(Cc, nsl), dim3(256), l2, s, dy, x, (float*)workspace, B, Cc, T, k,
+                                                pad_left, lpr, T4, BL);
+            }
+            if ((rc = ign_check_launch("xcorr_kernel"))) return rc;
+            ign_launch_reduce_parts((const float*)workspace, dw, nsl, (size_t)Cc * k, s);
+            return ign_check_launch("reduce_parts_kernel");
+        }
+    }
     const int nbs = std::max(1, std::min(B, 32));
     const int xs_len = (T + k + 8 + 3) & ~3;
     const size_t lds = ((size_t)xs_len + T) * 4;
-    hipStream_t s = (hipStream_t)stream;
     {
         IgnScopedTimer tm("dwconv1d_bwd_w", s);
         hipLaunchKernelGGL(dwconv1d_bwd_w_kernel, dim3(Cc, nbs), dim3(256), lds, s, x, dy, (float*)workspace, B, Cc, T, k, pad_left,
@@ -474,6 +647,9 @@ __global__ void __launch_bounds__(256) autocorr_kernel(const float* __restrict__
     if (d < K) part[((size_t)blockIdx.x * 2 + slot) * K + d] = acc;
 }
 
+// partial rows the caller must provide (and sum): blocks of XC_ROWS rows for rows of <= 1024 samples (xcorr_kernel), else the
+// 16-row blocks of autocorr_kernel; the count depends on T only through that switch, so the larger of the two is reserved and
+// ign_autocorr_fwd zero-fills what it does not write
 extern "C" long long ign_autocorr_parts(int rows) { return rows > 0 ? 2LL * ((rows + AC_ROWS - 1) / AC_ROWS) : 0; }
 
 // part: (ign_autocorr_parts(rows), K) partial lag sums; the caller adds them up (in double)
@@ -484,6 +660,20 @@ extern "C" int ign_autocorr_fwd(const float* x, float* part, int rows, int T, in
         return IGN_E_ARG;
     }
     if (K > AC_LAGS) { ign_set_error("%s: K=%d lags exceed %d", who, K, AC_LAGS); return IGN_E_UNSUP; }
+    {
+        int lpr, T4, BL, NT; size_t l2;
+        if (xcorr_geometry(T, K, &lpr, &T4, &BL, &NT, &l2)) {
+            // C[d] = sum_rows sum_u x[u] x[u+d]: the cross-correlation of every row with itself, one group
+            const int nsl = (rows + XC_ROWS - 1) / XC_ROWS;
+            const long long nparts = ign_autocorr_parts(rows);
+            hipStream_t s = (hipStream_t)stream;
+            if (nparts > nsl) (void)hipMemsetAsync(part + (size_t)nsl * K, 0, (size_t)(nparts - nsl) * K * sizeof(float), s);
+            IgnScopedTimer tm("autocorr", s);
+            if (NT == 1) hipLaunchKernelGGL(xcorr_kernel<1>, dim3(1, nsl), dim3(256), l2, s, x, x, part, rows, 1, T, K, 0, lpr, T4, BL);
+            else         hipLaunchKernelGGL(xcorr_kernel<4>, dim3(1, nsl), dim3(256), l2, s, x, x, part, rows, 1, T, K, 0, lpr, T4, BL);
+            return ign_check_launch("xcorr_kernel");
+        }
+    }
     const int xs_len = (((T + 3) & ~3) + AC_LAGS + 4 + 3) & ~3;
     const size_t lds = (size_t)2 * xs_len * sizeof(float);
     if (lds > 64 * 1024) { ign_set_error("%s: T=%d needs %zu bytes of LDS", who, T, lds); return IGN_E_TOOBIG; }
