@@ -334,23 +334,24 @@ __global__ void __launch_bounds__(64) dwconv1d_wave_kernel(const float* __restri
     __syncthreads();
     const cfp wk = (cfp)(uintptr_t)(w + (size_t)ch * k);
     const float* xl = xs + lane * TT;
-    float acc[TT], xw[TT + 3];
+    constexpr int J = 8;                            // taps per unrolled group: one s_load_dwordx8 of taps, TT-1 register moves
+    float acc[TT], xw[TT + J - 1];
 #pragma unroll
     for (int t = 0; t < TT; ++t) acc[t] = 0.f;
 #pragma unroll
     for (int i = 0; i < TT - 1; ++i) xw[i] = xl[i];
     int j0 = 0;
-    for (; j0 + 4 <= k; j0 += 4) {
+    for (; j0 + J <= k; j0 += J) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) xw[TT - 1 + jj] = xl[j0 + TT - 1 + jj];
+        for (int jj = 0; jj < J; ++jj) xw[TT - 1 + jj] = xl[j0 + TT - 1 + jj];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < J; ++jj) {
             const float wv = FLIP ? wk[k - 1 - (j0 + jj)] : wk[j0 + jj];             // wave-uniform: s_load, SGPR operand
 #pragma unroll
             for (int t = 0; t < TT; ++t) acc[t] = fmaf(wv, xw[t + jj], acc[t]);
         }
 #pragma unroll
-        for (int i = 0; i < TT - 1; ++i) xw[i] = xw[i + 4];
+        for (int i = 0; i < TT - 1; ++i) xw[i] = xw[i + J];
     }
     for (; j0 < k; ++j0) {
         xw[TT - 1] = xl[j0 + TT - 1];
@@ -387,19 +388,34 @@ __global__ void __launch_bounds__(256) xcorr_kernel(const float* __restrict__ a,
     for (int q = 0; q < NT; ++q)
 #pragma unroll
         for (int j = 0; j < 32; ++j) acc[q][j] = 0.f;
-    for (int rb = r0; rb < r1; rb += rpp) {
-        __syncthreads();
-        for (int i = tid; i < rpp * T4; i += 256) {
+    // rows are prefetched into registers one pass ahead: the global-load latency of pass p+1 runs under the FMAs of pass p
+    constexpr int NA = 4, NB = 6;                   // ceil(rpp*T4 / 256) <= 4, ceil(rpp*BL / 256) <= 6 for T <= 1024, K <= 128
+    float pa[NA], pb[NB];
+    auto gload = [&](int rb) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int i = tid + 256 * q;
             const int sl = i / T4, u = i - sl * T4;
             const int rr = rb + sl;
-            as_[i] = (rr < r1 && u < T) ? a[((size_t)rr * Cc + ch) * T + u] : 0.f;
+            pa[q] = (i < rpp * T4 && rr < r1 && u < T) ? a[((size_t)rr * Cc + ch) * T + u] : 0.f;
         }
-        for (int i = tid; i < rpp * BL; i += 256) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int i = tid + 256 * q;
             const int sl = i / BL, u = i - sl * BL - pl;
             const int rr = rb + sl;
-            bs_[i] = (rr < r1 && u >= 0 && u < T) ? b[((size_t)rr * Cc + ch) * T + u] : 0.f;
+            pb[q] = (i < rpp * BL && rr < r1 && u >= 0 && u < T) ? b[((size_t)rr * Cc + ch) * T + u] : 0.f;
         }
+    };
+    if (r0 < r1) gload(r0);
+    for (int rb = r0; rb < r1; rb += rpp) {
+        __syncthreads();                            // the previous pass has consumed the LDS rows
+#pragma unroll
+        for (int q = 0; q < NA; ++q) { const int i = tid + 256 * q; if (i < rpp * T4) as_[i] = pa[q]; }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) { const int i = tid + 256 * q; if (i < rpp * BL) bs_[i] = pb[q]; }
         __syncthreads();
+        if (rb + rpp < r1) gload(rb + rpp);
         if (u0 < T4) {
             const float4 av = *reinterpret_cast<const float4*>(as_ + slot * T4 + u0);
             const float aq[4] = {av.x, av.y, av.z, av.w};
