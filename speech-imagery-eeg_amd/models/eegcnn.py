@@ -251,7 +251,9 @@ class EEGCNNTransformer(nn.Module):
         """(B,C,T) -> encoder output (B,S,d)."""
         h = self.eegcnn(x).permute(0, 2, 1)
         if self.num_layers > 0:
-            h = self.pos_encoder(self.cnn_projection(h))
+            proj = self.cnn_projection
+            h = ops.linear(h, proj.weight, proj.bias) if isinstance(proj, nn.Linear) else proj(h)
+            h = self.pos_encoder(h)
             for layer in self.transformer_encoder.layers:
                 h = _encoder_layer_forward(layer, h, self.n_heads)
         return h
@@ -271,5 +273,5 @@ class EEGCNNTransformer(nn.Module):
             h = h[:, 0, :]
         else:
             raise ValueError(f"Unsupported pooling method: {self.pooling}")
-        logits = self.classifier(h)
+        logits = ops.head_linear(h, self.classifier.weight, self.classifier.bias)      # N = 3: the streaming head kernel
         return logits, ModelInfo(loss=torch.zeros((), device=logits.device), preds=logits)
