@@ -51,3 +51,27 @@ def test_two_rank_rehearsal_end_to_end():
     col = res["config"]["collective"]
     assert col["ranks"] == 2 and col["bucket_bytes"] > 4_000_000 and col["allreduce_ms_per_step"] > 0
     assert "rehearsal" in res["config"] and res["scaling"] == "weak"
+
+
+def test_committed_bench_line_carries_the_contract_fields():
+    """The driver-facing JSON line (profiles/r2k_bench_line.json = the default `python bench.py` run of the round-end
+    measurement pass): metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline /
+    dtype / data / config.workload, the roofline object of the dominant kernel, the CPU baseline, and configs 3 / 4."""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r2k_bench_line.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "baselines"):
+        assert k in line, k
+    assert line["unit"] == "epochs/s" and line["n_gpus"] == 1 and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] - line["steps"] * 256 / 8192 / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1e-9 * line["value"] + 1e-12
+    roof = line["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"} <= set(roof)
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0 < roof["frac"] < 1
+    assert roof["traffic"] and "NOT measured in this run" in roof["traffic_source"]
+    cpu = line["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample", "cpu"} <= set(cpu) and cpu["kind"] == "port" and "3 timed" in cpu["sample"]
+    for name in ("eegcnn", "transformer"):
+        b = line["baselines"][name]
+        assert b["roofline"]["peak"] == 2500.0 and 0 < b["roofline"]["frac"] < 1          # executed bf16 flops / dense bf16 peak
+        assert all(0 < g["frac"] < 1 for g in b["gemm_kernels"].values())
+        assert b["cpu_baseline"]["kind"] == "port" and b["cpu_baseline"]["value"] > 0

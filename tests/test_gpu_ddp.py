@@ -1,0 +1,95 @@
+"""The batch-sharded data-parallel path on the HIP models: two ranks on ONE GPU (collective over gloo -- RCCL needs one GPU per
+rank; the driver's 8-GPU node is the only place that runs it) train the SBM for three steps through the flat gradient bucket and
+the one-launch Adam.  Replicas must stay bit-identical, and equal a single process stepping on the concatenated batch (the CE is
+a mean over equal shards, the regulariser is replica-identical: SURVEY 8(e))."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, has_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cfg():
+    from argparse import Namespace
+    return Namespace(enc_in=5, seq_len=120, num_class=3, epsilon=1.0, distance_func='euclidean', memory_efficient=False,
+                     sbm_cls='linear', dropout=0.0, lambda_reg=0.1, lambda_div=0.1)
+
+
+def _data():
+    g = torch.Generator().manual_seed(7)
+    return torch.randn(3, 16, 120, 5, generator=g), torch.randint(0, 3, (3, 16), generator=g)
+
+
+def _train(model, bucket, opt, xs, ys, sl):
+    import torch.nn.functional as F
+    for i in range(xs.shape[0]):
+        out, info = model(xs[i, sl].cuda())
+        (F.cross_entropy(out, ys[i, sl].cuda()) + info.loss.mean()).backward()
+        bucket.allreduce()
+        opt.step()
+        bucket.zero_grad()
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import speech_imagery_eeg_amd  # noqa: F401
+    from ign_hip.ddp import FlatAdam, FlatParamBucket
+    from models.Shapelet import ShapeBottleneckModel
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                      # replicas start different ...
+    model = ShapeBottleneckModel(_cfg(), [5, 3], [0.2, 0.5]).cuda().train()
+    bucket = FlatParamBucket(model, world)
+    bucket.broadcast_state(0)                          # ... and are made rank 0's
+    opt = FlatAdam(bucket, lr=5e-3)
+    xs, ys = _data()
+    _train(model, bucket, opt, xs, ys, slice(rank * 8, rank * 8 + 8))
+    sd = [None] * world
+    dist.all_gather_object(sd, {k: v.cpu().numpy() for k, v in model.state_dict().items()})
+    for k in sd[0]:
+        np.testing.assert_array_equal(sd[0][k], sd[1][k], err_msg=k)                # bit-identical replicas
+    if rank == 0:
+        torch.save({k: torch.from_numpy(v) for k, v in sd[0].items()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_the_hip_models_equal_one_process_on_the_joint_batch(tmp_path):
+    if not has_gpu():
+        pytest.skip("needs a GPU")
+    out = str(tmp_path / "sd.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    import speech_imagery_eeg_amd  # noqa: F401
+    from ign_hip.ddp import FlatAdam, FlatParamBucket
+    from models.Shapelet import ShapeBottleneckModel
+    torch.manual_seed(100)
+    model = ShapeBottleneckModel(_cfg(), [5, 3], [0.2, 0.5]).cuda().train()
+    bucket = FlatParamBucket(model, 1)
+    opt = FlatAdam(bucket, lr=5e-3)
+    xs, ys = _data()
+    _train(model, bucket, opt, xs, ys, slice(0, 16))
+    ddp = torch.load(out, weights_only=True)
+    for k, v in model.state_dict().items():
+        # the gradient of the mean over 16 = the mean of the two 8-sample means, up to fp32 summation order (then Adam's
+        # normalisation: the band of tests/test_gpu_models.py::test_three_adam_steps)
+        a, b = ddp[k].double().numpy(), v.double().cpu().numpy()
+        diff = np.abs(a - b)
+        assert (diff > 5e-4 + 5e-3 * np.abs(b)).mean() <= 0.05 and diff.max() <= 3 * 2 * 5e-3 + 1e-6, k
