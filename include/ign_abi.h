@@ -205,11 +205,6 @@ int ign_conv1_sumsq_fwd(const float* x, const float* w1, const float* mu, float*
 int ign_conv1_sumsq_bwd(const float* x, const float* w1, const float* mu, float* g_fj, void* workspace,
                         int rows, int T, int F1, int k1, int pad_left, void* stream);
 
-/* y = LayerNorm(x + add) in one pass (`x = self.norm1(x + dropout(new_x))`, IGN/layers/Transformer_EncDec.py:44-45,50);
- * sum_out receives x + add, the tensor ign_layernorm_bwd then takes as its `x`.                                            */
-int ign_add_layernorm_fwd(const float* x, const float* add, float* sum_out, const float* gamma, const float* beta, float* y,
-                          float* mean, float* rstd, long long R, int D, float eps, void* stream);
-
 /* LayerNorm over the last dimension of an (R, D) matrix (nn.LayerNorm semantics: biased variance, eps inside the sqrt), forward
  * and backward; D % 4 == 0, D <= 4096 (backward: D <= 2048).  fwd saves mean / rstd (R each).  bwd: gx and, when not NULL,
  * dgamma / dbeta (fixed-order two-pass reduction: reproducible); part = ign_layernorm_parts(R, D) * 2 * D floats of workspace.
@@ -319,12 +314,6 @@ int ign_clconv_dgrad_x6(const float* dyp, const void* wt3_dgrad, const float* y_
 size_t ign_clconv_wgrad_x6_workspace_bytes(int B, int Tin, int Ci, int Co, int k);
 int ign_clconv_wgrad_x6(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
                         float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream);
-/* y = x W^T + bias + res for a Linear layer (split-bf16 GEMM, k = 1): `res` (M, Co) is added in the epilogue -- the residual
- * connection of an encoder layer (IGN/layers/Transformer_EncDec.py:44,50; nn.TransformerEncoderLayer) or, in the backward, the
- * gradient that autograd would add to this product in a separate pass.  wt3 from ign_clconv_pack_weights_x3.             */
-int ign_linear_fwd_res_x6(const float* x, const void* wt3, const float* bias, const float* res, float* y, long long M, int Ci,
-                          int Co, int bf16, void* stream);
-
 /* The three split-bf16 GEMMs with ONE product per step: operands rounded to bf16 (round-to-nearest-even), products and sums in
  * fp32 -- the arithmetic of the reference's default bf16-autocast mode (IGN/exp/experiment_classification.py:319; `--amp`
  * switches it OFF).  Same packed weights (plane 0 is read), same arguments, same workspace as the *_x6 entry points.        */

@@ -57,8 +57,6 @@ struct GemmNTArgs {
     const float* ey; const float* ea; const float* eb; const float* emean; const float* einv;
     int mtiles, ntiles;
     const unsigned short* B3; int Kp;          // split-bf16 kernels: Bt as 3 bf16 planes (3, N, Kp), Kp = K rounded up to 8
-    const float* res;                          // EPI_BIAS_STATS: dense (M, N) matrix added to the output (residual / gradient
-                                               // accumulation fused into the GEMM epilogue), or null
 };
 
 // ---- epilogue shared by the fp32 and the split-bf16 kernels.  Lane (l31, h) of accumulator (i, j) holds column
@@ -98,7 +96,6 @@ __device__ __forceinline__ void nt_epilogue_body(const GemmNTArgs& a, const f32x
                 float v = acc[i][j][r];
                 if (EPI == EPI_BIAS_STATS) {
                     v += bv;
-                    if (a.res && ok) v += a.res[(long long)m * a.N + n];
                     if (ok) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
                 } else {
                     v = (fmaf(ea, yv[r], eb) > 0.f) ? v : 0.f;

@@ -328,8 +328,7 @@ extern "C" int ign_clconv_pack_weights(const float* w_oik, float* wt_fwd, float*
 
 // x6: 0 = fp32 MFMA, 6 = split bf16 (six products), 1 = operands rounded to bf16 (one product)
 static int clconv_fwd_impl(const char* who, int x6, const float* x, const void* wt, const float* bias, const float* pro_a,
-                           const float* pro_b, float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream,
-                           const float* res = nullptr) {
+                           const float* pro_b, float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream) {
     const int Tout = Tin - k + 1;
     if (!x || !wt || !y || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || ((pro_a == nullptr) != (pro_b == nullptr))) {
         ign_set_error("%s: bad argument (B=%d Tin=%d Ci=%d Co=%d k=%d)", who, B, Tin, Ci, Co, k);
@@ -341,7 +340,7 @@ static int clconv_fwd_impl(const char* who, int x6, const float* x, const void* 
     a.A = x; a.am = RowMap{Tout, 0, Ci, (long long)Tin * Ci}; a.K = k * Ci;
     a.Bt = x6 ? nullptr : (const float*)wt; a.ldb = k * Ci; a.C = y; a.M = (int)M; a.N = Co; a.bias = bias;
     a.B3 = x6 ? (const unsigned short*)wt : nullptr; a.Kp = 0;
-    a.pro_a = pro_a; a.pro_b = pro_b; a.pro_c = Ci; a.part = stat_part; a.res = res;
+    a.pro_a = pro_a; a.pro_b = pro_b; a.pro_c = Ci; a.part = stat_part;
     a.mtiles = (int)((M + TM - 1) / TM); a.ntiles = (Co + TN - 1) / TN;
     IgnScopedTimer tm("clconv_fwd", (hipStream_t)stream);
     if (x6) {
@@ -364,16 +363,6 @@ extern "C" int ign_clconv_fwd(const float* x, const float* wt, const float* bias
 extern "C" int ign_clconv_fwd_x6(const float* x, const void* wt3, const float* bias, const float* pro_a, const float* pro_b,
                                  float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream) {
     return clconv_fwd_impl("ign_clconv_fwd_x6", 6, x, wt3, bias, pro_a, pro_b, y, stat_part, B, Tin, Ci, Co, k, stream);
-}
-
-// y = x W^T + bias + res for a Linear layer (k = 1): the residual connection of an encoder layer, or -- in the backward -- the
-// gradient that autograd would otherwise add to this GEMM's result in a separate pass, fused into the epilogue.  res (M, Co) may
-// alias nothing that the call writes.  bf16 != 0: the single-product autocast form.
-extern "C" int ign_linear_fwd_res_x6(const float* x, const void* wt3, const float* bias, const float* res, float* y, long long M,
-                                     int Ci, int Co, int bf16, void* stream) {
-    if (M <= 0 || M > 0x3fffffffLL) { ign_set_error("ign_linear_fwd_res_x6: bad M=%lld", M); return IGN_E_ARG; }
-    return clconv_fwd_impl("ign_linear_fwd_res_x6", bf16 ? 1 : 6, x, wt3, bias, nullptr, nullptr, y, nullptr, 1, (int)M, Ci, Co, 1,
-                           stream, res);
 }
 
 extern "C" int ign_clconv_fwd_bf16(const float* x, const void* wt3, const float* bias, const float* pro_a, const float* pro_b,

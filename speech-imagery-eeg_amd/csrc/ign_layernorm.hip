@@ -14,8 +14,6 @@ constexpr int LN_ITERS_MAX = 32;              // row groups per wave (fewer when
 
 struct LnArgs {
     const float *x, *gy, *gamma, *beta, *mean_in, *rstd_in;
-    const float* add;                         // forward: y = LN(x + add), the sum written to sum_out (kept for the backward)
-    float* sum_out;
     float *y, *gx, *mean, *rstd, *part;       // part: (nblocks, 2, D)
     long long R;
     int D, G, nv;                             // lanes per row, float4 pieces per lane
@@ -47,19 +45,12 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const LnArgs a) {
         if (row0 + (long long)it * rpw >= a.R) break;               // wave-uniform
         const bool ok = r < a.R;
         const float4* xr = reinterpret_cast<const float4*>(a.x + (ok ? r : a.R - 1) * a.D);
-        const float4* ar = a.add ? reinterpret_cast<const float4*>(a.add + (ok ? r : a.R - 1) * a.D) : nullptr;
-        float4* sr = (a.add && ok) ? reinterpret_cast<float4*>(a.sum_out + r * a.D) : nullptr;
         float4 xv[NV];
         float s = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int c = li + v * G;
             xv[v] = c < D4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ar && c < D4) {
-                const float4 av = ar[c];
-                xv[v] = make_float4(xv[v].x + av.x, xv[v].y + av.y, xv[v].z + av.z, xv[v].w + av.w);
-                if (sr) sr[c] = xv[v];
-            }
             s += (xv[v].x + xv[v].y) + (xv[v].z + xv[v].w);
         }
         const float mean = group_sum(s, G) * invD;
@@ -235,22 +226,6 @@ extern "C" int ign_layernorm_fwd(const float* x, const float* gamma, const float
     int rc;
     if ((rc = ln_geometry(who, R, D, &a.G, &a.nv, &nblk, &a.iters))) return rc;
     a.x = x; a.gamma = gamma; a.beta = beta; a.y = y; a.mean = mean; a.rstd = rstd; a.R = R; a.D = D; a.eps = eps;
-    IgnScopedTimer tm("layernorm_fwd", (hipStream_t)stream);
-    IGN_LN_DISPATCH(layernorm_fwd_kernel, a.nv, dim3((unsigned)nblk), 0, (hipStream_t)stream, a);
-    return ign_check_launch("layernorm_fwd_kernel");
-}
-
-// y = LayerNorm(x + add); sum_out receives x + add (the backward differentiates the norm at the sum)
-extern "C" int ign_add_layernorm_fwd(const float* x, const float* add, float* sum_out, const float* gamma, const float* beta, float* y,
-                                     float* mean, float* rstd, long long R, int D, float eps, void* stream) {
-    static const char* who = "ign_add_layernorm_fwd";
-    if (!x || !add || !sum_out || !gamma || !y || !mean || !rstd) { ign_set_error("%s: null pointer", who); return IGN_E_ARG; }
-    LnArgs a = {};
-    long long nblk;
-    int rc;
-    if ((rc = ln_geometry(who, R, D, &a.G, &a.nv, &nblk, &a.iters))) return rc;
-    a.x = x; a.add = add; a.sum_out = sum_out; a.gamma = gamma; a.beta = beta; a.y = y; a.mean = mean; a.rstd = rstd; a.R = R; a.D = D;
-    a.eps = eps;
     IgnScopedTimer tm("layernorm_fwd", (hipStream_t)stream);
     IGN_LN_DISPATCH(layernorm_fwd_kernel, a.nv, dim3((unsigned)nblk), 0, (hipStream_t)stream, a);
     return ign_check_launch("layernorm_fwd_kernel");

@@ -62,8 +62,6 @@ SIGNATURES = {
     "ign_bn_elu_pool_bwd_apply": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "ign_bn_fold_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ll, cf, cf, vp]),
     "ign_bn_fold_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ll, cf, vp]),
-    "ign_linear_fwd_res_x6": (ci, [vp, vp, vp, vp, vp, ll, ci, ci, ci, vp]),
-    "ign_add_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, cf, vp]),
     "ign_clconv_mtiles": (ll, [ll]),
     "ign_clconv_pack_weights": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "ign_clconv_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),

@@ -359,15 +359,8 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, Ci, device=g2.device, dtype=torch.float32)
-            res = getattr(ctx, "dx_res", None)          # EncoderLayerFn: a gradient to accumulate, fused into the GEMM epilogue
-            if res is not None:
-                res = res.reshape(M, Ci)
-                res = res if res.is_contiguous() else res.contiguous()
-                _lib.check(L.ign_linear_fwd_res_x6(_ptr(g2), _ptr(ctx.wd3), None, _ptr(res), _ptr(dx), M, Co, Ci, 1 if ctx.bf16 else 0,
-                                                   _stream()), "ign_linear_fwd_res_x6(dx)")
-            else:
-                _lib.check(_gemm(L, ctx.bf16)[0](_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, 1, M, Co, Ci, 1, _stream()),
-                           "ign_clconv_fwd_x6(dx)")
+            _lib.check(_gemm(L, ctx.bf16)[0](_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, 1, M, Co, Ci, 1, _stream()),
+                       "ign_clconv_fwd_x6(dx)")
             dx = dx.view(ctx.xshape)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
@@ -451,145 +444,6 @@ def layer_norm(x, norm):
             or x.numel() < LAYERNORM_MIN_ROWS * D):
         return norm(x)
     return LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
-
-
-class _Node:
-    """Stand-in for an autograd context: lets EncoderLayerFn call the forward / backward statics of the Functions above
-    directly, without autograd nodes (and their gradient-accumulation kernels) in between."""
-
-    def __init__(self, *needs):
-        self.needs_input_grad = tuple(needs)
-        self.saved_tensors = ()
-
-    def save_for_backward(self, *ts):
-        self.saved_tensors = ts
-
-    def mark_non_differentiable(self, *ts):
-        pass
-
-
-def _ln_fwd(x2, add2, w, b, eps):
-    """LayerNorm(x2 [+ add2]) on (R, D) rows -> (y, s, mean, rstd); s = the normalised input (x2 itself without add2)."""
-    L = _lib.lib()
-    R, D = x2.shape
-    y = torch.empty_like(x2)
-    mean = torch.empty(R, device=x2.device, dtype=torch.float32)
-    rstd = torch.empty(R, device=x2.device, dtype=torch.float32)
-    if add2 is None:
-        _lib.check(L.ign_layernorm_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), R, D, float(eps), _stream()),
-                   "ign_layernorm_fwd")
-        return y, x2, mean, rstd
-    ssum = torch.empty_like(x2)
-    _lib.check(L.ign_add_layernorm_fwd(_ptr(x2), _ptr(add2), _ptr(ssum), _ptr(w), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), R, D,
-                                       float(eps), _stream()), "ign_add_layernorm_fwd")
-    return y, ssum, mean, rstd
-
-
-def _ln_bwd(s2, g2, w, mean, rstd, has_bias):
-    L = _lib.lib()
-    R, D = s2.shape
-    gx = torch.empty_like(s2)
-    dgamma = torch.empty(D, device=s2.device, dtype=torch.float32)
-    dbeta = torch.empty(D, device=s2.device, dtype=torch.float32) if has_bias else None
-    part = torch.empty(int(L.ign_layernorm_parts(R, D)) * 2 * D, device=s2.device, dtype=torch.float32)
-    _lib.check(L.ign_layernorm_bwd(_ptr(s2), _ptr(g2), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dgamma), _ptr(dbeta), _ptr(part),
-                                   R, D, _stream()), "ign_layernorm_bwd")
-    return gx, dgamma, dbeta
-
-
-class EncoderLayerFn(torch.autograd.Function):
-    """One post-norm encoder layer -- self-attention, residual, LayerNorm, two-layer feed-forward, residual, LayerNorm -- as ONE
-    autograd node: the reference's `EncoderLayer` (IGN/layers/Transformer_EncDec.py:39-51; separate q / k / v projections, 1x1-conv
-    feed-forward, gelu or relu) and `nn.TransformerEncoderLayer` of the EEG-CNN baseline (IGN/model/eegcnn.py:219-228; packed
-    in_proj, relu).  The arithmetic is exactly that of the individual ops above (their forward / backward statics are called
-    directly); what disappears are the element-wise passes in between:
-      * forward: `x + attn` and `x + ff` ride in the LayerNorm kernel (ign_add_layernorm_fwd);
-      * backward: the residual stream's gradient is added in the EPILOGUE of the input-gradient GEMM that produces the other
-        summand (ign_linear_fwd_res_x6) instead of by autograd's accumulation kernels -- six 0.25 ms passes per layer at the
-        Transformer baseline's shape, four launch-bound ones per layer in the EEG-CNN encoder.
-    params: packed   -> in_w, in_b, out_w, out_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b
-            separate -> q_w, q_b, k_w, k_b, v_w, v_b, out_w, out_b, n1_w, n1_b, l1_w, l1_b, l2_w, l2_b, n2_w, n2_b"""
-
-    @staticmethod
-    def forward(ctx, x, n_heads, scale, gelu, packed, eps1, eps2, *params):
-        _need_gpu("encoder_layer", x, *params)
-        B, S, d = x.shape
-        H, E = n_heads, d // n_heads
-        x = x.contiguous()
-        nodes = {}
-        if packed:
-            in_w, in_b, out_w, out_b, n1w, n1b, l1w, l1b, l2w, l2b, n2w, n2b = params
-            nodes["in"] = c = _Node(True, True, True)
-            qkv = LinearFn.forward(c, x, in_w, in_b)
-            nodes["att"] = c = _Node(True, False)
-            o = PackedAttentionFn.forward(c, qkv.view(B, S, 3, H, E), scale)
-        else:
-            qw, qb, kw, kb, vw, vb, out_w, out_b, n1w, n1b, l1w, l1b, l2w, l2b, n2w, n2b = params
-            proj = []
-            for name, w, b in (("q", qw, qb), ("k", kw, kb), ("v", vw, vb)):
-                nodes[name] = c = _Node(True, True, True)
-                proj.append(LinearFn.forward(c, x, w, b).view(B, S, H, E))
-            nodes["att"] = c = _Node(True, True, True, False)
-            o = AttentionFn.forward(c, proj[0], proj[1], proj[2], scale)
-        nodes["out"] = c = _Node(True, True, True)
-        a = LinearFn.forward(c, o.reshape(B, S, d), out_w, out_b)
-        y1, s1, m1, r1 = _ln_fwd(x.view(-1, d), a.view(-1, d), n1w, n1b, eps1)
-        nodes["l1"] = c = _Node(True, True, True)
-        h = LinearFn.forward(c, y1.view(B, S, d), l1w, l1b)
-        act = torch.nn.functional.gelu(h) if gelu else torch.relu(h)
-        nodes["l2"] = c = _Node(True, True, True)
-        f = LinearFn.forward(c, act, l2w, l2b)
-        y2, s2, m2, r2 = _ln_fwd(y1, f.view(-1, d), n2w, n2b, eps2)
-        ctx.save_for_backward(s1, m1, r1, s2, m2, r2, h, n1w, n2w)
-        ctx.nodes, ctx.cfg = nodes, (B, S, d, H, E, bool(gelu), bool(packed), n1b is not None, n2b is not None)
-        return y2.view(B, S, d)
-
-    @staticmethod
-    def backward(ctx, g):
-        s1, m1, r1, s2, m2, r2, h, n1w, n2w = ctx.saved_tensors
-        B, S, d, H, E, gelu, packed, has_b1, has_b2 = ctx.cfg
-        nd = ctx.nodes
-        g2 = g.reshape(-1, d)
-        g2 = g2 if g2.is_contiguous() else g2.contiguous()
-        gs2, dn2w, dn2b = _ln_bwd(s2, g2, n2w, m2, r2, has_b2)
-        gact, dl2w, dl2b = LinearFn.backward(nd["l2"], gs2.view(B, S, d))
-        gh = torch.ops.aten.gelu_backward(gact, h) if gelu else torch.ops.aten.threshold_backward(gact, h, 0)
-        nd["l1"].dx_res = gs2                                      # d/dy1 = through the feed-forward + the residual, one GEMM
-        gy1, dl1w, dl1b = LinearFn.backward(nd["l1"], gh)
-        gs1, dn1w, dn1b = _ln_bwd(s1, gy1.view(-1, d), n1w, m1, r1, has_b1)
-        go, dow, dob = LinearFn.backward(nd["out"], gs1.view(B, S, d))
-        if packed:
-            gqkv = PackedAttentionFn.backward(nd["att"], go.view(B, S, H, E))[0]
-            nd["in"].dx_res = gs1                                  # d/dx = through the attention branch + the residual
-            gx, dinw, dinb = LinearFn.backward(nd["in"], gqkv.view(B, S, 3 * d))
-            grads = (dinw, dinb, dow, dob, dn1w, dn1b, dl1w, dl1b, dl2w, dl2b, dn2w, dn2b)
-        else:
-            gq, gk, gv = AttentionFn.backward(nd["att"], go.view(B, S, H, E))[:3]
-            nd["q"].dx_res = gs1                                   # residual + three projections: a chain of fused accumulations
-            gx, dqw, dqb = LinearFn.backward(nd["q"], gq.view(B, S, d))
-            nd["k"].dx_res = gx
-            gx, dkw, dkb = LinearFn.backward(nd["k"], gk.view(B, S, d))
-            nd["v"].dx_res = gx
-            gx, dvw, dvb = LinearFn.backward(nd["v"], gv.view(B, S, d))
-            grads = (dqw, dqb, dkw, dkb, dvw, dvb, dow, dob, dn1w, dn1b, dl1w, dl1b, dl2w, dl2b, dn2w, dn2b)
-        return (gx.view(B, S, d), None, None, None, None, None, None) + grads
-
-
-def encoder_layer_supported(x, d_ff, n_heads, params, norms, dropouts_active):
-    """the fused node covers the shapes the individual kernels cover; anything else takes the op-by-op path"""
-    if dropouts_active or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3) or ATTN_MATH != "bf16x6" \
-            or LINEAR_WGRAD != "bf16x6":
-        return False
-    d = x.shape[-1]
-    if d % n_heads or (d // n_heads) not in (16, 32, 64) or d % 4 or d_ff % 4 or d > 2048 or x.numel() // d >= (1 << 30):
-        return False
-    if any(p is None or p.dtype != torch.float32 or not p.is_cuda for p in params):
-        return False
-    return all(n.weight is not None and len(n.normalized_shape) == 1 for n in norms)
-
-
-def encoder_layer(x, n_heads, scale, gelu, packed, eps1, eps2, *params):
-    return EncoderLayerFn.apply(x, n_heads, scale, gelu, packed, eps1, eps2, *params)
 
 
 class ConvCLFn(torch.autograd.Function):

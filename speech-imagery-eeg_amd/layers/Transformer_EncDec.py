@@ -1,7 +1,6 @@
 """Encoder stack of the Transformer baseline (IGN/layers/Transformer_EncDec.py:27-80): post-norm layers with a
 1x1-Conv1d feed-forward, and a final LayerNorm.  Decoder / ConvLayer of the reference file are unused by the
 classification path and not rebuilt."""
-import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -20,33 +19,7 @@ class EncoderLayer(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.activation = F.relu if activation == "relu" else F.gelu
 
-    def _fused(self, x):
-        """the whole layer as one autograd node (ops.EncoderLayerFn) when it is the plain self-attention layer of the
-        classification path: FullAttention without mask / attention maps, no active dropout, shapes the kernels cover"""
-        from layers.SelfAttention_Family import AttentionLayer, FullAttention
-        al = self.attention
-        if not isinstance(al, AttentionLayer) or not isinstance(al.inner_attention, FullAttention) or torch.is_autocast_enabled():
-            return None
-        fa = al.inner_attention
-        if fa.mask_flag or fa.output_attention or fa.scale is not None:
-            return None
-        drop = self.training and (self.dropout.p > 0 or fa.dropout.p > 0)
-        d = x.shape[-1]
-        params = (al.query_projection.weight, al.query_projection.bias, al.key_projection.weight, al.key_projection.bias,
-                  al.value_projection.weight, al.value_projection.bias, al.out_projection.weight, al.out_projection.bias,
-                  self.norm1.weight, self.norm1.bias, self.conv1.weight.squeeze(-1), self.conv1.bias,
-                  self.conv2.weight.squeeze(-1), self.conv2.bias, self.norm2.weight, self.norm2.bias)
-        if al.query_projection.out_features != d or al.value_projection.out_features != d or self.conv1.kernel_size != (1,) \
-                or not ops.encoder_layer_supported(x, self.conv1.out_channels, al.n_heads, params, (self.norm1, self.norm2), drop):
-            return None
-        return ops.encoder_layer(x, al.n_heads, 1.0 / (d // al.n_heads) ** 0.5, self.activation is F.gelu, False, self.norm1.eps,
-                                 self.norm2.eps, *params)
-
     def forward(self, x, attn_mask=None, tau=None, delta=None):
-        if attn_mask is None and tau is None and delta is None:
-            y = self._fused(x)
-            if y is not None:
-                return y, None
         new_x, attn = self.attention(x, x, x, attn_mask=attn_mask, tau=tau, delta=delta)
         x = ops.layer_norm(x + self.dropout(new_x), self.norm1)
         # the k=1 convolutions are plain GEMMs over (B*T, d): apply them without the two transposes

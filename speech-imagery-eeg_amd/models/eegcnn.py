@@ -193,17 +193,9 @@ _BN1_VARIANCE = os.environ.get("IGN_EEG_BN1", "gram")
 
 
 def _encoder_layer_forward(layer, x, n_heads):
-    """One post-norm nn.TransformerEncoderLayer (relu): as ONE fused autograd node (ops.EncoderLayerFn: residual adds in the
-    LayerNorm kernel, gradient accumulations in the GEMM epilogues) when its shapes are covered and no dropout is active,
-    otherwise op by op with the fused attention core."""
+    """One post-norm nn.TransformerEncoderLayer (relu) evaluated with the fused attention core."""
     B, S, d = x.shape
     sa = layer.self_attn
-    drop = layer.training and any(m.p > 0 for m in (layer.dropout, layer.dropout1, layer.dropout2))
-    params = (sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, layer.norm1.weight, layer.norm1.bias,
-              layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias)
-    if ops.encoder_layer_supported(x, layer.linear1.out_features, n_heads, params, (layer.norm1, layer.norm2), drop) \
-            and not torch.is_autocast_enabled():
-        return ops.encoder_layer(x, n_heads, 1.0 / math.sqrt(d // n_heads), False, True, layer.norm1.eps, layer.norm2.eps, *params)
     qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias).view(B, S, 3, n_heads, d // n_heads)
     o = ops.attention_packed(qkv, 1.0 / math.sqrt(d // n_heads))      # gradients land in one packed buffer
     a = ops.linear(o.reshape(B, S, d), sa.out_proj.weight, sa.out_proj.bias)
