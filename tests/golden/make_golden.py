@@ -837,7 +837,32 @@ def case_driver_smoke(R):
     save("driver_smoke", **out)
 
 
-CASES.update(transformer_ch512=case_transformer_ch512, eegcnn_ch512=case_eegcnn_ch512, train_steps_r2=case_train_steps_r2,
+def case_sbm_ch_6x10(R):
+    """The SBM / LTS registry entries at the CHISCO shape with the bank the driver gives them (6 lengths x 10 shapelets,
+    exp:264-270): B=2 (the reference materialises ~7.4 GB per sample here), parameters from seeded_fill, gradients compact."""
+    S = R["Shapelet"]
+    c = cfg(enc_in=122, seq_len=1000, num_class=3, c_out=3)
+    lens = [0.05, 0.1, 0.2, 0.3, 0.5, 0.8]
+    g = torch.Generator().manual_seed(231)
+    x = torch.randn(2, 1000, 122, generator=g)
+    y = torch.tensor([1, 2])
+    for name, cls in (("sbm_ch_6x10", "ShapeBottleneckModel"), ("lts_ch_6x10", "DistThresholdSBM")):
+        torch.manual_seed(0)
+        m = seeded_fill(getattr(S, cls)(configs=c, num_shapelet=[10] * 6, shapelet_len=lens), 231)
+        with torch.no_grad():                                   # shapelets at the scale of the normalised input, thresholds in (0, 1)
+            for sh in m.shapelets:
+                sh.weights.mul_(sh.weights.shape[-1] ** 0.5)
+                if hasattr(sh, "threshold"):
+                    sh.threshold.abs_().mul_(10.0)
+        m.train()
+        out, info = m(x)
+        loss = torch.nn.functional.cross_entropy(out, y) + info.loss.mean()
+        loss.backward()
+        save(name, x=npy(x), y=npy(y), seed=np.int64(231), out=npy(out), p=npy(info.p), d=npy(info.d), model_loss=npy(info.loss),
+             train_loss=npy(loss), **grads_compact(m, "grad"))
+
+
+CASES.update(sbm_ch_6x10=case_sbm_ch_6x10, transformer_ch512=case_transformer_ch512, eegcnn_ch512=case_eegcnn_ch512, train_steps_r2=case_train_steps_r2,
              ign_transformer=case_ign_transformer, shapelet_ch=case_shapelet_ch, driver_smoke=case_driver_smoke)
 
 

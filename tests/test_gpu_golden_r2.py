@@ -206,3 +206,39 @@ def test_shapelet_bank_chisco_row_and_strided_golden(name):
     parity("grad_w", w.grad, g["grad_w"], kind="scale")
     if lts:
         parity("grad_thr", thr.grad, g["grad_thr"], kind="scale")
+
+
+@pytest.mark.parametrize("name,lts", [("sbm_ch_6x10", False), ("lts_ch_6x10", True)])
+def test_sbm_and_lts_at_the_chisco_shape_with_the_6x10_bank(name, lts):
+    """`--model SBM` / `--model LTS` as the driver builds them (6 lengths x 10 shapelets, exp:264-270) at C 122, T 1000: outputs,
+    every ModelInfo field, loss and all gradients against the reference's own run (B=2: ~7.4 GB per sample there)."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from models.Shapelet import DistThresholdSBM, ShapeBottleneckModel
+    g = golden(name)
+    cfg = make_cfg(enc_in=122, seq_len=1000, num_class=3, c_out=3)
+    torch.manual_seed(0)
+    m = seeded_fill((DistThresholdSBM if lts else ShapeBottleneckModel)(cfg, [10] * 6, [0.05, 0.1, 0.2, 0.3, 0.5, 0.8]), int(g["seed"]))
+    with torch.no_grad():                      # the same rescaling make_golden.py applies after the fill
+        for sh in m.shapelets:
+            sh.weights.mul_(sh.weights.shape[-1] ** 0.5)
+            if hasattr(sh, "threshold"):
+                sh.threshold.abs_().mul_(10.0)
+    m.to(dev).train()
+    x, y = _t(g["x"], dev), _t(g["y"], dev)
+    out, info = m(x)
+    loss = F.cross_entropy(out, y) + info.loss.mean()
+    loss.backward()
+    for k, v in (("out", out), ("p", info.p), ("d", info.d), ("model_loss", info.loss), ("train_loss", loss)):
+        parity(k, v, g[k], kind="elem")
+    gmax = max(float(np.abs(g[k]).max()) for k in g if k.startswith(("grad.", "gradsample.")))
+    n_checked = 0
+    for n, p in m.named_parameters():
+        if "grad." + n in g:
+            parity("grad." + n, p.grad, g["grad." + n], kind="scale", floor=1e-4 * gmax)
+        else:
+            idx = _sample_idx(p.numel()).to(p.device)
+            parity("gradsample." + n, p.grad.flatten()[idx], g["gradsample." + n], kind="scale", floor=1e-4 * gmax)
+            parity("gradnorm." + n, p.grad.double().norm(), g["gradnorm." + n], kind="scale")
+        n_checked += 1
+    assert n_checked == (13 if lts else 7)

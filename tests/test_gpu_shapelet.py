@@ -153,6 +153,42 @@ def test_shapelet_vs_oracle_random(B, C, T, K, L, mode):
     _grad_close(wg.grad, wo.grad.numpy(), f"B{B} C{C} T{T} K{K} L{L}")
 
 
+@pytest.mark.parametrize("B,C,T,K,L,mode", [
+    (4, 122, 1000, 5, 100, 0),     # CHISCO row, TT=15
+    (3, 122, 1000, 10, 500, 0),    # two K-tiles, JJ=8 backward
+    (5, 3, 200, 7, 33, 0),         # K = 5 + 2 tiles, odd L
+    (2, 4, 1300, 3, 10, 0),        # two passes per row: the soft-min statistics are merged across passes
+    (3, 5, 300, 4, 50, 1),         # LTS over the MSE distance
+    (3, 5, 300, 5, 50, 2),         # ... cosine
+    (3, 5, 120, 6, 3, 0),          # minimum shapelet length
+    (2, 3, 50, 2, 50, 0),          # a single window: soft-min weight 1
+])
+def test_lts_gate_vs_oracle_random(B, C, T, K, L, mode):
+    """The LTS soft-min / threshold gate (IGN/model/Shapelet.py:96-111) over the same seeded shape sweep the RBF gate gets:
+    p, d_min, grad_w and grad_threshold against the oracle."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    from oracle import ign_oracle as O
+    g = torch.Generator().manual_seed(B * 1000 + L + 7)
+    x = torch.randn(B, T, C, generator=g)
+    w0 = torch.randn(K, C, L, generator=g)
+    t0 = torch.rand(1, K, C, generator=g) * 2.0
+    r = torch.randn(B, K * C, generator=g)
+    xn_o = O.instance_norm(x)
+    wo, to = w0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
+    po, do = O.lts_softmin_gate(O.window_distance(xn_o, wo, 1, mode, chunk=8), to)
+    (po * r).sum().backward()
+    xn, _ = ops.instance_norm(x.to(dev))
+    wg, tg = w0.clone().to(dev).requires_grad_(True), t0.clone().to(dev).requires_grad_(True)
+    p, dmin = ops.shapelet_bank(xn, [wg], 1.0, mode | ops.GATE_LTS, thresholds=[tg])
+    (p * r.to(dev)).sum().backward()
+    _close(p, po, msg="p")
+    _close(dmin, do, msg="dmin")
+    _grad_close(wg.grad, wo.grad.numpy(), f"w B{B} C{C} T{T} K{K} L{L} mode{mode}")
+    _grad_close(tg.grad, to.grad.numpy(), "threshold")
+
+
 def test_strided_windows_forward():
     """seq_len >= 3000 switches the reference to stride int(log2(L)) (Shapelet.py:162): TT=1 kernel path."""
     dev = _dev()

@@ -139,3 +139,25 @@ def test_oracle_three_adam_steps_sbm(which):
         opt.step()
         opt.zero_grad()
         assert abs(loss.item() - g["losses"][i]) < 1e-5 * max(1.0, abs(g["losses"][i]))
+
+
+@pytest.mark.parametrize("name,lts", [("sbm_ch_6x10", False), ("lts_ch_6x10", True)])
+def test_oracle_sbm_and_lts_at_the_chisco_shape_with_the_6x10_bank(name, lts):
+    g = golden(name)
+    cfg = make_cfg(enc_in=122, seq_len=1000, num_class=3, c_out=3)
+    torch.manual_seed(0)
+    m = seeded_fill(O.OracleSBM(cfg, [10] * 6, [0.05, 0.1, 0.2, 0.3, 0.5, 0.8], lts=lts), int(g["seed"]))
+    with torch.no_grad():
+        for sh in m.shapelets:
+            sh.weights.mul_(sh.weights.shape[-1] ** 0.5)
+            if getattr(sh, "threshold", None) is not None:
+                sh.threshold.abs_().mul_(10.0)
+    m.train()
+    out, info = m(_t(g["x"]))
+    loss = F.cross_entropy(out, _t(g["y"])) + info.loss.mean()
+    loss.backward()
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], **TOL)
+    np.testing.assert_allclose(info.p.detach().numpy(), g["p"], **TOL)
+    np.testing.assert_allclose(info.d.detach().numpy(), g["d"], **TOL)
+    assert abs(loss.item() - float(g["train_loss"])) < 2e-5
+    assert _grad_check(dict(m.named_parameters()), g) == (13 if lts else 7)
