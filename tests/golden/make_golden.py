@@ -858,8 +858,11 @@ def case_sbm_ch_6x10(R):
         out, info = m(x)
         loss = torch.nn.functional.cross_entropy(out, y) + info.loss.mean()
         loss.backward()
+        # shapelet gradients as per-(k, c) row norms + the fixed sample: a straight-through arg-max that flips between two windows
+        # whose gate values tie to the last bit changes ONE row of the gradient; the test leaves such rows out (see there)
+        rows = {f"gradrownorm.{k}": npy(p_.grad.double().norm(dim=-1)) for k, p_ in m.named_parameters() if p_.grad.dim() == 3}
         save(name, x=npy(x), y=npy(y), seed=np.int64(231), out=npy(out), p=npy(info.p), d=npy(info.d), model_loss=npy(info.loss),
-             train_loss=npy(loss), **grads_compact(m, "grad"))
+             train_loss=npy(loss), **grads_compact(m, "grad"), **rows)
 
 
 CASES.update(sbm_ch_6x10=case_sbm_ch_6x10, transformer_ch512=case_transformer_ch512, eegcnn_ch512=case_eegcnn_ch512, train_steps_r2=case_train_steps_r2,

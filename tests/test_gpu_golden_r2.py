@@ -211,10 +211,17 @@ def test_shapelet_bank_chisco_row_and_strided_golden(name):
 @pytest.mark.parametrize("name,lts", [("sbm_ch_6x10", False), ("lts_ch_6x10", True)])
 def test_sbm_and_lts_at_the_chisco_shape_with_the_6x10_bank(name, lts):
     """`--model SBM` / `--model LTS` as the driver builds them (6 lengths x 10 shapelets, exp:264-270) at C 122, T 1000: outputs,
-    every ModelInfo field, loss and all gradients against the reference's own run (B=2: ~7.4 GB per sample there)."""
+    every ModelInfo field, loss and all gradients against the reference's own run (B=2: ~7.4 GB per sample there).
+
+    14 640 (sample, shapelet, channel) rows x ~900 windows: a few rows have their two best windows tie to the last bit, and the
+    straight-through arg-max (Shapelet.py:79 / :101) is discontinuous there -- whichever window an implementation's summation
+    order favours gets the hard part of the gradient.  The test finds those rows from the oracle's distances (gate values of
+    the two best windows within 1e-6), requires the kernel's own choice to be one of the tied windows, bounds their number, and
+    compares the gradient on all other rows at 1e-4."""
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
     from models.Shapelet import DistThresholdSBM, ShapeBottleneckModel
+    from oracle import ign_oracle as O
     g = golden(name)
     cfg = make_cfg(enc_in=122, seq_len=1000, num_class=3, c_out=3)
     torch.manual_seed(0)
@@ -224,6 +231,7 @@ def test_sbm_and_lts_at_the_chisco_shape_with_the_6x10_bank(name, lts):
             sh.weights.mul_(sh.weights.shape[-1] ** 0.5)
             if hasattr(sh, "threshold"):
                 sh.threshold.abs_().mul_(10.0)
+    w_cpu = [sh.weights.detach().clone() for sh in m.shapelets]
     m.to(dev).train()
     x, y = _t(g["x"], dev), _t(g["y"], dev)
     out, info = m(x)
@@ -231,14 +239,37 @@ def test_sbm_and_lts_at_the_chisco_shape_with_the_6x10_bank(name, lts):
     loss.backward()
     for k, v in (("out", out), ("p", info.p), ("d", info.d), ("model_loss", info.loss), ("train_loss", loss)):
         parity(k, v, g[k], kind="elem")
+    # rows whose two best windows tie (from the oracle's distances), and the kernel's choice among them
+    xn_o = O.instance_norm(torch.from_numpy(g["x"]))
+    t_hip = info.t.cpu().long()
+    C, col, tie_rows, n_tie = 122, 0, [], 0
+    for gi, w in enumerate(w_cpu):
+        K = w.shape[0]
+        d = O.window_distance(xn_o, w, 1, O.MODE_L1, chunk=16)                     # (B, Tw, K, C)
+        score = -d if lts else torch.exp(-d.pow(2))                                 # arg-min d / arg-max p
+        top2 = score.topk(2, dim=1).values
+        tied = (top2[:, 0] - top2[:, 1]) <= 1e-6                                    # (B, K, C)
+        chosen = score.gather(1, t_hip[:, col:col + K * C].view(-1, 1, K, C)).squeeze(1)
+        assert float((top2[:, 0] - chosen).max()) <= 1e-6, f"group {gi}: the kernel's window is not a best window"
+        tie_rows.append(tied.any(dim=0))                                             # (K, C)
+        n_tie += int(tied.sum())
+        col += K * C
+    assert n_tie <= 0.005 * t_hip.numel(), n_tie
     gmax = max(float(np.abs(g[k]).max()) for k in g if k.startswith(("grad.", "gradsample.")))
     n_checked = 0
     for n, p in m.named_parameters():
         if "grad." + n in g:
             parity("grad." + n, p.grad, g["grad." + n], kind="scale", floor=1e-4 * gmax)
         else:
-            idx = _sample_idx(p.numel()).to(p.device)
-            parity("gradsample." + n, p.grad.flatten()[idx], g["gradsample." + n], kind="scale", floor=1e-4 * gmax)
-            parity("gradnorm." + n, p.grad.double().norm(), g["gradnorm." + n], kind="scale")
+            gi = int(n.split(".")[1])
+            keep = (~tie_rows[gi]).to(dev)                                           # (K, C)
+            idx = _sample_idx(p.numel())
+            row_ok = keep.flatten()[(idx // p.shape[-1]).to(dev)]
+            got, ref = p.grad.flatten()[idx.to(dev)][row_ok], torch.from_numpy(g["gradsample." + n]).to(dev)[row_ok]
+            parity("gradsample." + n, got, ref, kind="scale", floor=1e-4 * gmax)
+            rn = p.grad.double().norm(dim=-1)
+            parity("gradrownorm." + n, rn[keep], torch.from_numpy(g["gradrownorm." + n]).to(dev)[keep], kind="scale")
         n_checked += 1
     assert n_checked == (13 if lts else 7)
+    parity("rows left out as arg-max ties (count / 14640)", np.float64(n_tie / 14640.0), np.float64(0.0), tol=5e-3, kind="elem",
+           ref_is="bound on the number of tie rows, not a parity claim")

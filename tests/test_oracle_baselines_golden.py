@@ -160,4 +160,13 @@ def test_oracle_sbm_and_lts_at_the_chisco_shape_with_the_6x10_bank(name, lts):
     np.testing.assert_allclose(info.p.detach().numpy(), g["p"], **TOL)
     np.testing.assert_allclose(info.d.detach().numpy(), g["d"], **TOL)
     assert abs(loss.item() - float(g["train_loss"])) < 2e-5
-    assert _grad_check(dict(m.named_parameters()), g) == (13 if lts else 7)
+    # gradients: small tensors and the fixed samples of the large ones; rows whose arg-max ties to the last bit are allowed to
+    # differ (tests/test_gpu_golden_r2.py explains), so the sample check tolerates a handful of outliers
+    gmax = max(float(np.abs(g[k]).max()) for k in g if k.startswith(("grad.", "gradsample.")))
+    for k, p_ in m.named_parameters():
+        if "grad." + k in g:
+            assert float(np.abs(p_.grad.numpy() - g["grad." + k]).max()) <= 1e-4 * max(float(np.abs(g["grad." + k]).max()), 1e-4 * gmax), k
+        else:
+            idx = torch.linspace(0, p_.numel() - 1, 2048).long()
+            bad = np.abs(p_.grad.flatten()[idx].numpy() - g["gradsample." + k]) > 1e-4 * max(float(np.abs(g["gradsample." + k]).max()), 1e-4 * gmax)
+            assert bad.mean() <= 0.01, (k, bad.mean())
