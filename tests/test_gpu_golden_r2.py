@@ -260,6 +260,10 @@ def test_sbm_and_lts_at_the_chisco_shape_with_the_6x10_bank(name, lts):
     for n, p in m.named_parameters():
         if "grad." + n in g:
             parity("grad." + n, p.grad, g["grad." + n], kind="scale", floor=1e-4 * gmax)
+        elif not n.startswith("shapelets."):                     # the class weights: a function of the gate values only
+            idx = _sample_idx(p.numel()).to(dev)
+            parity("gradsample." + n, p.grad.flatten()[idx], g["gradsample." + n], kind="scale", floor=1e-4 * gmax)
+            parity("gradnorm." + n, p.grad.double().norm(), g["gradnorm." + n], kind="scale")
         else:
             gi = int(n.split(".")[1])
             keep = (~tie_rows[gi]).to(dev)                                           # (K, C)
