@@ -86,6 +86,16 @@ int ign_shapelet_fwd_bank(const float* xn_bct, int G, const float* const* w_kcl,
  *   workspace: ign_shapelet_bwd_workspace_bytes() bytes.
  * Gradients w.r.t. the input are not produced (inputs are data: IGN/exp/experiment_classification.py:315).
  * LTS: dloss/dthr is a (B,KC) elementwise reduction the caller forms from g_out and p_out.
+ * sign(0) convention (IGN_DIST_L1 only).  The reference differentiates |x - w| with aten::sgn, sign(0) = 0
+ * (IGN/model/Shapelet.py:74).  The kernel accumulates P_j = sum_{t: x > w} A_t and returns 2 P_j - sum_t A_t, which counts an
+ * element with x[b,c,t+j] == w[k,c,j] (bit-equal floats) as sign = -1.  Hence, exactly,
+ *     gw_kcl[k,c,j] = reference[k,c,j] - sum_{(b,t): x[b,c,t*stride+j] == w[k,c,j]} A[b,k,c,t],   A = -(dloss/dd[b,t,k,c]) / L,
+ * and the two agree wherever no sample is bit-equal to the weight it is compared with (always, for weights that an
+ * optimiser has moved; a shapelet initialised as a copy of an input window is the reachable exception -- and with the RBF gate
+ * a perfect-match window has d = 0, dp/dd = 0, so A = 0 there).  Forward outputs are unaffected.  Pinned by the reference
+ * fixtures tests/golden/shapelet_tie_{l1,lts}.npz: tests/test_gpu_shapelet.py::test_exact_ties_differ_from_sgn0_by_exactly_
+ * the_documented_term asserts this identity (and nothing else) at 1e-4.  Other distances have no kink (MSE: the factor x - w
+ * is 0 at a tie; cosine / pearson: smooth).
  * stride > 1 (IGN/model/Shapelet.py:162: int(log2 L) once seq_len >= 3000 -- run_uea.sh's MotorImagery, EigenWorms) is
  * served by a generic-step kernel; shapelets longer than 2048 positions are split over several blocks.  Rows up to
  * T ~ 40 000 fit the forward's LDS staging (160 KB per CU); beyond that both calls return IGN_E_TOOBIG.             */

@@ -371,6 +371,7 @@ __global__ void __launch_bounds__(64) dwconv1d_wave_kernel(const float* __restri
 }
 
 constexpr int XC_ROWS = 32;                        // rows per block and group
+constexpr int XC_NA = 4, XC_NB = 6;                // register prefetch of one pass: 256*XC_NA floats of a rows, 256*XC_NB of b rows
 template <int NT>
 __global__ void __launch_bounds__(256) xcorr_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part,
                                                     int nrows_g /* rows per group */, int Cc, int T, int K, int pl, int lpr, int T4,
@@ -389,7 +390,7 @@ __global__ void __launch_bounds__(256) xcorr_kernel(const float* __restrict__ a,
 #pragma unroll
         for (int j = 0; j < 32; ++j) acc[q][j] = 0.f;
     // rows are prefetched into registers one pass ahead: the global-load latency of pass p+1 runs under the FMAs of pass p
-    constexpr int NA = 4, NB = 6;                   // ceil(rpp*T4 / 256) <= 4, ceil(rpp*BL / 256) <= 6 for T <= 1024, K <= 128
+    constexpr int NA = XC_NA, NB = XC_NB;           // one pass = rpp*T4 <= 256 NA and rpp*BL <= 256 NB floats: xcorr_geometry picks lpr so
     float pa[NA], pb[NB];
     auto gload = [&](int rb) {
 #pragma unroll
@@ -457,11 +458,19 @@ __global__ void __launch_bounds__(256) xcorr_kernel(const float* __restrict__ a,
 static int xcorr_geometry(int T, int K, int* lpr, int* T4, int* BL, int* NT, size_t* lds) {
     if (T > 1024 || K > 128 || T < 1 || K < 1) return 0;
     *T4 = (T + 3) & ~3;
-    int l = 1;
-    while (l < *T4 / 4) l <<= 1;
-    *lpr = l;
     *NT = K <= 32 ? 1 : 4;
-    *BL = 4 * l + 32 * (*NT) + 8;                   // the last lane's last window: u0 + 32 (NT-1) + 36 <= 4 lpr + 32 NT + 4
+    // lanes per row: the smallest power of two that covers the row AND keeps one pass of 256 / lpr rows inside the kernel's
+    // register prefetch (rpp*T4 <= 256 XC_NA, rpp*BL <= 256 XC_NB).  Short rows would otherwise put more rows into a pass than
+    // the prefetch loops cover (T <= 64 at K <= 32, T <= 128 or 233..256 at K > 32) and leave the tail slots of bs_ unwritten.
+    int l = 1;
+    for (;; l <<= 1) {
+        const int bl = 4 * l + 32 * (*NT) + 8;      // the last lane's last window: u0 + 32 (NT-1) + 36 <= 4 lpr + 32 NT + 4
+        const int rpp_ = 256 / l;
+        if (l >= *T4 / 4 && rpp_ * (*T4) <= 256 * XC_NA && rpp_ * bl <= 256 * XC_NB) break;
+        if (l == 256) return 0;
+    }
+    *lpr = l;
+    *BL = 4 * l + 32 * (*NT) + 8;
     const int rpp = 256 / l;
     *lds = std::max((size_t)rpp * (*T4 + *BL), (size_t)4 * (*NT) * 32) * sizeof(float);
     return 1;
@@ -584,7 +593,8 @@ extern "C" int ign_dwconv1d_fwd(const float* x, const float* w, float* y, int B,
 
 extern "C" size_t ign_dwconv1d_bwd_weight_workspace_bytes(int B, int Cc, int k) {
     if (B <= 0 || Cc <= 0 || k <= 0) return 0;
-    const int nbs = std::max(1, std::min(B, 32));
+    // slabs of per-block partials: min(B, 32) batch slices (dwconv1d_bwd_w_kernel) or ceil(B / XC_ROWS) blocks of rows (xcorr_kernel)
+    const int nbs = std::max(std::max(1, std::min(B, 32)), (B + XC_ROWS - 1) / XC_ROWS);
     return (size_t)nbs * Cc * k * sizeof(float);
 }
 
@@ -598,7 +608,7 @@ extern "C" int ign_dwconv1d_bwd_weight(const float* x, const float* dy, float* d
         int lpr, T4, BL, NT; size_t l2;
         if (xcorr_geometry(T, k, &lpr, &T4, &BL, &NT, &l2)) {
             // dw[ch][j] = sum_{b,t} dy[b,ch,t] xpad[b,ch,t+j]: the cross-correlation kernel, group = channel, 32 samples per block
-            const int nsl = (B + XC_ROWS - 1) / XC_ROWS;              // <= min(B, 32): fits the workspace
+            const int nsl = (B + XC_ROWS - 1) / XC_ROWS;              // slabs: ign_dwconv1d_bwd_weight_workspace_bytes reserves max(min(B,32), nsl)
             {
                 IgnScopedTimer tm("dwconv1d_bwd_w", s);
                 if (NT == 1) hipLaunchKernelGGL(xcorr_kernel<1>, dim3(Cc, nsl), dim3(256), l2, s, dy, x, (float*)workspace, B, Cc, T, k,

@@ -55,8 +55,8 @@ __device__ __forceinline__ float wave_bcast_l63(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-// The body of one block: (bx, by) play the role of blockIdx.x / .y so that the single-group kernel and the bank kernel
-// (ign_shapelet_fwd_multi.hip: all length groups of a bank in ONE launch) share it.
+// The body of one block; (bx, by) play the role of blockIdx.x / .y (kept as parameters: round 2's one-grid bank kernel called the
+// same body with a remapped block index, measured slower and was removed -- DESIGN 4.1b).
 template <int TT, int KT, int DIST>
 __device__ __forceinline__ void shp_fwd_body(const ShpFwdArgs& a, const int bx, const int by, float* smem) {
     constexpr int J = FwdJ<TT>::J;

@@ -98,7 +98,7 @@ class ShapeletBankFn(torch.autograd.Function):
             col0 += K * C
         G = len(ws)
         if G <= 8:
-            # the whole bank in one call: one launch for all length groups on the headline path (ign_shapelet_fwd_bank)
+            # the whole bank in one call (ign_shapelet_fwd_bank validates every group, then launches group by group)
             vpa, ia = ctypes.c_void_p * G, ctypes.c_int * G
             pv = lambda ts: vpa(*[(t.data_ptr() if t is not None else None) for t in ts])
             _lib.check(L.ign_shapelet_fwd_bank(
@@ -441,7 +441,7 @@ def layer_norm(x, norm):
     # PatchTST: 3.9 M rows of 64, 123.9 -> 79.4 ms/step); for few rows (EEG-CNN: 25 600 rows of 512) the grid is sized by the row
     # count and the d(gamma) partials are reduced in parallel: 22 / 37 us per call against torch's 34 / 97 (7.52 -> 7.36 ms/step)
     if (not x.is_cuda or x.dtype != torch.float32 or norm.weight is None or len(norm.normalized_shape) != 1 or D % 4 or D > 2048
-            or x.numel() < LAYERNORM_MIN_ROWS * D):
+            or x.numel() == 0 or x.numel() < LAYERNORM_MIN_ROWS * D):
         return norm(x)
     return LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
 
@@ -791,18 +791,25 @@ def bn_elu_pool(v, bn, P, alpha=None, cshift=None):
     `alpha`, `cshift`: per-channel affine map y = alpha v + cshift applied in front of the BatchNorm (see BnEluPoolFn).
     Training mode uses batch statistics and updates the running ones like nn.BatchNorm2d; eval mode uses the running ones."""
     _need_gpu("bn_elu_pool", v)
+    C = v.shape[1]
+    # affine=False: the identity affine map (constants, no gradient)
+    gamma = bn.weight if bn.weight is not None else torch.ones(C, device=v.device, dtype=torch.float32)
+    beta = bn.bias if bn.bias is not None else torch.zeros(C, device=v.device, dtype=torch.float32)
     if bn.training or not bn.track_running_stats:
         track = bn.training and bn.track_running_stats
+        momentum = bn.momentum
         if track:
             bn.num_batches_tracked.add_(1)
-        return BnEluPoolFn.apply(v, alpha, cshift, bn.weight, bn.bias, P, bn.eps, bn.running_mean if track else None,
-                                 bn.running_var if track else None, bn.momentum)
+            if momentum is None:      # nn.BatchNorm with momentum=None: cumulative moving average, factor 1 / num_batches_tracked
+                momentum = 1.0 / float(bn.num_batches_tracked)
+        return BnEluPoolFn.apply(v, alpha, cshift, gamma, beta, P, bn.eps, bn.running_mean if track else None,
+                                 bn.running_var if track else None, momentum)
     # eval: z = gamma (alpha v + c - running_mean) / sqrt(running_var + eps) + beta -- an affine map, then the apply kernel
     r = torch.rsqrt(bn.running_var + bn.eps)
     a = alpha if alpha is not None else torch.ones_like(r)
     c = cshift if cshift is not None else torch.zeros_like(r)
-    scale = (bn.weight * a * r).contiguous()
-    shift = (bn.weight * (c - bn.running_mean) * r + bn.bias).contiguous()
+    scale = (gamma * a * r).contiguous()
+    shift = (gamma * (c - bn.running_mean) * r + beta).contiguous()
     return AffineEluPoolFn.apply(v, scale, shift, P)
 
 

@@ -27,11 +27,9 @@ class FullyConvNetwork(nn.Module):
     def forward(self, x, x_mark_enc=None, x_dec=None, x_mark_dec=None, mask=None, x_bct=None):
         if not x.is_cuda:
             raise ops._lib.IgnError(f"FCN expert: tensor on {x.device}; the deep experts run on the MI355X only (no CPU fallback)")
-        if x.dtype == torch.float32:
-            # x (B,T,C) is already the channels-last operand of the implicit GEMM: no transpose, no im2col
-            pooled = fcn.fcn_body(x, [(b[0], b[1]) for b in (self.block1, self.block2, self.block3)])
-        else:
-            h = x_bct if x_bct is not None else x.permute(0, 2, 1)
-            h = self.block3(self.block2(self.block1(h)))
-            pooled = self.pooling(h).flatten(start_dim=1)
+        # x (B,T,C) is already the channels-last operand of the implicit GEMM: no transpose, no im2col.  The kernels take fp32
+        # activations (inside an autocast region they round the GEMM operands to bf16 themselves): other dtypes are cast, never
+        # handed to a library convolution
+        pooled = fcn.fcn_body(x if x.dtype == torch.float32 else x.float(),
+                              [(b[0], b[1]) for b in (self.block1, self.block2, self.block3)])
         return ops.head_linear(pooled, self.fc.weight, self.fc.bias)

@@ -92,12 +92,16 @@ def parity(label, got, ref, tol=NORTH_STAR_TOL, kind="scale", floor=0.0, f64=Non
     rec = dict(max_abs_err=float(diff.max()) if diff.size else 0.0, scale=scale, kind=kind, tol=tol,
                err_over_1e4=budget / NORTH_STAR_TOL, against=ref_is)
     ok = budget <= tol
+    rec["passed_by"] = "fp32 reference within tol" if ok else "FAILED"
     if f64 is not None:
         t = _np64(f64)
         sc = max(float(np.abs(t).max()), floor, 1e-30)
         e_hip, e_ref = float(np.abs(g - t).max()) / sc, float(np.abs(r - t).max()) / sc
         rec.update(hip_vs_f64=e_hip, ref_fp32_vs_f64=e_ref)
-        ok = ok or e_hip <= max(tol, e_ref)
+        if not ok and e_hip <= max(tol, e_ref):
+            # the widened clause: recorded as such so the ledger shows every comparison that needed it
+            ok = True
+            rec["passed_by"] = "float64 clause: no further from the float64 run than the reference's own fp32 run"
     test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::", 1)[-1]
     _LEDGER.setdefault(test, {})[label] = rec
     if os.environ.get("IGN_PARITY_RECORD_ONLY") != "1":
@@ -118,6 +122,8 @@ def pytest_sessionfinish(session, exitstatus):
     with open(os.path.join(out, "parity.json"), "w") as f:
         json.dump(dict(north_star_tol=NORTH_STAR_TOL, n_records=len(recs), n_records_at_1e4=len(strict),
                        worst_at_1e4=None if worst is None else dict(test=worst[0], tensor=worst[1], **worst[2]),
+                       records_passed_by_the_float64_clause=[dict(test=t, tensor=l) for t, l, r in recs
+                                                             if str(r.get("passed_by", "")).startswith("float64")],
                        records_above_1e4_by_design=[dict(test=t, tensor=l, tol=r["tol"], err_over_1e4=r["err_over_1e4"],
                                                          why=r["against"]) for t, l, r in relaxed],
                        tests=_LEDGER), f, indent=1, sort_keys=True)

@@ -869,6 +869,36 @@ CASES.update(sbm_ch_6x10=case_sbm_ch_6x10, transformer_ch512=case_transformer_ch
              ign_transformer=case_ign_transformer, shapelet_ch=case_shapelet_ch, driver_smoke=case_driver_smoke)
 
 
+def case_shapelet_tie(R):
+    """Round 3: exact ties x == w (the one point where |.| has no derivative; autograd's aten::sgn gives sign(0) = 0,
+    IGN/model/Shapelet.py:74).  One shapelet equals a window of xn on every channel (a perfect match), three single elements of
+    the other shapelets equal single samples.  RBF gate and LTS gate, L1 distance; same tiny shape as `shapelet_modes`."""
+    S = R["Shapelet"]
+    B, C, T, K, L = 3, 4, 60, 3, 9
+    g = torch.Generator().manual_seed(17)
+    xn = torch.randn(B, C, T, generator=g)
+    r = torch.randn(B, K * C, generator=g)
+    for name, lts in (("l1", False), ("lts", True)):
+        torch.manual_seed(6)
+        cls = S.DistThresholdShapelet if lts else S.Shapelet
+        m = cls(dim_data=C, shapelet_len=L, num_shapelet=K, stride=1, eps=0.7, distance_func="euclidean")
+        with torch.no_grad():
+            m.weights[0] = xn[1, :, 20:29]                    # whole window, all channels
+            m.weights[1, 2, 4] = xn[0, 2, 13]                 # single elements
+            m.weights[2, 0, 0] = xn[2, 0, 5]
+            m.weights[2, 0, 8] = xn[2, 0, 50]
+        p, dmin = m(xn)
+        (p * r).sum().backward()
+        out = dict(xn=npy(xn), r=npy(r), w=npy(m.weights), eps=np.float32(0.7), p=npy(p), dmin=npy(dmin),
+                   grad_w=npy(m.weights.grad))
+        if lts:
+            out.update(thr=npy(m.threshold), grad_thr=npy(m.threshold.grad))
+        save(f"shapelet_tie_{name}", **out)
+
+
+CASES["shapelet_tie"] = case_shapelet_tie
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     names = sys.argv[1:] or list(CASES)

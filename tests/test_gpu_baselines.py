@@ -178,7 +178,10 @@ def test_conv1_sumsq_vs_torch(R, T, F1, k1):
     assert _rel(w.grad, wd.grad) < 1e-4        # (the reference grad includes d/dmu = 0 exactly: mu is the batch mean)
 
 
-@pytest.mark.parametrize("B,C,T,k", [(3, 64, 500, 25), (2, 64, 1000, 125), (2, 5, 37, 4), (1, 3, 16, 16)])
+# the last ten shapes: at least 32 samples per channel at short rows -- a pass of the cross-correlation kernel then holds many rows
+# (round-2 advisor finding: its register prefetch covered fewer rows than a pass, the tail rows multiplied unwritten LDS)
+@pytest.mark.parametrize("B,C,T,k", [(3, 64, 500, 25), (2, 64, 1000, 125), (2, 5, 37, 4), (1, 3, 16, 16)] +
+                         [(40, 3, T, k) for T in (16, 64, 100, 128, 250) for k in (25, 125)] + [(1100, 2, 64, 25)])
 def test_dwconv1d_vs_torch(B, C, T, k):
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
@@ -227,6 +230,32 @@ def test_eegcnn_block_matches_reference_ops_in_eval_and_train():
             for k in m.state_dict():
                 parity("sd." + k, m.state_dict()[k].float(), ref.state_dict()[k].float(), kind="scale",
                        ref_is="same module, layer-by-layer torch ops (fp32, GPU)")
+
+
+@pytest.mark.parametrize("T,k1", [(64, 25), (128, 125), (250, 125), (100, 25)])
+def test_eegcnn_train_step_at_short_rows_with_many_samples(T, k1):
+    """An EEGcnn training step (forward, backward, BatchNorm statistics) at short rows and 48 samples -- every pass of the
+    cross-correlation kernel is full -- against the layer-by-layer evaluation of the same module."""
+    dev = _dev()
+    import copy
+    import speech_imagery_eeg_amd  # noqa
+    from models.eegcnn import EEGcnn
+    torch.manual_seed(T + k1)
+    m = EEGcnn(Chans=9, kernLength1=k1, kernLength2=25, F1=4, D=2, F2=8, P1=2, P2=4, dropoutRate=0.0).to(dev)
+    ref = copy.deepcopy(m)
+    x = torch.randn(48, 9, T, device=dev) * 1.5 + 0.2
+    m.train(); ref.train()
+    a, b = m(x), ref._forward_reference_ops(x)
+    assert torch.isfinite(a).all()
+    parity(f"short rows T={T} k={k1}: out", a, b, kind="scale", ref_is="same module, layer-by-layer torch ops (fp32, GPU)")
+    ga = torch.autograd.grad(a.square().sum(), list(m.parameters()), allow_unused=True)
+    gb = torch.autograd.grad(b.square().sum(), list(ref.parameters()))
+    top = float(max(t.abs().max() for t in gb))
+    for (n, _), u, v in zip(m.named_parameters(), ga, gb):
+        if float(v.abs().max()) < 1e-4 * top:
+            continue                              # zero-gradient parameters (bias removed by the next BatchNorm)
+        assert u is not None and torch.isfinite(u).all(), n
+        parity(f"short rows T={T} k={k1}: grad." + n, u, v, kind="scale", ref_is="same module, layer-by-layer torch ops (fp32, GPU)")
 
 
 @pytest.mark.parametrize("shape,Co,bias", [((256, 100, 512), 256, True), ((3, 77, 64), 512, True), ((5, 130), 12, False),
@@ -530,7 +559,8 @@ def test_packed_attention_equals_unpacked(B, L, H, E):
     assert torch.equal(g1, torch.stack([gq, gk, gv], dim=2))
 
 
-@pytest.mark.parametrize("R,T,k,pl", [(7, 200, 125, 62), (33, 1000, 125, 62), (5, 64, 25, 12), (3, 130, 8, 0), (2, 129, 128, 127)])
+@pytest.mark.parametrize("R,T,k,pl", [(7, 200, 125, 62), (33, 1000, 125, 62), (5, 64, 25, 12), (3, 130, 8, 0), (2, 129, 128, 127)] +
+                         [(70, T, k, (k - 1) // 2) for T in (16, 64, 100, 128, 250) for k in (25, 125) if T >= k // 2])   # rows shorter than the padding: not a model shape
 def test_window_gram_matrix_equals_brute_force(R, T, k, pl):
     """EEGcnn._window_gram (lag sums from ign_autocorr_fwd + edge terms) against the brute-force Gram matrix of all padded windows
     in float64, and the quadratic form against sum_t (w (*) x)^2 of the convolution itself."""

@@ -99,6 +99,54 @@ def test_shapelet_golden_lts():
     _grad_close(thr.grad, g["grad_thr"], "lts thr")
 
 
+@pytest.mark.parametrize("name", ["l1", "lts"])
+def test_exact_ties_differ_from_sgn0_by_exactly_the_documented_term(name):
+    """x == w exactly.  The reference's gradient uses sign(0) = 0 (aten::sgn behind abs, IGN/model/Shapelet.py:74); the L1
+    backward kernel accumulates P = sum_{x > w} A and forms 2P - S, i.e. it counts a tie as sign = -1 (include/ign_abi.h,
+    ign_shapelet_bwd).  So   grad_kernel[k,c,j] = grad_ref[k,c,j] - sum_{(b,t): x[b,c,t+j] == w[k,c,j]} A[b,k,c,t],
+    A = -(dl/dd[b,t,k,c]) / L.  The fixture (reference run) plants one perfect-match shapelet and three single-element
+    ties; the tie term is evaluated from the oracle's dl/dd (the oracle is pinned to the same fixture) and the kernel must
+    equal reference-minus-tie-term at 1e-4 -- no other difference is allowed, forward values included."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    from oracle import ign_oracle as O
+    g = golden(f"shapelet_tie_{name}")
+    xn_c, w_c, r_c = _t(g["xn"]), _t(g["w"]), _t(g["r"])
+    lts = name == "lts"
+    # the tie term from the oracle
+    wo = w_c.clone().requires_grad_(True)
+    d = O.window_distance(xn_c, wo, 1, O.MODE_L1, chunk=7)
+    d.retain_grad()
+    if lts:
+        po, _ = O.lts_softmin_gate(d, _t(g["thr"]))
+    else:
+        po, _ = O.rbf_straight_through_max(d, float(g["eps"]))
+    (po * r_c).sum().backward()
+    B, C, T = xn_c.shape
+    K, _, L = w_c.shape
+    Tw = T - L + 1
+    A = -d.grad / L                                                   # (B, Tw, K, C)
+    win = xn_c.unfold(2, L, 1)                                        # (B, C, Tw, L)
+    tie = (win.permute(0, 2, 1, 3).unsqueeze(2) == w_c.view(1, 1, K, C, L))     # (B, Tw, K, C, L)
+    delta = (A.unsqueeze(-1) * tie).sum(dim=(0, 1))                   # (K, C, L)
+    assert int(tie.sum()) >= 3 + C * L
+    if lts:
+        assert float(delta[0].abs().max()) > 1e-3 * float(np.abs(g["grad_w"]).max())     # the perfect match carries gradient
+    assert float(delta[1:].abs().max()) > 1e-4 * float(np.abs(g["grad_w"]).max())       # the test has teeth
+    # the kernel
+    xn, r = xn_c.to(dev), r_c.to(dev)
+    w = w_c.to(dev).requires_grad_(True)
+    kw = dict(thresholds=[_t(g["thr"], dev).requires_grad_(True)]) if lts else {}
+    p, dmin = ops.shapelet_bank(xn, [w], float(g["eps"]), ops.DIST_L1 | (ops.GATE_LTS if lts else ops.GATE_RBF), **kw)
+    (p * r).sum().backward()
+    _close(p, g["p"], msg=f"tie {name} p")
+    _close(dmin, g["dmin"], msg=f"tie {name} dmin")
+    _grad_close(w.grad, g["grad_w"] - delta.numpy(), f"tie {name}: reference gradient minus the documented tie term")
+    if lts:
+        _grad_close(kw["thresholds"][0].grad, g["grad_thr"], f"tie {name} thr")
+
+
 def test_shapelet_bm_groups_one_bank():
     """The four driver-default groups of the BasicMotions shape in ONE bank call (column offsets, K=5 tiles)."""
     dev = _dev()

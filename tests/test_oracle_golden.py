@@ -41,6 +41,27 @@ def test_shapelet_lts():
     np.testing.assert_allclose(thr.grad.numpy(), g["grad_thr"], **TOL)
 
 
+@pytest.mark.parametrize("name", ["l1", "lts"])
+def test_shapelet_exact_ties_follow_sgn0(name):
+    """x == w exactly (a shapelet planted from the input, single planted elements): the reference's autograd uses
+    aten::sgn, sign(0) = 0 (IGN/model/Shapelet.py:74) -- so does the oracle."""
+    g = golden(f"shapelet_tie_{name}")
+    xn, w, r = _t(g["xn"]), _t(g["w"]).requires_grad_(True), _t(g["r"])
+    assert torch.equal(w[0].detach(), xn[1, :, 20:29]) and float(w[1, 2, 4]) == float(xn[0, 2, 13])
+    d = O.window_distance(xn, w, 1, O.MODE_L1, chunk=7)
+    if name == "lts":
+        thr = _t(g["thr"]).requires_grad_(True)
+        p, dmin = O.lts_softmin_gate(d, thr)
+    else:
+        p, dmin = O.rbf_straight_through_max(d, float(g["eps"]))
+    (p * r).sum().backward()
+    np.testing.assert_allclose(p.detach().numpy(), g["p"], **TOL)
+    np.testing.assert_allclose(dmin.detach().numpy(), g["dmin"], **TOL)
+    np.testing.assert_allclose(w.grad.numpy(), g["grad_w"], **TOL)
+    if name == "lts":
+        np.testing.assert_allclose(thr.grad.numpy(), g["grad_thr"], **TOL)
+
+
 def test_shapelet_bm_groups_and_instance_norm():
     g = golden("shapelet_bm")
     xn = O.instance_norm(_t(g["x"]))
