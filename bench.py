@@ -39,8 +39,11 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 (never the 2:1-sparsity figure)
 MFMA_32x32x16_FLOP = 2 * 32 * 32 * 16
 
 
-def ch_config(model='InterpGN', dnn_type='FCN'):
-    return Namespace(enc_in=122, seq_len=1000, num_class=3, c_out=3, epsilon=1.0, distance_func='euclidean',
+def ch_config(model='InterpGN', dnn_type='FCN', shape='ch'):
+    """shape 'ch': the CHISCO shape of BASELINE.json configs 2-5 (122 channels x 1000 samples, 3 classes);
+    'bm': UEA BasicMotions, config 1 / run_uea.sh (6 channels x 100 samples, 4 classes)."""
+    C, T, N = (122, 1000, 3) if shape == 'ch' else (6, 100, 4)
+    return Namespace(enc_in=C, seq_len=T, num_class=N, c_out=N, epsilon=1.0, distance_func='euclidean',
                      memory_efficient=False, sbm_cls='linear', dropout=0.0, lambda_reg=0.1, lambda_div=0.1,
                      dnn_type=dnn_type, model=model, task_name='classification', pred_len=0, label_len=0,
                      output_attention=False, d_model=512, embed='timeF', freq='h', factor=1, n_heads=8, d_ff=2048,
@@ -174,6 +177,43 @@ def cpu_baseline_baseline(config, cfg, state_dict, sample_b, threads):
     return _time_cpu_steps(step, sample_b, f"CPU oracle of the {config} baseline (oracle/baselines_oracle.py)", threads)
 
 
+# ------------------------------------------------------------------------------------------------- harness leg (f1)
+def harness_leg(B, epochs=2):
+    """epochs/s of the drop-in harness itself -- Experiment.train_one_epoch of exp/experiment_classification.py
+    (IGN/exp/experiment_classification.py:313-343) on `--data SYNTH` (8192 x (1000, 122) samples on the HOST), batches collated
+    by the DataLoader, pinned and copied per step by the DevicePrefetcher (the H2D copy of :315-317 is inside the timed region),
+    validation excluded.  One warm-up epoch, then `epochs` timed ones."""
+    import speech_imagery_eeg_amd  # noqa: F401
+    import run as ign_run
+    from exp.experiment_classification import Experiment
+    import tempfile
+    argv = ["--model", "InterpGN", "--dnn_type", "FCN", "--data", "SYNTH", "--dataset", "SYNTH", "--batch_size", str(B), "--amp",
+            "--train_epochs", str(epochs + 1), "--num_workers", "0", "--seed", "0"]
+    a = ign_run.get_args(argv)
+    a.synthetic = f"{N_TRAIN},122,1000,3"
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)                                        # Experiment creates ./checkpoints
+        try:
+            ign_run.set_seed(0)
+            exp = Experiment(a)
+            steps_per_epoch = len(exp.train_loader)
+            _, ts = exp.train_one_epoch(0, 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for e in range(epochs):
+                _, ts = exp.train_one_epoch(e + 1, ts)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            os.chdir(cwd)
+    return {"value": epochs / dt, "unit": "epochs/s", "ms_per_step": 1e3 * dt / (epochs * steps_per_epoch),
+            "steps_per_epoch": steps_per_epoch, "epochs_timed": epochs,
+            "what": "Experiment.train_one_epoch (the reference's exp:313-343 loop) on --data SYNTH: host-resident samples, "
+                    "DataLoader collate (num_workers 0), pinned H2D copy of every batch through DevicePrefetcher INSIDE the timed "
+                    "region, forward / fused loss / backward / flat Adam; validation excluded"}
+
+
 # ------------------------------------------------------------------------------------------------- self-launch for N > 1
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` with no rendezvous environment: start N ranks with torch.distributed.run as a CHILD process
@@ -213,7 +253,7 @@ class Bench:
         from ign_hip.ddp import FlatAdam, FlatParamBucket
         self.config, self.args, self.dev, self.rank, self.world, self.dist = config, args, dev, rank, world, dist
         self.ops = ign_ops
-        cfg = ch_config(dnn_type=args.dnn)
+        cfg = ch_config(dnn_type=args.dnn, shape=args.shape)
         if config == "ign" and args.dnn == "PatchTST":
             cfg.d_model, cfg.d_ff, cfg.n_heads = 64, 128, 4
         elif config == "ign" and args.dnn == "TimesNet":
@@ -261,7 +301,7 @@ class Bench:
         if cfgname == "ign":
             out, info = model(x, mask, None, None)
             # = F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y), one launch
-            return self.ops.ign_loss(info.shapelet_preds, info.dnn_preds, y, 1.0)[0] + info.loss.mean()
+            return self.ops.ign_loss(info.shapelet_preds, info.dnn_preds, y, 1.0, reg=info.loss)[0]
         if cfgname == "eegcnn":
             out, info = model(x.permute(0, 2, 1).contiguous())        # (B,C,T), no mask
             return F.cross_entropy(out, y) + info.loss.mean()
@@ -269,7 +309,7 @@ class Bench:
 
     def step_xy(self, x, y):
         loss = self.loss_of(x, y)
-        loss.backward()
+        self.ops.backward(loss)
         self.opt.step()
         self.bucket.zero_grad()
         return loss.detach()
@@ -279,7 +319,7 @@ class Bench:
         if self.graphed is not None:
             return self.graphed(x, y)
         loss = self.loss_of(x, y)
-        loss.backward()
+        self.ops.backward(loss)                  # = loss.backward(), as Experiment.train_one_epoch calls it
         if time_allreduce and self.world > 1:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -312,6 +352,26 @@ class Bench:
             self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt, last
+
+
+def count_launches(step_fn, n=2):
+    """GPU kernel launches of one step, counted by torch.profiler over `n` steps (None if the profiler is unavailable)."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for i in range(n):
+                step_fn(i)
+            torch.cuda.synchronize()
+        names = {}
+        for ev in prof.events():
+            if str(getattr(ev, "device_type", "")).endswith("CUDA") and "memcpy" not in ev.name.lower() and "memset" not in ev.name.lower():
+                names[ev.name] = names.get(ev.name, 0) + 1
+        total = sum(names.values())
+        return None if total == 0 else {"per_step": total / n,
+                                        "by_kernel": {k[:60]: v / n for k, v in sorted(names.items(), key=lambda kv: -kv[1])[:40]}}
+    except Exception as e:                                   # profiler not usable here: report that, never fail the bench
+        return {"per_step": None, "error": repr(e)[:200]}
 
 
 def attention_roofline(lib_timing, steps, Bh, Lq, E, layers, attn_math):
@@ -381,15 +441,21 @@ def baseline_result(b, lib, steps, dt, last, cpu_sample):
         roof = attention_roofline(timing, steps, B * cfg.n_heads, T, cfg.d_model // cfg.n_heads, cfg.e_layers, ign_ops.ATTN_MATH)
         lin = 2.0 * M * (4 * 512 * 512 + 2 * 512 * 2048) * cfg.e_layers        # Q,K,V,O + the two 1x1-conv FFN layers
         emb = 2.0 * M * 512 * 122 * 3                                            # k=3 circular token embedding
-        groups = gemm_groups(lib, steps, {"clconv_fwd": lin + emb, "clconv_dgrad": lin, "clconv_wgrad": lin + emb}, x6)
-        others = other_kernels(lib, steps, ("layernorm_fwd", "layernorm_bwd", "head_fwd", "head_bwd_x", "head_bwd_w", "adam"))
+        # timer label "clconv_fwd" = every launch of ign_clconv_fwd_x6: the Linear / embedding FORWARD GEMMs and the Linear
+        # INPUT-GRADIENT GEMMs (the same kernel with W in place of W^T; the embedding's input is data and takes none)
+        groups = gemm_groups(lib, steps, {"clconv_fwd": lin + emb + lin, "clconv_wgrad": lin + emb}, x6)
+        if "clconv_fwd" in groups:
+            groups["clconv_fwd"]["what"] = "Linear + token-embedding forward GEMMs and the Linear input-gradient GEMMs (one kernel)"
+        others = other_kernels(lib, steps, ("layernorm_fwd", "layernorm_bwd", "head_fwd", "head_bwd_xw", "head_bwd_x", "head_bwd_w", "adam"))
     else:
         desc = "EEG-CNN baseline (CNN 8x8 filters k=125/25 + 2-layer encoder d_model 512, 8 heads, d_ff 256)"
         S = T // 10
         roof = attention_roofline(timing, steps, B * 8, S, cfg.d_model // 8, 2, ign_ops.ATTN_MATH)
         Me = float(B * S)
         lin = 2.0 * Me * (64 * 512 + 2 * (4 * 512 * 512 + 2 * 512 * 256))       # projection + 2 x (in_proj, out_proj, FFN)
-        groups = gemm_groups(lib, steps, {"clconv_fwd": lin, "clconv_dgrad": lin, "clconv_wgrad": lin}, x6)
+        groups = gemm_groups(lib, steps, {"clconv_fwd": lin + lin, "clconv_wgrad": lin}, x6)      # forward + input gradient (see above)
+        if "clconv_fwd" in groups:
+            groups["clconv_fwd"]["what"] = "Linear forward GEMMs and the Linear input-gradient GEMMs (one kernel)"
         others = other_kernels(lib, steps, ("chan_contract", "chan_contract_bwd_w", "dwconv1d", "dwconv1d_bwd_w", "chan_stats",
                                             "affine_elu_pool", "bn_elu_pool_bwd_sums", "bn_elu_pool_bwd_apply", "autocorr",
                                             "conv1_sumsq_fwd", "conv1_sumsq_bwd", "layernorm_fwd", "layernorm_bwd", "adam"))
@@ -428,6 +494,9 @@ def main():
                     "steps; 0 = skip every CPU baseline)")
     ap.add_argument("--baseline-steps", type=int, default=6, help="timed steps of each baseline (configs 3 / 4) appended to the "
                     "default single-GPU IGN run as the `baselines` object (0 = skip)")
+    ap.add_argument("--harness-epochs", type=int, default=2,
+                    help="timed epochs of the harness leg (Experiment.train_one_epoch on --data SYNTH with per-step H2D copies; "
+                         "single GPU, default config only; 0 = skip)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step (fwd + loss + bwd + Adam) as one captured hipGraph (single GPU; pays off in "
                          "launch-bound regimes such as --batch 32, the UEA setting of run_uea.sh)")
@@ -446,6 +515,13 @@ def main():
     ap.add_argument("--config", choices=["ign", "eegcnn", "transformer"], default="ign",
                     help="ign = BASELINE.json's headline (config 1 / 5); eegcnn / transformer = the baselines of "
                          "configs 3 / 4 on the same synthetic tensors")
+    ap.add_argument("--shape", choices=["ch", "bm"], default="ch",
+                    help="ch = the CHISCO shape (122 ch x 1000, 3 classes: BASELINE.json's metric); bm = UEA BasicMotions (6 ch x 100, "
+                         "4 classes: the shape run_uea.sh trains at --batch 32) -- a launch-bound regime, reported with the launch "
+                         "count, never the headline")
+    ap.add_argument("--count-launches", action="store_true",
+                    help="count the GPU kernel launches of one step with torch.profiler (config.launches_per_step); off by default "
+                         "so that a bench run under rocprofv3 does not start a second profiler")
     ap.add_argument("--planted", action="store_true",
                     help="SURVEY 8(d)'s learnable synthetic variant (class-specific sine bursts planted in the noise): shows the "
                          "training loss falling at the full benchmark size; reported in config.loss_curve, never the headline")
@@ -495,6 +571,7 @@ def main():
         if args.planted:
             curve.append(l)
 
+    launches = count_launches(lambda i: b.step(i)) if args.count_launches else None
     log("timed region ...")
     _lib.timing_enable(True)
     if args.planted:             # the loss curve costs nothing inside the region: detached device scalars, read afterwards
@@ -558,8 +635,8 @@ def main():
     if rank == 0:
         amp = b.amp
         res = {
-            "metric": "epochs/sec (B=256, C=122, T=1000) IGN 3-class" if args.config == "ign" else
-                      f"epochs/sec (B=256, C=122, T=1000) {args.config} baseline 3-class",
+            "metric": f"epochs/sec (B={B}, C={C}, T={T}) IGN {cfg.num_class}-class" if args.config == "ign" else
+                      f"epochs/sec (B={B}, C={C}, T={T}) {args.config} baseline {cfg.num_class}-class",
             "value": (args.steps * B * world / N_TRAIN) / dt,
             "unit": "epochs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -573,11 +650,15 @@ def main():
         if args.config == "ign" and args.dnn != "FCN":
             res["metric"] += f" [deep expert {args.dnn}]"
         common = {"per_gpu_batch": B, "global_batch": B * world, "samples_per_epoch": N_TRAIN,
+                  "data": "resident in HBM (no H2D copy in the timed region; the harness path with the per-step copy is the "
+                          "`harness` object)",
                   "parallelism": f"dp{world}", "final_loss": float(last), "hipgraph": bool(b.use_graph)}
         if world > 1:
             common["collective"] = {"backend": "gloo (rehearsal)" if rehearsal else "nccl (RCCL over xGMI)", "ranks": world,
                                     "bucket_bytes": b.bucket.nbytes, "allreduce_ms_per_step": ar_ms,
                                     "what": "one all-reduce(sum) of the flat fp32 gradient bucket per optimizer step, then / ranks"}
+        if launches is not None:
+            common["launches_per_step"] = launches
         if rehearsal:
             common["rehearsal"] = "all ranks on cuda:0 over gloo: functional check of the N > 1 path, NOT a measurement"
         if args.planted:
@@ -593,8 +674,8 @@ def main():
             fwd_tflops = (f_fwd * args.steps) / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
             traffic, traffic_src = None, None
             try:    # HBM bytes per step of the dominant kernel, from the committed PMC passes (see profiles/traffic.json)
-                if args.groups != "4x5":
-                    raise KeyError("the PMC passes were collected for the headline bank only")
+                if args.groups != "4x5" or args.shape != "ch" or B != 256:
+                    raise KeyError("the PMC passes were collected for the headline workload only")
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
                 traffic = tj["shp_bwd_kernel"]["bytes_per_step"]
                 traffic_src = ("NOT measured in this run: read from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
@@ -602,9 +683,11 @@ def main():
             except Exception:
                 pass
             from ign_hip import fcn as _fcn
-            res["config"] = dict(common, workload="Synthetic CHISCO-shape EEG (122ch x 1000, 3-class) IGN(FCN expert), "
-                                 + ("driver-default groups K=5 x L{100,200,300,500}" if args.groups == "4x5" else
-                                    "stress bank K=10 x L{50,100,200,300,500,800}") + ", Adam lr 5e-3, fp32",
+            res["config"] = dict(common, workload=("Synthetic CHISCO-shape EEG (122ch x 1000, 3-class)" if args.shape == "ch" else
+                                                   "Synthetic BasicMotions-shape series (6ch x 100, 4-class; run_uea.sh's shape)")
+                                 + f" IGN({args.dnn} expert), "
+                                 + ("driver-default groups K=5 x L=" if args.groups == "4x5" else "stress bank K=10 x L=")
+                                 + "{" + ",".join(str(L_) for _, L_ in groups) + "}" + ", Adam lr 5e-3, fp32",
                                  conv_math=_fcn.CONV_MATH + (" (fp32 operands split exactly into 3 bf16 terms, 6 partial products "
                                                             "accumulated in fp32; <= 3e-6 vs float64, same as the fp32-MFMA "
                                                             "kernel; IGN_CONV_MATH=f32 selects that one)"
@@ -621,7 +704,7 @@ def main():
                                               "ms_per_step": fwd_ms / max(1, args.steps), "launches": fwd_n}}
             if alt is not None:
                 res["fp32_mfma_conv"] = alt
-            if iso:
+            if iso and args.shape == "ch":
                 def _tf(flops, ms):
                     return flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
                 x6 = _fcn.CONV_MATH == "bf16x6"
@@ -681,6 +764,14 @@ def main():
             torch.cuda.empty_cache()
         res["baselines"] = baselines
 
+    if rank == 0 and world == 1 and args.config == "ign" and args.harness_epochs > 0 and args.shape == "ch" and B == 256 \
+            and args.groups == "4x5" and args.dnn == "FCN" and not args.planted and args.precision == "fp32":
+        log("harness leg ...")
+        torch.cuda.empty_cache()
+        try:
+            res["harness"] = harness_leg(B, args.harness_epochs)
+        except Exception as e:                               # the headline must not die with the side leg
+            res["harness"] = {"error": repr(e)[:300]}
     if rank == 0:
         if world == 1 and args.cpu_sample > 0 and args.config == "ign":
             log("cpu baseline (ign) ...")

@@ -107,6 +107,19 @@ int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const float* g_out
                      float* gw_kcl, void* workspace,
                      int B, int C, int T, int K, int L, int stride, float eps, int mode, void* stream);
 
+/* Backward of every group of a bank in one call (the per-group arguments of ign_shapelet_bwd as tables of G <= 8 host entries):
+ * G backward launches, then ONE reduction launch over all groups that also adds add_scale_dev[0] * gw_add[g] into group g's
+ * result (gw_add / add_scale_dev nullable) -- the batch-independent gradient of the diversity regulariser
+ * (ign_sbm_reg_fwd_bwd), so that a parameter with two gradient sources needs no accumulate kernel.  Every group is validated
+ * before the first launch; with nothing added the results are bitwise those of G ign_shapelet_bwd calls (B <= 256).
+ * workspace: ign_shapelet_bwd_bank_workspace_bytes() bytes.                                                              */
+size_t ign_shapelet_bwd_bank_workspace_bytes(int G, int B, int C, int T, const int* K, const int* L, const int* stride, int mode);
+int ign_shapelet_bwd_bank(const float* xn_bct, int G, const float* const* w_kcl, const float* g_out, const float* p_out,
+                          const float* dmin_out, int ld, const int* col0, const int32_t* const* tstar, const float* const* zmu,
+                          const float* const* d_save, const float* const* xstat_save, const float* const* wnorm_kc,
+                          float* const* gw_kcl, const float* const* gw_add, const float* add_scale_dev, void* workspace,
+                          int B, int C, int T, const int* K, const int* L, const int* stride, float eps, int mode, void* stream);
+
 /* Fused attention core softmax(scale * Q K^T) V, exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32), scores never
  * materialised.  Replaces IGN/layers/SelfAttention_Family.py:56-75 (FullAttention: no mask, dropout 0) and the
  * attention inside nn.TransformerEncoderLayer of IGN/model/eegcnn.py:219-228.
@@ -167,6 +180,10 @@ int ign_head_fwd(const float* X, const float* W, const float* bias, float* out, 
                  void* stream);
 int ign_head_bwd(const float* g_out, const float* X, const float* W, float* gX, float* gW, float* gbias,
                  int B, int F, int N, long long ldx, void* stream);
+/* The same with gW += add_scale_dev[0] * gW_add (both nullable; add_scale_dev NULL = 1): a batch-independent gradient of W --
+ * the L1 regulariser mean|W| of IGN/model/Shapelet.py:219 -- lands in the same store instead of an accumulate kernel.   */
+int ign_head_bwd_acc(const float* g_out, const float* X, const float* W, float* gX, float* gW, float* gbias,
+                     const float* gW_add, const float* add_scale_dev, int B, int F, int N, long long ldx, void* stream);
 
 /* Gini-index gate of the two experts, forward and backward.  Replaces IGN/model/InterpGN.py:44-52:
  * eta = (N*sum softmax(sbm)^2 - 1)/(N-1); if use_gating_value and eta > gating_value: eta = 1 (test time);
@@ -182,12 +199,27 @@ int ign_gate_bwd(const float* sbm, const float* dnn, const float* gout, const fl
  * out (B,N), eta (B), loss2 = {CE(out,y), CE(sbm,y), their beta-weighted sum}, gsbm / gdnn (B,N) = d(CE(out,y) + beta*CE(sbm,y)) / d logits.  N <= 16. */
 int ign_loss_fwd_bwd(const float* sbm, const float* dnn, const long long* labels, float* out, float* eta, float* loss2,
                      float* gsbm, float* gdnn, int B, int N, float beta, void* stream);
+/* The same with the model's regulariser value added to loss2[2] on the device (`reg`: one float, nullable): the whole training
+ * loss CE(out,y) + info.loss.mean() + beta*CE(sbm,y) of IGN/exp/experiment_classification.py:325-329 in one launch.        */
+int ign_loss_fwd_bwd_reg(const float* sbm, const float* dnn, const long long* labels, const float* reg, float* out, float* eta,
+                         float* loss2, float* gsbm, float* gdnn, int B, int N, float beta, void* stream);
 
 /* Shapelet diversity regulariser of one length group, forward and gradient in one launch.
  * Replaces IGN/model/Shapelet.py:223-230:  mean_{c,i,j} exp(-||w[i,c,:] - w[j,c,:] + eps||_2) (1 - delta_ij), eps = 1e-6.
  * loss_part_c (C): per-channel partial sums (their sum is the group's loss); gw_kcl (K,C,L): d loss / d w.  K <= 16.  */
 int ign_diversity_fwd_bwd(const float* w_kcl, float* loss_part_c, float* gw_kcl, int K, int C, int L, float eps,
                           void* stream);
+
+/* Both regularisers of the shapelet bottleneck model -- ShapeBottleneckModel.loss(), IGN/model/Shapelet.py:217-230 -- value and
+ * gradients in ONE launch:  loss_out[0] = lambda_reg * mean|W| + lambda_div * sum_g diversity_g  (G = 0 skips the diversity
+ * term, as the reference does for lambda_div <= 0);  gW_reg (nW) = lambda_reg * sign(W) / nW (sign(0) = 0);  gw_kcl[g] (K,C,L) =
+ * lambda_div * d diversity_g / d w.  Per-block partials are combined in a fixed order by the block that finishes last (bitwise
+ * reproducible).  workspace: ign_sbm_reg_workspace_bytes() bytes, ZERO-FILLED ONCE by the caller and then owned by one model on
+ * one stream (the kernel re-arms its ticket counter itself).  G <= 8, K <= 16.                                             */
+size_t ign_sbm_reg_workspace_bytes(int G, int C, long long nW);
+int ign_sbm_reg_fwd_bwd(const float* W, float* gW_reg, long long nW, float lambda_reg, int G, const float* const* w_kcl,
+                        float* const* gw_kcl, const int* K, const int* L, int C, float lambda_div, float eps, float* loss_out,
+                        void* workspace, void* stream);
 
 /* One Adam step over flat buffers (torch.optim.Adam semantics, no weight decay / amsgrad): replaces the per-tensor
  * optimizer.step() of IGN/exp/experiment_classification.py:338.  `step` is the 1-based step count.               */
@@ -324,6 +356,18 @@ int ign_clconv_dgrad_x6(const float* dyp, const void* wt3_dgrad, const float* y_
 size_t ign_clconv_wgrad_x6_workspace_bytes(int B, int Tin, int Ci, int Co, int k);
 int ign_clconv_wgrad_x6(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
                         float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream);
+/* Deferred reduction: ign_clconv_wgrad_x6 / _bf16 called with dw_oik == NULL (k > 1) leave their ign_clconv_wgrad_x6_nsplit()
+ * partial slabs in `workspace`; ign_clconv_wgrad_reduce_multi then reduces up to 8 layers in ONE launch (same ascending-order
+ * sums as the per-layer reduction: identical bits).  Tables are host arrays.                                                  */
+int ign_clconv_wgrad_x6_nsplit(int B, int Tin, int Ci, int Co, int k);
+int ign_clconv_wgrad_reduce_multi(int n, const void* const* part, float* const* dw_oik, const int* nsplit, const int* Co,
+                                  const int* Ci, const int* k, void* stream);
+/* ign_clconv_pack_weights_x3 for up to 8 layers in ONE launch; counters[l] (nullable table / entries): an int64 device counter
+ * incremented by one -- nn.BatchNorm1d.num_batches_tracked of the BatchNorm behind layer l in training mode
+ * (IGN/model/FullyConvNet.py:31-50 builds Conv1d + BatchNorm1d pairs).                                                       */
+int ign_clconv_pack_weights_x3_multi(int n, const float* const* w_oik, void* const* wt3_fwd, void* const* wt3_dgrad,
+                                     const int* Co, const int* Ci, const int* k, long long* const* counters, void* stream);
+
 /* The three split-bf16 GEMMs with ONE product per step: operands rounded to bf16 (round-to-nearest-even), products and sums in
  * fp32 -- the arithmetic of the reference's default bf16-autocast mode (IGN/exp/experiment_classification.py:319; `--amp`
  * switches it OFF).  Same packed weights (plane 0 is read), same arguments, same workspace as the *_x6 entry points.        */

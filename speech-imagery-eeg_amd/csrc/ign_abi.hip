@@ -337,12 +337,12 @@ extern "C" size_t ign_shapelet_bwd_workspace_bytes(int B, int C, int T, int K, i
     return (size_t)p.nbs * K * C * L * sizeof(float);
 }
 
-extern "C" int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const float* g_out, const float* p_out,
-                                const float* dmin_out, int ld, int col0, const int32_t* tstar, const float* zmu,
-                                const float* d_save, const float* xstat_save, const float* wnorm_kc, float* gw_kcl,
-                                void* workspace, int B, int C, int T, int K, int L, int stride, float eps, int mode,
-                                void* stream) {
-    static const char* who = "ign_shapelet_bwd";
+// validate + launch the backward kernel of one group (partials into `workspace`); *nbs_out = batch slices to reduce
+static int launch_bwd_group(const char* who, const float* xn_bct, const float* w_kcl, const float* g_out, const float* p_out,
+                            const float* dmin_out, int ld, int col0, const int32_t* tstar, const float* zmu,
+                            const float* d_save, const float* xstat_save, const float* wnorm_kc, float* gw_kcl,
+                            void* workspace, int B, int C, int T, int K, int L, int stride, float eps, int mode,
+                            void* stream, int* nbs_out, bool launch) {
     int dist, gate, rc;
     if ((rc = split_mode(mode, &dist, &gate, who))) return rc;
     if ((rc = check_dims(who, B, C, T, K, L, stride))) return rc;
@@ -379,12 +379,76 @@ extern "C" int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const f
     a.nbs = p.nbs; a.kb = p.kb; a.cpk = p.cpk; a.tc = p.tc; a.xs_len = p.xs_len; a.gate = gate;
     a.eps = eps; a.invL = 1.0f / (float)L;
     a.stride = stride; a.njt = p.njt;
+    *nbs_out = p.nbs;
+    if (!launch) return 0;
     {
         IgnScopedTimer tm("shp_bwd", (hipStream_t)stream);
         fn(a, dim3((unsigned)C, (unsigned)p.nbs, (unsigned)(p.nkt * p.njt)), dim3(p.threads), p.lds, (hipStream_t)stream);
     }
-    if ((rc = ign_check_launch("shp_bwd_kernel"))) return rc;
+    return ign_check_launch("shp_bwd_kernel");
+}
+
+extern "C" int ign_shapelet_bwd(const float* xn_bct, const float* w_kcl, const float* g_out, const float* p_out,
+                                const float* dmin_out, int ld, int col0, const int32_t* tstar, const float* zmu,
+                                const float* d_save, const float* xstat_save, const float* wnorm_kc, float* gw_kcl,
+                                void* workspace, int B, int C, int T, int K, int L, int stride, float eps, int mode,
+                                void* stream) {
+    int rc, nbs = 0;
+    if ((rc = launch_bwd_group("ign_shapelet_bwd", xn_bct, w_kcl, g_out, p_out, dmin_out, ld, col0, tstar, zmu, d_save, xstat_save,
+                               wnorm_kc, gw_kcl, workspace, B, C, T, K, L, stride, eps, mode, stream, &nbs, true))) return rc;
     IgnScopedTimer tm2("reduce_parts", (hipStream_t)stream);
-    ign_launch_reduce_parts(a.part, gw_kcl, p.nbs, (size_t)K * C * L, (hipStream_t)stream);
+    ign_launch_reduce_parts((const float*)workspace, gw_kcl, nbs, (size_t)K * C * L, (hipStream_t)stream);
     return ign_check_launch("reduce_parts_kernel");
+}
+
+// Every group of a bank: G backward kernels, then ONE reduction launch that also adds `add_scale_dev[0] * gw_add[g]` (the
+// batch-independent gradient of the diversity regulariser) into each group's result.  Workspace: the groups' partial buffers
+// back to back, each ign_shapelet_bwd_workspace_bytes(...) rounded up to 256 bytes.
+extern "C" size_t ign_shapelet_bwd_bank_workspace_bytes(int G, int B, int C, int T, const int* K, const int* L, const int* stride,
+                                                        int mode) {
+    if (G <= 0 || G > SHP_MAX_GROUPS || !K || !L || !stride) return 0;
+    size_t tot = 0;
+    for (int g = 0; g < G; ++g) {
+        const size_t b = ign_shapelet_bwd_workspace_bytes(B, C, T, K[g], L[g], stride[g], mode);
+        if (!b) return 0;
+        tot += (b + 255) & ~(size_t)255;
+    }
+    return tot;
+}
+
+extern "C" int ign_shapelet_bwd_bank(const float* xn_bct, int G, const float* const* w_kcl, const float* g_out, const float* p_out,
+                                     const float* dmin_out, int ld, const int* col0, const int32_t* const* tstar,
+                                     const float* const* zmu, const float* const* d_save, const float* const* xstat_save,
+                                     const float* const* wnorm_kc, float* const* gw_kcl, const float* const* gw_add,
+                                     const float* add_scale_dev, void* workspace, int B, int C, int T, const int* K, const int* L,
+                                     const int* stride, float eps, int mode, void* stream) {
+    static const char* who = "ign_shapelet_bwd_bank";
+    if (G <= 0 || G > SHP_MAX_GROUPS || !w_kcl || !col0 || !tstar || !zmu || !d_save || !gw_kcl || !K || !L || !stride || !workspace) {
+        ign_set_error("%s: G=%d outside 1..%d or null table", who, G, SHP_MAX_GROUPS);
+        return IGN_E_ARG;
+    }
+    ReduceBankTable t;
+    char* ws[SHP_MAX_GROUPS];
+    int rc;
+    for (int pass = 0; pass < 2; ++pass) {            // pass 0 validates every group, pass 1 launches
+        char* cur = (char*)workspace;
+        for (int g = 0; g < G; ++g) {
+            const size_t b = ign_shapelet_bwd_workspace_bytes(B, C, T, K[g], L[g], stride[g], mode);
+            if (!b) { ign_set_error("%s: group %d: no launch plan for K=%d L=%d stride=%d", who, g, K[g], L[g], stride[g]); return IGN_E_ARG; }
+            ws[g] = cur;
+            cur += (b + 255) & ~(size_t)255;
+            int nbs = 0;
+            if ((rc = launch_bwd_group(who, xn_bct, w_kcl[g], g_out, p_out, dmin_out, ld, col0[g], tstar[g], zmu[g], d_save[g],
+                                       xstat_save ? xstat_save[g] : nullptr, wnorm_kc ? wnorm_kc[g] : nullptr, gw_kcl[g], ws[g], B, C,
+                                       T, K[g], L[g], stride[g], eps, mode, stream, &nbs, pass == 1))) return rc;
+            t.part[g] = (const float*)ws[g];
+            t.add[g] = gw_add ? gw_add[g] : nullptr;
+            t.out[g] = gw_kcl[g];
+            t.n[g] = (size_t)K[g] * C * L[g];
+            t.nparts[g] = nbs;
+        }
+    }
+    IgnScopedTimer tm2("reduce_parts", (hipStream_t)stream);
+    ign_launch_reduce_bank(t, G, add_scale_dev, (hipStream_t)stream);
+    return ign_check_launch("reduce_bank_kernel");
 }

@@ -286,6 +286,58 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     dw[(co * Ci + ci) * k + j] = s;
 }
 
+// the reductions of several layers in one launch (blockIdx.y = layer); same arithmetic as wgrad_reduce_kernel
+constexpr int WRED_LMAX = 8;
+struct WgradReduceTable {
+    const float* part[WRED_LMAX];
+    float* dw[WRED_LMAX];
+    int nsplit[WRED_LMAX], Co[WRED_LMAX], Ci[WRED_LMAX], k[WRED_LMAX];
+};
+__global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const WgradReduceTable t) {
+    const int l = blockIdx.y;
+    const int Co = t.Co[l], Ci = t.Ci[l], k = t.k[l], nsplit = t.nsplit[l];
+    const float* __restrict__ part = t.part[l];
+    const long long n = (long long)Co * Ci * k;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    int p = 0;
+    for (; p + 8 <= nsplit; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(long long)(p + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < nsplit; ++p) s += part[(long long)p * n + i];
+    const int ci = (int)(i % Ci);
+    const long long tt = i / Ci;
+    const int j = (int)(tt % k);
+    const long long co = tt / k;
+    t.dw[l][(co * Ci + ci) * k + j] = s;
+}
+
+extern "C" int ign_clconv_wgrad_reduce_multi(int n, const void* const* part, float* const* dw_oik, const int* nsplit, const int* Co,
+                                             const int* Ci, const int* k, void* stream) {
+    if (n <= 0 || n > WRED_LMAX || !part || !dw_oik || !nsplit || !Co || !Ci || !k) {
+        ign_set_error("ign_clconv_wgrad_reduce_multi: n=%d outside 1..%d or null table", n, WRED_LMAX);
+        return IGN_E_ARG;
+    }
+    WgradReduceTable t;
+    long long nmax = 0;
+    for (int l = 0; l < n; ++l) {
+        if (!part[l] || !dw_oik[l] || nsplit[l] <= 0 || Co[l] <= 0 || Ci[l] <= 0 || k[l] <= 0) {
+            ign_set_error("ign_clconv_wgrad_reduce_multi: layer %d: bad argument", l);
+            return IGN_E_ARG;
+        }
+        t.part[l] = (const float*)part[l]; t.dw[l] = dw_oik[l]; t.nsplit[l] = nsplit[l]; t.Co[l] = Co[l]; t.Ci[l] = Ci[l]; t.k[l] = k[l];
+        const long long e = (long long)Co[l] * Ci[l] * k[l];
+        nmax = e > nmax ? e : nmax;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
+    return ign_check_launch("wgrad_reduce_multi_kernel");
+}
+
 // Wt[co][j*Ci + ci] = W[co][ci][j];   Wd[ci][jj*Co + co] = W[co][ci][k-1-jj]
 __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wt,
                                                            float* __restrict__ wd, int Co, int Ci, int k) {

@@ -398,12 +398,11 @@ __global__ void __launch_bounds__(512, 2) clconv_x6w_kernel(const ConvX6Args ca)
 // Step-block-major planes for the kernel above: block (n-tile, chunk cc, tap j) = [plane][row 0..127][16 channels of chunk cc]
 // of tap j, contiguous; rows past N and channels past C are zero.
 //   forward: rows = co, value W[co][ci][j];   data gradient: rows = ci, channels = co, value W[co][ci][k-1-jj].
-__global__ void __launch_bounds__(256) pack_weights_x3t_kernel(const float* __restrict__ w, unsigned short* __restrict__ wt3,
-                                                               unsigned short* __restrict__ wd3, int Co, int Ci, int k, int Cip,
-                                                               int Cop) {
+__device__ __forceinline__ void pack_weights_x3t_body(const float* __restrict__ w, unsigned short* __restrict__ wt3,
+                                                      unsigned short* __restrict__ wd3, int Co, int Ci, int k, int Cip, int Cop,
+                                                      long long i) {
     const long long nf = (long long)((Co + TN - 1) / TN) * (Cip / KC) * k * (TN * KC);        // elements per plane set / 3
     const long long nd = wd3 ? (long long)((Ci + TN - 1) / TN) * (Cop / KC) * k * (TN * KC) : 0;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool fwd = i < nf;
     if (!fwd && i >= nf + nd) return;
     const long long e = fwd ? i : i - nf;
@@ -426,6 +425,29 @@ __global__ void __launch_bounds__(256) pack_weights_x3t_kernel(const float* __re
     const long long blk = ((long long)(nt * ncc + cc) * k + j) * X6_BLOCK + (long long)row * KC + q;
     __bf16* dst = reinterpret_cast<__bf16*>(fwd ? wt3 : wd3) + blk;
     dst[0] = x0; dst[TN * KC] = x1; dst[2 * TN * KC] = x2;
+}
+
+__global__ void __launch_bounds__(256) pack_weights_x3t_kernel(const float* __restrict__ w, unsigned short* __restrict__ wt3,
+                                                               unsigned short* __restrict__ wd3, int Co, int Ci, int k, int Cip,
+                                                               int Cop) {
+    pack_weights_x3t_body(w, wt3, wd3, Co, Ci, k, Cip, Cop, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// The weights of every layer of a convolution stack in ONE launch (blockIdx.y = layer), plus the per-step counter bump of the
+// BatchNorm behind each layer (nn.BatchNorm1d.num_batches_tracked += 1 in training mode): the "prologue" of an FCN step.
+constexpr int PACK_LMAX = 8;
+struct PackMultiTable {
+    const float* w[PACK_LMAX];
+    unsigned short* wt3[PACK_LMAX];
+    unsigned short* wd3[PACK_LMAX];
+    long long* counter[PACK_LMAX];
+    int Co[PACK_LMAX], Ci[PACK_LMAX], k[PACK_LMAX];
+};
+__global__ void __launch_bounds__(256) pack_weights_x3t_multi_kernel(const PackMultiTable t) {
+    const int l = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && t.counter[l]) *t.counter[l] += 1;
+    pack_weights_x3t_body(t.w[l], t.wt3[l], t.wd3[l], t.Co[l], t.Ci[l], t.k[l], (t.Ci[l] + 15) / 16 * 16, (t.Co[l] + 15) / 16 * 16,
+                          (long long)blockIdx.x * 256 + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient, split bf16
@@ -812,6 +834,30 @@ extern "C" int ign_clconv_pack_weights_x3(const float* w_oik, void* wt3_fwd, voi
     return ign_check_launch("pack_weights_x3t_kernel");
 }
 
+extern "C" int ign_clconv_pack_weights_x3_multi(int n, const float* const* w_oik, void* const* wt3_fwd, void* const* wt3_dgrad,
+                                               const int* Co, const int* Ci, const int* k, long long* const* counters, void* stream) {
+    if (n <= 0 || n > PACK_LMAX || !w_oik || !wt3_fwd || !Co || !Ci || !k) {
+        ign_set_error("ign_clconv_pack_weights_x3_multi: n=%d outside 1..%d or null table", n, PACK_LMAX);
+        return IGN_E_ARG;
+    }
+    PackMultiTable t;
+    long long nmax = 0;
+    for (int l = 0; l < n; ++l) {
+        if (!w_oik[l] || !wt3_fwd[l] || Co[l] <= 0 || Ci[l] <= 0 || k[l] <= 0) {
+            ign_set_error("ign_clconv_pack_weights_x3_multi: layer %d: bad argument (Co=%d Ci=%d k=%d)", l, Co[l], Ci[l], k[l]);
+            return IGN_E_ARG;
+        }
+        t.w[l] = w_oik[l]; t.wt3[l] = (unsigned short*)wt3_fwd[l]; t.wd3[l] = wt3_dgrad ? (unsigned short*)wt3_dgrad[l] : nullptr;
+        t.counter[l] = counters ? counters[l] : nullptr;
+        t.Co[l] = Co[l]; t.Ci[l] = Ci[l]; t.k[l] = k[l];
+        const long long e = ign_clconv_x3_elems(Co[l], Ci[l], k[l]) / 3 + (t.wd3[l] ? ign_clconv_x3_elems(Ci[l], Co[l], k[l]) / 3 : 0);
+        nmax = e > nmax ? e : nmax;
+    }
+    hipLaunchKernelGGL(pack_weights_x3t_multi_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)n), dim3(256), 0,
+                       (hipStream_t)stream, t);
+    return ign_check_launch("pack_weights_x3t_multi_kernel");
+}
+
 template <int KT, int NR, int NP>
 static int launch_wgrad_x6(const WgradX6Args& a, int V, bool pro, dim3 grid, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 3 * ((16 * NR) + (16 * NR + KT - 1)) * WG_PITCH * sizeof(unsigned short);
@@ -866,7 +912,8 @@ static int wgrad_x6_impl(const char* who, const float* dyp, int dy_pad, const fl
                          float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream,
                          float* db = nullptr) {
     const int Tout = Tin - k + 1, ru = wgrad_x6_rows_per_unit(k);
-    if (!dyp || !x || !dw_oik || !workspace || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || dy_pad < 0 ||
+    const bool defer = dw_oik == nullptr && k > 1;       // partials only: the caller reduces several layers in one launch
+    if (!dyp || !x || (!dw_oik && !defer) || !workspace || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || dy_pad < 0 ||
         ((pro_a == nullptr) != (pro_b == nullptr))) {
         ign_set_error("%s: bad argument (B=%d Tin=%d Ci=%d Co=%d k=%d pad=%d)", who, B, Tin, Ci, Co, k, dy_pad);
         return IGN_E_ARG;
@@ -921,7 +968,14 @@ static int wgrad_x6_impl(const char* who, const float* dyp, int dy_pad, const fl
         else rc = launch_wgrad_x6<2, 2, NP>(a, V, pro, grid, s);
     }
     if (rc) return rc;
+    if (defer) return 0;
     return ign_clconv_launch_wgrad_reduce((const float*)workspace, dw_oik, a.nsplit, Co, Ci, k, s);
+}
+
+extern "C" int ign_clconv_wgrad_x6_nsplit(int B, int Tin, int Ci, int Co, int k) {
+    const int Tout = Tin - k + 1, ru = wgrad_x6_rows_per_unit(k);
+    if (B <= 0 || Tout <= 0 || Ci <= 0 || Co <= 0 || !ru) return 0;
+    return wgrad_x6_splits(B * ((Tout + ru - 1) / ru), ((Co + 63) / 64) * ((Ci + 63) / 64));
 }
 
 

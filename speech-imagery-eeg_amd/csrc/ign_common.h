@@ -75,3 +75,13 @@ shp_bwd_launch_t ign_get_bwd_launcher(int dist, int JJ);            // JJ in {4,
 shp_bwd_launch_t ign_get_bwd_strided_launcher(int dist);            // stride > 1: JJ = 4, generic window step
 
 void ign_launch_reduce_parts(const float* part, float* out, int nparts, size_t n, hipStream_t s);
+
+// the reductions of every group of a bank in one launch (ign_shapelet_bwd.hip)
+struct ReduceBankTable {
+    const float* part[SHP_MAX_GROUPS];
+    const float* add[SHP_MAX_GROUPS];      // nullable: out += scale[0] * add
+    float* out[SHP_MAX_GROUPS];
+    size_t n[SHP_MAX_GROUPS];
+    int nparts[SHP_MAX_GROUPS];
+};
+void ign_launch_reduce_bank(const ReduceBankTable& t, int G, const float* scale_dev, hipStream_t s);

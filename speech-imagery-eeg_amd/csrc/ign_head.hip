@@ -57,10 +57,9 @@ __global__ void __launch_bounds__(1024) head_fwd_kernel(const float* __restrict_
 }
 
 // gX[b,f] = sum_n g[b,n] W[n,f]
-__global__ void __launch_bounds__(256) head_bwd_x_kernel(const float* __restrict__ g, const float* __restrict__ W,
-                                                         float* __restrict__ gX, int B, int F, int N, long long ldx) {
-    const int b = blockIdx.y;
-    const int f = (blockIdx.x * 256 + threadIdx.x) * 4;
+__device__ __forceinline__ void head_bwd_x_body(const float* __restrict__ g, const float* __restrict__ W,
+                                                float* __restrict__ gX, int B, int F, int N, long long ldx, int bx, int b) {
+    const int f = (bx * 256 + threadIdx.x) * 4;
     if (f >= F) return;
     float gn[HEAD_NMAX];
 #pragma unroll
@@ -83,25 +82,33 @@ __global__ void __launch_bounds__(256) head_bwd_x_kernel(const float* __restrict
     }
 }
 
+__global__ void __launch_bounds__(256) head_bwd_x_kernel(const float* __restrict__ g, const float* __restrict__ W,
+                                                         float* __restrict__ gX, int B, int F, int N, long long ldx) {
+    head_bwd_x_body(g, W, gX, B, F, N, ldx, blockIdx.x, blockIdx.y);
+}
+
 // gW[n,f] = sum_b g[b,n] X[b,f];  gbias[n] = sum_b g[b,n].
 // Block = 32 consecutive f x 8 batch groups: each thread sums its group's rows in ascending order, the 8 partials are
 // combined in fixed order through LDS (deterministic).  32 f per block keeps F/32 blocks in flight (F=2440: 77 blocks;
 // a 256-f-per-block version ran 10 blocks and took 125 us of a 17.9 ms step).
-__global__ void __launch_bounds__(256) head_bwd_w_kernel(const float* __restrict__ g, const float* __restrict__ X,
-                                                         float* __restrict__ gW, float* __restrict__ gbias, int B, int F,
-                                                         int N, long long ldx) {
+// `add` / `add_scale` (both nullable): gW += add_scale[0] * add -- a gradient of the same tensor that does not depend on the batch
+// (the L1 regulariser of the SBM head, IGN/model/Shapelet.py:219) rides on this store instead of an accumulate kernel.
+__device__ __forceinline__ void head_bwd_w_body(const float* __restrict__ g, const float* __restrict__ X,
+                                                float* __restrict__ gW, float* __restrict__ gbias, int B, int F,
+                                                int N, long long ldx, const float* __restrict__ add,
+                                                const float* __restrict__ add_scale, const int bx) {
     extern __shared__ float sm[];               // g copy [B*N], then partials [8][HEAD_NMAX][32]
     float* gs = sm;
     float* part = sm + B * N;
     for (int i = threadIdx.x; i < B * N; i += 256) gs[i] = g[i];
     __syncthreads();
-    if (gbias && blockIdx.x == 0 && threadIdx.x < N) {
+    if (gbias && bx == 0 && threadIdx.x < N) {
         float s = 0.f;
         for (int b = 0; b < B; ++b) s += gs[b * N + threadIdx.x];
         gbias[threadIdx.x] = s;
     }
     const int fl = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int f = blockIdx.x * 32 + fl;
+    const int f = bx * 32 + fl;
     const int per = (B + 7) / 8;
     const int b0 = grp * per, b1 = min(B, b0 + per);
     float acc[HEAD_NMAX];
@@ -120,12 +127,37 @@ __global__ void __launch_bounds__(256) head_bwd_w_kernel(const float* __restrict
     __syncthreads();
     for (int i = threadIdx.x; i < N * 32; i += 256) {
         const int n = i >> 5, ff = i & 31;
-        if (blockIdx.x * 32 + ff < F) {
+        if (bx * 32 + ff < F) {
             float s = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) s += part[(q * HEAD_NMAX + n) * 32 + ff];
-            gW[(long long)n * F + blockIdx.x * 32 + ff] = s;
+            const long long o = (long long)n * F + bx * 32 + ff;
+            if (add) s += (add_scale ? add_scale[0] : 1.f) * add[o];
+            gW[o] = s;
         }
+    }
+}
+
+__global__ void __launch_bounds__(256) head_bwd_w_kernel(const float* __restrict__ g, const float* __restrict__ X,
+                                                         float* __restrict__ gW, float* __restrict__ gbias, int B, int F,
+                                                         int N, long long ldx, const float* __restrict__ add,
+                                                         const float* __restrict__ add_scale) {
+    head_bwd_w_body(g, X, gW, gbias, B, F, N, ldx, add, add_scale, blockIdx.x);
+}
+
+// both gradients in ONE launch: blocks [0, nwb) play head_bwd_w_kernel's role, the rest head_bwd_x_kernel's ((nxb, B) grid
+// flattened) -- block-uniform branch, the two halves touch disjoint outputs
+__global__ void __launch_bounds__(256) head_bwd_xw_kernel(const float* __restrict__ g, const float* __restrict__ X,
+                                                          const float* __restrict__ W, float* __restrict__ gX,
+                                                          float* __restrict__ gW, float* __restrict__ gbias, int B, int F, int N,
+                                                          long long ldx, const float* __restrict__ add,
+                                                          const float* __restrict__ add_scale, int nwb, int nxb) {
+    const int blk = blockIdx.x;
+    if (blk < nwb) {
+        head_bwd_w_body(g, X, gW, gbias, B, F, N, ldx, add, add_scale, blk);
+    } else {
+        const int r = blk - nwb;
+        head_bwd_x_body(g, W, gX, B, F, N, ldx, r % nxb, r / nxb);
     }
 }
 
@@ -191,7 +223,8 @@ constexpr int LOSS_NMAX = 16;
 __global__ void __launch_bounds__(256) ign_loss_kernel(const float* __restrict__ s, const float* __restrict__ d,
                                                        const long long* __restrict__ y, float* __restrict__ out,
                                                        float* __restrict__ eta_out, float* __restrict__ loss2,
-                                                       float* __restrict__ gs, float* __restrict__ gd, int B, int N, float beta) {
+                                                       float* __restrict__ gs, float* __restrict__ gd, int B, int N, float beta,
+                                                       const float* __restrict__ reg) {
     __shared__ float red[2][256];
     float ce_o = 0.f, ce_s = 0.f;
     const float invB = 1.f / (float)B;
@@ -240,19 +273,24 @@ __global__ void __launch_bounds__(256) ign_loss_kernel(const float* __restrict__
         for (int i = 0; i < 256; ++i) { a += red[0][i]; b2 += red[1][i]; }
         loss2[0] = a * invB;
         loss2[1] = b2 * invB;
-        loss2[2] = a * invB + beta * (b2 * invB);
+        loss2[2] = a * invB + beta * (b2 * invB) + (reg ? reg[0] : 0.f);        // + info.loss.mean() (exp:325-329)
     }
 }
 
-extern "C" int ign_loss_fwd_bwd(const float* sbm, const float* dnn, const long long* labels, float* out, float* eta, float* loss2,
-                                float* gsbm, float* gdnn, int B, int N, float beta, void* stream) {
+extern "C" int ign_loss_fwd_bwd_reg(const float* sbm, const float* dnn, const long long* labels, const float* reg, float* out,
+                                    float* eta, float* loss2, float* gsbm, float* gdnn, int B, int N, float beta, void* stream) {
     if (!sbm || !dnn || !labels || !out || !eta || !loss2 || !gsbm || !gdnn || B <= 0 || N < 2 || N > LOSS_NMAX) {
         ign_set_error("ign_loss_fwd_bwd: null pointer or bad dimension (B=%d N=%d, N <= %d)", B, N, LOSS_NMAX);
         return IGN_E_ARG;
     }
     hipLaunchKernelGGL(ign_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sbm, dnn, labels, out, eta, loss2, gsbm, gdnn, B, N,
-                       beta);
+                       beta, reg);
     return ign_check_launch("ign_loss_kernel");
+}
+
+extern "C" int ign_loss_fwd_bwd(const float* sbm, const float* dnn, const long long* labels, float* out, float* eta, float* loss2,
+                                float* gsbm, float* gdnn, int B, int N, float beta, void* stream) {
+    return ign_loss_fwd_bwd_reg(sbm, dnn, labels, nullptr, out, eta, loss2, gsbm, gdnn, B, N, beta, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ Adam
@@ -340,6 +378,11 @@ extern "C" int ign_head_fwd(const float* X, const float* W, const float* bias, f
 
 extern "C" int ign_head_bwd(const float* g, const float* X, const float* W, float* gX, float* gW, float* gbias, int B,
                             int F, int N, long long ldx, void* stream) {
+    return ign_head_bwd_acc(g, X, W, gX, gW, gbias, nullptr, nullptr, B, F, N, ldx, stream);
+}
+
+extern "C" int ign_head_bwd_acc(const float* g, const float* X, const float* W, float* gX, float* gW, float* gbias,
+                                const float* gW_add, const float* add_scale_dev, int B, int F, int N, long long ldx, void* stream) {
     if (!g || !X || !W || B <= 0 || F <= 0 || N <= 0 || ldx < F) {
         ign_set_error("ign_head_bwd: null pointer or bad dimension");
         return IGN_E_ARG;
@@ -352,6 +395,13 @@ extern "C" int ign_head_bwd(const float* g, const float* X, const float* W, floa
     if ((size_t)B * N * 4 > 40 * 1024) { ign_set_error("ign_head_bwd: B*N=%d too large for the LDS copy of g", B * N); return IGN_E_TOOBIG; }
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    if (gX && gW) {
+        const int nwb = (F + 31) / 32, nxb = (F / 4 + 255) / 256;
+        IgnScopedTimer tm("head_bwd_xw", s);
+        hipLaunchKernelGGL(head_bwd_xw_kernel, dim3((unsigned)(nwb + nxb * B)), dim3(256), ((size_t)B * N + 8 * HEAD_NMAX * 32) * 4, s, g, X,
+                           W, gX, gW, gbias, B, F, N, ldx, gW_add, add_scale_dev, nwb, nxb);
+        return ign_check_launch("head_bwd_xw_kernel");
+    }
     if (gX) {
         IgnScopedTimer tm("head_bwd_x", s);
         hipLaunchKernelGGL(head_bwd_x_kernel, dim3((F / 4 + 255) / 256, B), dim3(256), 0, s, g, W, gX, B, F, N, ldx);
@@ -359,7 +409,8 @@ extern "C" int ign_head_bwd(const float* g, const float* X, const float* W, floa
     }
     if (gW) {
         IgnScopedTimer tm("head_bwd_w", s);
-        hipLaunchKernelGGL(head_bwd_w_kernel, dim3((F + 31) / 32), dim3(256), ((size_t)B * N + 8 * HEAD_NMAX * 32) * 4, s, g, X, gW, gbias, B, F, N, ldx);
+        hipLaunchKernelGGL(head_bwd_w_kernel, dim3((F + 31) / 32), dim3(256), ((size_t)B * N + 8 * HEAD_NMAX * 32) * 4, s, g, X, gW, gbias, B, F, N, ldx,
+                           gW_add, add_scale_dev);
         if ((rc = ign_check_launch("head_bwd_w_kernel"))) return rc;
     }
     return 0;
@@ -452,12 +503,13 @@ extern "C" int ign_adam_step_dev(float* p, const float* g, float* m, float* v, l
 // gradient of the (unit-weighted) loss w.r.t. w.  Replaces ~25 tiny elementwise / reduction launches per group.
 constexpr int DIV_KMAX = 16;
 
-__global__ void __launch_bounds__(256) diversity_kernel(const float* __restrict__ w, float* __restrict__ loss_part,
-                                                        float* __restrict__ gw, int K, int C, int L, float eps) {
+// one block = one channel c of one group; thread 0 returns the loss partial (already times `scale`), gw receives scale * gradient
+__device__ __forceinline__ float diversity_block(const float* __restrict__ w, float* __restrict__ gw, int K, int C, int L, int c,
+                                                 float eps, float scale) {
     __shared__ float D2[DIV_KMAX][DIV_KMAX];        // D2[i][j] = sum_l (w_i - w_j + eps)^2
     __shared__ float Ew[DIV_KMAX][DIV_KMAX];        // exp(-D_ij) / D_ij   (0 on the diagonal)
     __shared__ float red[4];
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t cs = (size_t)C * L;                 // stride between shapelets
     const float* wc = w + (size_t)c * L;
     for (int i = 0; i < K; ++i)
@@ -494,11 +546,12 @@ __global__ void __launch_bounds__(256) diversity_kernel(const float* __restrict_
         D2[i][j] = e;                                // reuse as e_ij for the loss sum below
     }
     __syncthreads();
+    float lossp = 0.f;
     if (tid == 0) {
         float s = 0.f;
         for (int i = 0; i < K; ++i)
             for (int j = 0; j < K; ++j) s += D2[i][j];
-        loss_part[c] = s * norm;
+        lossp = s * norm * scale;
     }
     // d e_ij / d w_i[l] = -e_ij (dl + eps) / D_ij ;  d e_ji / d w_i[l] = +e_ji (eps - dl) / D_ji   (dl = w_i[l] - w_j[l])
     for (int l = tid; l < L; l += 256)
@@ -510,8 +563,120 @@ __global__ void __launch_bounds__(256) diversity_kernel(const float* __restrict_
                     const float dl = wi - wc[j * cs + l];
                     g += -Ew[i][j] * (dl + eps) + Ew[j][i] * (eps - dl);
                 }
-            gw[i * cs + (size_t)c * L + l] = g * norm;
+            gw[i * cs + (size_t)c * L + l] = g * norm * scale;
         }
+    return lossp;
+}
+
+__global__ void __launch_bounds__(256) diversity_kernel(const float* __restrict__ w, float* __restrict__ loss_part,
+                                                        float* __restrict__ gw, int K, int C, int L, float eps) {
+    const float lp = diversity_block(w, gw, K, C, L, blockIdx.x, eps, 1.f);
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = lp;
+}
+
+// ------------------------------------------------------------------------------------------------ both SBM regularisers, one launch
+// loss = lambda_reg * mean |W| + lambda_div * sum_g diversity_g   (ShapeBottleneckModel.loss, IGN/model/Shapelet.py:217-230) with
+// the gradient of every term -- the value does not depend on the batch, so forward and backward are one launch; the consumers
+// (head weight gradient, shapelet gradient reduction) add `upstream * gradient` in their own epilogues.
+//   blocks [0, G*C): channel c of group g (diversity_block);  blocks [G*C, G*C + nwb): 1024 elements of W each.
+// Every block leaves one partial; the block that draws the last ticket adds them up in a fixed order (thread-strided sums, then
+// a fixed tree), so the result is bitwise reproducible although the arrival order is not.  Cross-block visibility follows the
+// producer / consumer recipe of the MI355X guide (agent-scope release before the ticket, acquire after it, sc1 loads).
+constexpr int REG_GMAX = 8;
+struct RegTable {
+    const float* w[REG_GMAX];
+    float* gw[REG_GMAX];
+    int K[REG_GMAX], L[REG_GMAX];
+};
+__global__ void __launch_bounds__(256) sbm_reg_kernel(const RegTable t, int G, int C, const float* __restrict__ W,
+                                                      float* __restrict__ gWreg, long long nW, int nwb, float lam_reg, float lam_div,
+                                                      float eps, float* __restrict__ parts, unsigned int* __restrict__ ticket,
+                                                      float* __restrict__ loss_out) {
+    __shared__ float red[256];
+    __shared__ int is_last;
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    const int nblk = G * C + nwb;
+    float lp = 0.f;
+    if (blk < G * C) {
+        const int g = blk / C, c = blk - g * C;
+        lp = diversity_block(t.w[g], t.gw[g], t.K[g], C, t.L[g], c, eps, lam_div);
+    } else {
+        // lambda_reg * mean |W|: gradient lambda_reg * sign(W) / numel (sign(0) = 0, as aten::sgn)
+        const long long i0 = (long long)(blk - G * C) * 1024 + tid * 4;
+        const float sc = lam_reg / (float)nW;
+        float a = 0.f;
+        for (int u = 0; u < 4; ++u) {
+            const long long i = i0 + u;
+            if (i < nW) {
+                const float v = W[i];
+                a += fabsf(v);
+                gWreg[i] = v > 0.f ? sc : (v < 0.f ? -sc : 0.f);
+            }
+        }
+        red[tid] = a;
+        __syncthreads();
+        if (tid == 0) {
+            float sacc = 0.f;
+            for (int i = 0; i < 256; ++i) sacc += red[i];
+            lp = sacc * sc;
+        }
+    }
+    if (tid == 0) {
+        __hip_atomic_store(parts + blk, lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (old == (unsigned int)(nblk - 1));
+        if (is_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    float a = 0.f;
+    for (int i = tid; i < nblk; i += 256) a += __hip_atomic_load(parts + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[tid] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        loss_out[0] = red[0];
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
+    }
+}
+
+extern "C" size_t ign_sbm_reg_workspace_bytes(int G, int C, long long nW) {
+    if (G < 0 || G > REG_GMAX || C <= 0 || nW < 0) return 0;
+    return (size_t)(G * C + (nW + 1023) / 1024 + 4) * sizeof(float);
+}
+
+extern "C" int ign_sbm_reg_fwd_bwd(const float* W, float* gW_reg, long long nW, float lambda_reg, int G, const float* const* w_kcl,
+                                   float* const* gw_kcl, const int* K, const int* L, int C, float lambda_div, float eps,
+                                   float* loss_out, void* workspace, void* stream) {
+    static const char* who = "ign_sbm_reg_fwd_bwd";
+    if (!loss_out || !workspace || G < 0 || G > REG_GMAX || C <= 0 || nW < 0 || (nW > 0 && (!W || !gW_reg)) ||
+        (G > 0 && (!w_kcl || !gw_kcl || !K || !L))) {
+        ign_set_error("%s: null pointer or bad dimension (G=%d C=%d nW=%lld)", who, G, C, nW);
+        return IGN_E_ARG;
+    }
+    RegTable t;
+    for (int g = 0; g < G; ++g) {
+        if (!w_kcl[g] || !gw_kcl[g] || K[g] <= 0 || L[g] <= 0) { ign_set_error("%s: group %d: null pointer or bad K / L", who, g); return IGN_E_ARG; }
+        if (K[g] > DIV_KMAX) { ign_set_error("%s: K=%d > %d shapelets per group", who, K[g], DIV_KMAX); return IGN_E_UNSUP; }
+        t.w[g] = w_kcl[g]; t.gw[g] = gw_kcl[g]; t.K[g] = K[g]; t.L[g] = L[g];
+    }
+    const int nwb = (int)((nW + 1023) / 1024);
+    const int nblk = G * C + nwb;
+    if (nblk <= 0) { ign_set_error("%s: nothing to do", who); return IGN_E_ARG; }
+    float* parts = (float*)workspace;
+    unsigned int* ticket = (unsigned int*)(parts + nblk);      // the caller zero-fills the workspace ONCE; the kernel re-arms it
+    IgnScopedTimer tm("sbm_reg", (hipStream_t)stream);
+    hipLaunchKernelGGL(sbm_reg_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, t, G, C, W, gW_reg, nW, nwb, lambda_reg,
+                       lambda_div, eps, parts, ticket, loss_out);
+    return ign_check_launch("sbm_reg_kernel");
 }
 
 extern "C" int ign_diversity_fwd_bwd(const float* w_kcl, float* loss_part_c, float* gw_kcl, int K, int C, int L, float eps,

@@ -98,3 +98,50 @@ void ign_launch_reduce_parts(const float* part, float* out, int nparts, size_t n
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(blocks), dim3(256), 0, s, part, out, nparts, n);
 }
+
+// All groups of a bank in ONE reduction launch (blockIdx.y = group): out_g[i] = sum_s part_g[s][i] (+ scale[0] * add_g[i]).
+// Same arithmetic as the per-group kernels above for up to 128 partials -- >= 16: 4 slices, each summed in ascending order, combined
+// in a fixed order; fewer: one ascending sum -- so a bank call returns bitwise what G ign_shapelet_bwd calls return (nothing added).
+// `add` carries a batch-independent gradient of the same tensor (the diversity regulariser, IGN/model/Shapelet.py:223-230) so
+// that it needs no accumulate kernel; `scale` is the upstream gradient of that regulariser, read on the device.
+__global__ void __launch_bounds__(256) reduce_bank_kernel(const ReduceBankTable t, const float* __restrict__ scale) {
+    __shared__ float sm[4][64];
+    const int g = blockIdx.y;
+    const size_t n = t.n[g];
+    const int nparts = t.nparts[g];
+    const float* __restrict__ part = t.part[g];
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + o;
+    if ((size_t)blockIdx.x * 64 >= n) return;                       // block-uniform
+    float s = 0.f;
+    if (nparts >= 16) {
+        const int per = (nparts + 3) / 4;
+        const int p0 = sl * per, p1 = min(nparts, p0 + per);
+        if (i < n) {
+            int p = p0;
+            for (; p + 8 <= p1; p += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(p + u) * n + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; p < p1; ++p) s += part[(size_t)p * n + i];
+        }
+        sm[sl][o] = s;
+        __syncthreads();
+        if (sl != 0 || i >= n) return;
+        s = ((sm[0][o] + sm[1][o]) + sm[2][o]) + sm[3][o];
+    } else {
+        if (sl != 0 || i >= n) return;
+        for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + i];
+    }
+    if (t.add[g]) s += (scale ? scale[0] : 1.f) * t.add[g][i];
+    t.out[g][i] = s;
+}
+
+void ign_launch_reduce_bank(const ReduceBankTable& t, int G, const float* scale_dev, hipStream_t s) {
+    size_t nmax = 0;
+    for (int g = 0; g < G; ++g) nmax = t.n[g] > nmax ? t.n[g] : nmax;
+    hipLaunchKernelGGL(reduce_bank_kernel, dim3((unsigned)((nmax + 63) / 64), (unsigned)G), dim3(256), 0, s, t, scale_dev);
+}

@@ -68,6 +68,11 @@ def data_provider(args, flag, bin_edges=None):
         sampler = RankShardSampler(len(data_set), dist.get_rank(), dist.get_world_size(), shuffle,
                                    seed=max(0, getattr(args, 'seed', 0)))
     raw = bool(getattr(data_set, 'raw', False))
+    if args.data == 'SYNTH' and args.num_workers == 0:
+        # samples are rows of one in-memory tensor: a batch is one multi-threaded gather into a pinned buffer
+        from data_provider.device_prefetch import TensorBatchLoader
+        return data_set, TensorBatchLoader(data_set, args.batch_size, shuffle=shuffle, sampler=sampler,
+                                           pin_memory=torch.cuda.is_available())
     loader = DataLoader(data_set, batch_size=args.batch_size, shuffle=(shuffle and sampler is None), sampler=sampler,
                         num_workers=args.num_workers, drop_last=False, pin_memory=torch.cuda.is_available(),
                         collate_fn=collate_raw if raw else (lambda b: collate_fn(b, max_len=max_len)))

@@ -191,51 +191,58 @@ class Experiment(object):
         padding_mask = padding_mask.float().to(self.device, non_blocking=True)
         return batch_x, label, padding_mask
 
+    def train_one_epoch(self, epoch, train_step=0):
+        """The inner loop of train() -- IGN/exp/experiment_classification.py:313-343 -- over self.train_loader (host batches
+        copied by the DevicePrefetcher): -> (detached per-step losses, running step count).  Validation is the caller's."""
+        a = self.args
+        amp = a.amp and self.device.type == 'cuda'
+        self.model.train()
+        losses = []
+        for batch_x, label, padding_mask in self.train_loader:
+            train_step += 1
+            batch_x, label, padding_mask = self._to_device(batch_x, label, padding_mask)
+            with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=amp):
+                logits, info = self._forward(batch_x, padding_mask)
+                if a.model == 'InterpGN' and logits.is_cuda and not amp:
+                    # CE(mixture) + info.loss.mean() + beta*CE(sbm) and both logit gradients in one launch (ops.ign_loss)
+                    # instead of ~40 softmax / nll / mean kernels between the forward and the backward pass
+                    beta = compute_beta(epoch, a.train_epochs, a.beta_schedule)
+                    loss = ign_ops.ign_loss(info.shapelet_preds, info.dnn_preds, label, beta, reg=info.loss)[0]
+                else:
+                    loss = F.cross_entropy(logits, label)
+                    if a.model != 'DNN':
+                        loss = loss + info.loss.mean()
+                    if a.model == 'InterpGN':
+                        beta = compute_beta(epoch, a.train_epochs, a.beta_schedule)
+                        loss = loss + beta * F.cross_entropy(info.shapelet_preds, label)
+            if a.gradient_accumulation_steps > 1:
+                loss = loss / a.gradient_accumulation_steps
+            ign_ops.backward(loss)                 # = loss.backward() (a cached unit root gradient on the GPU)
+            if train_step % a.gradient_accumulation_steps == 0:
+                if self.bucket is not None:
+                    self.bucket.allreduce()
+                if a.gradient_clip > 0:
+                    nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=a.gradient_clip)
+                self.optimizer.step()
+                if a.pos_weight:
+                    self.model.step()
+                if self.bucket is not None:
+                    self.bucket.zero_grad()
+                else:
+                    self.optimizer.zero_grad()
+            losses.append(loss.detach())
+        return losses, train_step
+
     def train(self):
         a = self.args
         torch.set_float32_matmul_precision('medium')          # :297 (affects only torch's own GEMMs)
         early_stopping = EarlyStopping(patience=a.patience, verbose=self.rank == 0, delta=0)
         t_start = time.time()
         train_step = 0
-        amp = a.amp and self.device.type == 'cuda'
         for epoch in range(a.train_epochs):
-            self.model.train()
             if len(self.train_loader) == 0:
                 continue
-            losses = []
-            for batch_x, label, padding_mask in self.train_loader:
-                train_step += 1
-                batch_x, label, padding_mask = self._to_device(batch_x, label, padding_mask)
-                with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=amp):
-                    logits, info = self._forward(batch_x, padding_mask)
-                    if a.model == 'InterpGN' and logits.is_cuda and not amp:
-                        # CE(mixture) + beta*CE(sbm) and both logit gradients in one launch (ops.ign_loss) instead of
-                        # ~40 softmax / nll / mean kernels between the forward and the backward pass
-                        beta = compute_beta(epoch, a.train_epochs, a.beta_schedule)
-                        loss = ign_ops.ign_loss(info.shapelet_preds, info.dnn_preds, label, beta)[0] + info.loss.mean()
-                    else:
-                        loss = F.cross_entropy(logits, label)
-                        if a.model != 'DNN':
-                            loss = loss + info.loss.mean()
-                        if a.model == 'InterpGN':
-                            beta = compute_beta(epoch, a.train_epochs, a.beta_schedule)
-                            loss = loss + beta * F.cross_entropy(info.shapelet_preds, label)
-                if a.gradient_accumulation_steps > 1:
-                    loss = loss / a.gradient_accumulation_steps
-                loss.backward()
-                if train_step % a.gradient_accumulation_steps == 0:
-                    if self.bucket is not None:
-                        self.bucket.allreduce()
-                    if a.gradient_clip > 0:
-                        nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=a.gradient_clip)
-                    self.optimizer.step()
-                    if a.pos_weight:
-                        self.model.step()
-                    if self.bucket is not None:
-                        self.bucket.zero_grad()
-                    else:
-                        self.optimizer.zero_grad()
-                losses.append(loss.detach())
+            losses, train_step = self.train_one_epoch(epoch, train_step)
             if not losses:
                 continue
             train_loss = torch.stack(losses).mean().item()      # one host sync per epoch (the reference syncs per step)

@@ -90,6 +90,16 @@ SIGNATURES = {
     "ign_bn_bwd_apply": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ign_timing_enable": (ci, [ci]),
     "ign_timing_read": (ci, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
+    "ign_clconv_wgrad_x6_nsplit": (ci, [ci, ci, ci, ci, ci]),
+    "ign_clconv_wgrad_reduce_multi": (ci, [ci, vp, vp, vp, vp, vp, vp, vp]),
+    "ign_clconv_pack_weights_x3_multi": (ci, [ci, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ign_head_bwd_acc": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]),
+    "ign_loss_fwd_bwd_reg": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp]),
+    "ign_sbm_reg_workspace_bytes": (sz, [ci, ci, ll]),
+    "ign_sbm_reg_fwd_bwd": (ci, [vp, vp, ll, cf, ci, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp]),
+    "ign_shapelet_bwd_bank_workspace_bytes": (sz, [ci, ci, ci, ci, vp, vp, vp, ci]),
+    "ign_shapelet_bwd_bank": (ci, [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, cf, ci,
+                                   vp]),
     "ign_shapelet_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),
 }
 

@@ -45,12 +45,17 @@ class BnState:
         self.use_batch_stats = bn.training or not bn.track_running_stats
         self.running_mean = self.running_var = None
         self.momentum = 0.0
+        self.bump = None            # the num_batches_tracked counter to increment (fcn_body bumps every block's in ONE launch)
         if bn.track_running_stats:
             self.running_mean, self.running_var = bn.running_mean, bn.running_var
             if bn.training:
-                if bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked.add_(1)
-                self.momentum = float(bn.momentum) if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                if bn.momentum is None:     # cumulative moving average: the factor needs the counter's value on the host
+                    if bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked.add_(1)
+                    self.momentum = 1.0 / float(bn.num_batches_tracked)
+                else:
+                    self.bump = bn.num_batches_tracked
+                    self.momentum = float(bn.momentum)
         self.update_running = bn.training and bn.track_running_stats
 
 
@@ -73,6 +78,27 @@ class FcnBodyFn(torch.autograd.Function):
         conv_fwd = L.ign_clconv_fwd_bf16 if math == "bf16" else L.ign_clconv_fwd_x6
         inputs, affine, wds, shapes = [x], [], [], []
         pa = pb = None
+        packed = None
+        if x6 and nl <= 8:
+            # prologue: the weights of every block packed (split into bf16 planes) in ONE launch, which also bumps the
+            # BatchNorm step counters of the blocks that track running statistics
+            ws_ = [params[4 * l].contiguous() for l in range(nl)]
+            wts = [torch.empty(int(L.ign_clconv_x3_elems(w.shape[0], w.shape[1], w.shape[2])), device=dev, dtype=torch.bfloat16)
+                   for w in ws_]
+            wds_ = [torch.empty(int(L.ign_clconv_x3_elems(w.shape[1], w.shape[0], w.shape[2])), device=dev, dtype=torch.bfloat16)
+                    if (l > 0 and need_grad) else None for l, w in enumerate(ws_)]
+            vpa, ia = ctypes.c_void_p * nl, ctypes.c_int * nl
+            pv = lambda ts: vpa(*[(t.data_ptr() if t is not None else None) for t in ts])
+            bumps = [st.bump for st in states]
+            _lib.check(L.ign_clconv_pack_weights_x3_multi(nl, pv(ws_), pv(wts), pv(wds_), ia(*[w.shape[0] for w in ws_]),
+                                                          ia(*[w.shape[1] for w in ws_]), ia(*[w.shape[2] for w in ws_]),
+                                                          pv(bumps) if any(b is not None for b in bumps) else None, _stream()),
+                       "ign_clconv_pack_weights_x3_multi")
+            packed = (wts, wds_)
+        else:
+            bumps = [st.bump for st in states if st.bump is not None]
+            if bumps:
+                torch._foreach_add_(bumps, 1)
         for l in range(nl):
             w, b, gamma, beta = (p.contiguous() for p in params[4 * l:4 * l + 4])
             Co, Ci, k = w.shape
@@ -87,9 +113,13 @@ class FcnBodyFn(torch.autograd.Function):
             part = torch.empty(nparts, 2, Co, **f32) if st.use_batch_stats else None
             want_wd = l > 0 and need_grad
             if x6:
-                wt = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
-                wd = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, k)), device=dev, dtype=torch.bfloat16) if want_wd else None
-                _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt), _ptr(wd), Co, Ci, k, _stream()), "ign_clconv_pack_weights_x3")
+                if packed is not None:
+                    wt, wd = packed[0][l], packed[1][l]
+                else:
+                    wt = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
+                    wd = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, k)), device=dev, dtype=torch.bfloat16) if want_wd else None
+                    _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt), _ptr(wd), Co, Ci, k, _stream()),
+                               "ign_clconv_pack_weights_x3")
                 _lib.check(conv_fwd(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part), B, Tin, Ci, Co, k, _stream()),
                            "ign_clconv_fwd_x6")
             else:
@@ -135,6 +165,13 @@ class FcnBodyFn(torch.autograd.Function):
         f32 = dict(device=dev, dtype=torch.float32)
         gpool = gpool.contiguous()
         grads = [None] * (4 * nl)
+        # The bias in front of a batch-statistics BatchNorm has an identically zero gradient (the batch mean removes it): the
+        # zeros of all blocks are views of ONE buffer (one fill launch)
+        zoff, ztot = [], 0
+        for (Co_, _, _, _, _), bs_ in zip(shapes, batch_stats):
+            zoff.append(ztot)
+            ztot += Co_ if bs_ else 0
+        zbuf = torch.zeros(ztot, **f32) if ztot else None
 
         # last block: pool -> ReLU mask -> BatchNorm-backward sums
         Co, Ci, k, Tin, Tout = shapes[-1]
@@ -145,6 +182,9 @@ class FcnBodyFn(torch.autograd.Function):
         part = torch.empty(nparts, 2, Co, **f32)
         _lib.check(L.ign_bn_relu_pool_bwd(_ptr(y), _ptr(gpool), _ptr(a), _ptr(bb), _ptr(mean), _ptr(invstd), _ptr(g), _ptr(part),
                                           B, Tout, Co, _stream()), "ign_bn_relu_pool_bwd")
+        # weight-gradient partials of every block are reduced by ONE launch at the end (split-bf16 kernels with k in 2,3,5,8)
+        defer = x6 and all(sh[2] in (2, 3, 5, 8) for sh in shapes) and nl <= 8
+        deferred = []
         for l in range(nl - 1, -1, -1):
             Co, Ci, k, Tin, Tout = shapes[l]
             a, bb, mean, invstd = affine[l]
@@ -166,13 +206,14 @@ class FcnBodyFn(torch.autograd.Function):
             ws = torch.empty(int(ws_bytes) // 4, **f32)
             dw = torch.empty(Co, Ci, k, **f32)
             wgrad = (L.ign_clconv_wgrad_bf16 if math == "bf16" else L.ign_clconv_wgrad_x6) if wx6 else L.ign_clconv_wgrad
-            _lib.check(wgrad(_ptr(dyp), pad, _ptr(inputs[l]), _ptr(pa), _ptr(pb), _ptr(dw), _ptr(ws), B, Tin, Ci, Co, k,
-                             _stream()), "ign_clconv_wgrad")
+            _lib.check(wgrad(_ptr(dyp), pad, _ptr(inputs[l]), _ptr(pa), _ptr(pb), None if defer else _ptr(dw), _ptr(ws), B, Tin, Ci,
+                             Co, k, _stream()), "ign_clconv_wgrad")
+            if defer:
+                deferred.append((ws, dw, int(L.ign_clconv_wgrad_x6_nsplit(B, Tin, Ci, Co, k)), Co, Ci, k))
             del ws
             grads[4 * l + 0] = dw
-            # The bias in front of a batch-statistics BatchNorm has an identically zero gradient (the batch mean removes
-            # it); with running statistics it is the column sum of dL/dy.
-            grads[4 * l + 1] = torch.zeros(Co, **f32) if training else dyp.sum(dim=(0, 1))
+            # bias: zero with batch statistics (see above); with running statistics it is the column sum of dL/dy
+            grads[4 * l + 1] = zbuf[zoff[l]:zoff[l] + Co] if training else dyp.sum(dim=(0, 1))
             grads[4 * l + 2] = dgamma
             grads[4 * l + 3] = dbeta
             if l > 0:
@@ -184,6 +225,13 @@ class FcnBodyFn(torch.autograd.Function):
                 _lib.check(dgrad(_ptr(dyp), _ptr(wds[l]), _ptr(inputs[l]), _ptr(pa_), _ptr(pb_), _ptr(pm_), _ptr(pi_),
                                               _ptr(g), _ptr(part), B, Tin, Ci, Co, k, _stream()), "ign_clconv_dgrad")
             del dyp
+        if deferred:
+            n = len(deferred)
+            vpa, ia = ctypes.c_void_p * n, ctypes.c_int * n
+            _lib.check(L.ign_clconv_wgrad_reduce_multi(n, vpa(*[d[0].data_ptr() for d in deferred]), vpa(*[d[1].data_ptr() for d in deferred]),
+                                                       ia(*[d[2] for d in deferred]), ia(*[d[3] for d in deferred]),
+                                                       ia(*[d[4] for d in deferred]), ia(*[d[5] for d in deferred]), _stream()),
+                       "ign_clconv_wgrad_reduce_multi")
         ctx.saved = None
         return (None, None, *grads)
 
@@ -193,7 +241,7 @@ def fcn_body(x, blocks, math=None):
     `math`: arithmetic of the GEMMs (see CONV_MATH); default = "bf16" inside an autocast region, else CONV_MATH."""
     if math is None:
         math = "bf16" if torch.is_autocast_enabled() else CONV_MATH
-    states = [BnState(bn) for _, bn in blocks]
+    states = [BnState(bn) for _, bn in blocks]            # (the step counters are bumped by the node's prologue launch)
     params = []
     for conv, bn in blocks:
         if conv.bias is None or bn.weight is None or bn.bias is None:

@@ -59,6 +59,103 @@ def standardise_nct_to_btc(x_nct, eps=1e-8):
     return out
 
 
+def _tables(G):
+    return ctypes.c_void_p * G, ctypes.c_int * G
+
+
+def _pv(ts):
+    return (ctypes.c_void_p * len(ts))(*[(t.data_ptr() if t is not None else None) for t in ts])
+
+
+def _bank_forward(xn, ws, thrs, eps, mode, strides, need_grad):
+    """Forward of every length group of a bank: -> (P, D, saved) with P / D (B, sum_g K_g*C) in the reference's feature order
+    g*K*C + k*C + c (IGN/model/Shapelet.py:84,195-196) and saved[g] = (tstar, zmu, dsave, col0, stride, xstat)."""
+    B, C, T = xn.shape
+    ld = sum(w.shape[0] * C for w in ws)
+    P = torch.empty(B, ld, device=xn.device, dtype=torch.float32)
+    D = torch.empty_like(P)
+    L = _lib.lib()
+    saved, col0 = [], 0
+    for g, w in enumerate(ws):
+        K, Cw, Lg = w.shape
+        if Cw != C:
+            raise _lib.IgnError(f"shapelet group {g}: weights have {Cw} channels, input has {C}")
+        stride = int(strides[g])
+        Tw = (T - Lg) // stride + 1
+        tstar = torch.empty(B, K, C, device=xn.device, dtype=torch.int32)
+        zmu = torch.empty(B, K, C, 2, device=xn.device, dtype=torch.float32)
+        dsave = torch.empty(B, C, K, Tw, device=xn.device, dtype=torch.float32) if need_grad else None
+        xstat = torch.empty(B, C, Tw, device=xn.device, dtype=torch.float32) \
+            if (need_grad and (mode & 0xf) >= DIST_COS) else None
+        saved.append((tstar, zmu, dsave, col0, stride, xstat))
+        col0 += K * C
+    G = len(ws)
+    if G <= 8:
+        # the whole bank in one call (ign_shapelet_fwd_bank validates every group, then launches group by group)
+        _, ia = _tables(G)
+        _lib.check(L.ign_shapelet_fwd_bank(
+            _ptr(xn), G, _pv(ws), _pv(thrs), _ptr(P), _ptr(D), ld, ia(*[sv[3] for sv in saved]), _pv([sv[0] for sv in saved]),
+            _pv([sv[1] for sv in saved]), _pv([sv[2] for sv in saved]), _pv([sv[5] for sv in saved]), B, C, T,
+            ia(*[w.shape[0] for w in ws]), ia(*[w.shape[2] for w in ws]), ia(*[sv[4] for sv in saved]), float(eps), int(mode),
+            _stream()), "ign_shapelet_fwd_bank")
+    else:
+        for g, w in enumerate(ws):
+            tstar, zmu, dsave, c0, stride, xstat = saved[g]
+            _lib.check(L.ign_shapelet_fwd(_ptr(xn), _ptr(w), _ptr(thrs[g]), _ptr(P), _ptr(D), ld, c0, _ptr(tstar), _ptr(zmu),
+                                          _ptr(dsave), _ptr(xstat), B, C, T, w.shape[0], w.shape[2], stride, float(eps), int(mode),
+                                          _stream()), "ign_shapelet_fwd")
+    return P, D, saved
+
+
+def _cat_tstar(saved, B):
+    return torch.cat([sv[0].reshape(B, -1) for sv in saved], dim=1) if len(saved) > 1 else saved[0][0].reshape(B, -1)
+
+
+def _bank_backward(xn, ws, gP, P, D, saved, eps, mode, gw_add=None, add_scale=None):
+    """dloss/dw of every group (list of (K,C,L) tensors) from gP = dloss/dP (B, ld).  `gw_add[g]` / `add_scale` (a one-element
+    device tensor): a batch-independent gradient of the same shapelets that the reduction launch adds as add_scale * gw_add[g]
+    (the diversity regulariser) -- a parameter with two gradient sources then needs no accumulate kernel."""
+    B, C, T = xn.shape
+    ld = P.shape[1]
+    L = _lib.lib()
+    G = len(ws)
+    cos = (mode & 0xf) >= DIST_COS
+    wnorms = [w.square().sum(dim=-1).sqrt().contiguous() if cos else None for w in ws]
+    gws = [torch.empty_like(w) for w in ws]
+    if G <= 8:
+        _, ia = _tables(G)
+        Ks, Ls, Ss = ia(*[w.shape[0] for w in ws]), ia(*[w.shape[2] for w in ws]), ia(*[sv[4] for sv in saved])
+        nbytes = L.ign_shapelet_bwd_bank_workspace_bytes(G, B, C, T, Ks, Ls, Ss, mode)
+        if nbytes == 0:
+            raise _lib.IgnError(f"shapelet backward: no launch plan for K={list(Ks)} L={list(Ls)} stride={list(Ss)}")
+        work = torch.empty(nbytes // 4, device=xn.device, dtype=torch.float32)
+        _lib.check(L.ign_shapelet_bwd_bank(
+            _ptr(xn), G, _pv(ws), _ptr(gP), _ptr(P), _ptr(D), ld, ia(*[sv[3] for sv in saved]), _pv([sv[0] for sv in saved]),
+            _pv([sv[1] for sv in saved]), _pv([sv[2] for sv in saved]), _pv([sv[5] for sv in saved]), _pv(wnorms), _pv(gws),
+            _pv(gw_add) if gw_add is not None else None, _ptr(add_scale), _ptr(work), B, C, T, Ks, Ls, Ss, float(eps), int(mode),
+            _stream()), "ign_shapelet_bwd_bank")
+        return gws
+    for g, w in enumerate(ws):
+        K, _, Lg = w.shape
+        tstar, zmu, dsave, col0, stride, xstat = saved[g]
+        nbytes = L.ign_shapelet_bwd_workspace_bytes(B, C, T, K, Lg, stride, mode)
+        if nbytes == 0:
+            raise _lib.IgnError(f"shapelet backward: no launch plan for K={K} L={Lg} stride={stride}")
+        work = torch.empty(nbytes // 4, device=xn.device, dtype=torch.float32)
+        _lib.check(L.ign_shapelet_bwd(_ptr(xn), _ptr(w), _ptr(gP), _ptr(P), _ptr(D), ld, col0,
+                                      _ptr(tstar), _ptr(zmu), _ptr(dsave), _ptr(xstat), _ptr(wnorms[g]), _ptr(gws[g]), _ptr(work),
+                                      B, C, T, K, Lg, stride, eps, mode, _stream()), "ign_shapelet_bwd")
+        if gw_add is not None and gw_add[g] is not None:
+            gws[g] = gws[g] + (gw_add[g] if add_scale is None else gw_add[g] * add_scale)
+    return gws
+
+
+def _threshold_grads(gP, P, ws, saved, C):
+    """LTS: dP/dthr = sigma'(thr - m) = P(1-P), summed over the batch  (IGN/model/Shapelet.py:109)"""
+    gt = (gP * P * (1 - P)).sum(0)
+    return [gt[sv[3]:sv[3] + w.shape[0] * C].view(1, w.shape[0], C) for w, sv in zip(ws, saved)]
+
+
 class ShapeletBankFn(torch.autograd.Function):
     """All length groups of a shapelet bank in one autograd node.
 
@@ -76,43 +173,9 @@ class ShapeletBankFn(torch.autograd.Function):
         thrs = [t.contiguous() for t in params[n_groups:]] if (mode & GATE_LTS) else [None] * n_groups
         _need_gpu("shapelet_fwd", xn, *ws, *[t for t in thrs if t is not None])
         xn = xn.contiguous()
-        B, C, T = xn.shape
-        ld = sum(w.shape[0] * C for w in ws)
-        P = torch.empty(B, ld, device=xn.device, dtype=torch.float32)
-        D = torch.empty_like(P)
         need_grad = any(ctx.needs_input_grad[5:])     # grad mode is off inside forward(); ask the node instead
-        L = _lib.lib()
-        saved, col0 = [], 0
-        for g, w in enumerate(ws):
-            K, Cw, Lg = w.shape
-            if Cw != C:
-                raise _lib.IgnError(f"shapelet group {g}: weights have {Cw} channels, input has {C}")
-            stride = int(strides[g])
-            Tw = (T - Lg) // stride + 1
-            tstar = torch.empty(B, K, C, device=xn.device, dtype=torch.int32)
-            zmu = torch.empty(B, K, C, 2, device=xn.device, dtype=torch.float32)
-            dsave = torch.empty(B, C, K, Tw, device=xn.device, dtype=torch.float32) if need_grad else None
-            xstat = torch.empty(B, C, Tw, device=xn.device, dtype=torch.float32) \
-                if (need_grad and (mode & 0xf) >= DIST_COS) else None
-            saved.append((tstar, zmu, dsave, col0, stride, xstat))
-            col0 += K * C
-        G = len(ws)
-        if G <= 8:
-            # the whole bank in one call (ign_shapelet_fwd_bank validates every group, then launches group by group)
-            vpa, ia = ctypes.c_void_p * G, ctypes.c_int * G
-            pv = lambda ts: vpa(*[(t.data_ptr() if t is not None else None) for t in ts])
-            _lib.check(L.ign_shapelet_fwd_bank(
-                _ptr(xn), G, pv(ws), pv(thrs), _ptr(P), _ptr(D), ld, ia(*[sv[3] for sv in saved]), pv([sv[0] for sv in saved]),
-                pv([sv[1] for sv in saved]), pv([sv[2] for sv in saved]), pv([sv[5] for sv in saved]), B, C, T,
-                ia(*[w.shape[0] for w in ws]), ia(*[w.shape[2] for w in ws]), ia(*[sv[4] for sv in saved]), float(eps), int(mode),
-                _stream()), "ign_shapelet_fwd_bank")
-        else:
-            for g, w in enumerate(ws):
-                tstar, zmu, dsave, c0, stride, xstat = saved[g]
-                _lib.check(L.ign_shapelet_fwd(_ptr(xn), _ptr(w), _ptr(thrs[g]), _ptr(P), _ptr(D), ld, c0, _ptr(tstar), _ptr(zmu),
-                                              _ptr(dsave), _ptr(xstat), B, C, T, w.shape[0], w.shape[2], stride, float(eps), int(mode),
-                                              _stream()), "ign_shapelet_fwd")
-        Tstar = torch.cat([sv[0].reshape(B, -1) for sv in saved], dim=1) if len(saved) > 1 else saved[0][0].reshape(B, -1)
+        P, D, saved = _bank_forward(xn, ws, thrs, eps, mode, strides, need_grad)
+        Tstar = _cat_tstar(saved, xn.shape[0])
         ctx.mark_non_differentiable(D, Tstar)
         ctx.meta = (float(eps), int(mode), n_groups, saved, need_grad)
         ctx.save_for_backward(xn, P, D, *ws, *[t for t in thrs if t is not None])
@@ -125,28 +188,9 @@ class ShapeletBankFn(torch.autograd.Function):
             raise _lib.IgnError("shapelet backward called but the forward ran without saving distances")
         xn, P, D = ctx.saved_tensors[:3]
         ws = ctx.saved_tensors[3:3 + G]
-        thrs = ctx.saved_tensors[3 + G:]
         gP = gP.contiguous()
-        B, C, T = xn.shape
-        ld = P.shape[1]
-        L = _lib.lib()
-        grads_w, grads_t = [], []
-        for g, w in enumerate(ws):
-            K, _, Lg = w.shape
-            tstar, zmu, dsave, col0, stride, xstat = saved[g]
-            wnorm = w.square().sum(dim=-1).sqrt().contiguous() if (mode & 0xf) >= DIST_COS else None
-            nbytes = L.ign_shapelet_bwd_workspace_bytes(B, C, T, K, Lg, stride, mode)
-            if nbytes == 0:
-                raise _lib.IgnError(f"shapelet backward: no launch plan for K={K} L={Lg} stride={stride}")
-            work = torch.empty(nbytes // 4, device=xn.device, dtype=torch.float32)
-            gw = torch.empty_like(w)
-            _lib.check(L.ign_shapelet_bwd(_ptr(xn), _ptr(w), _ptr(gP), _ptr(P), _ptr(D), ld, col0,
-                                          _ptr(tstar), _ptr(zmu), _ptr(dsave), _ptr(xstat), _ptr(wnorm), _ptr(gw), _ptr(work),
-                                          B, C, T, K, Lg, stride, eps, mode, _stream()), "ign_shapelet_bwd")
-            grads_w.append(gw)
-            if mode & GATE_LTS:       # dP/dthr = sigma'(thr - m) = P(1-P);  IGN/model/Shapelet.py:109
-                Pg = P[:, col0:col0 + K * C]
-                grads_t.append((gP[:, col0:col0 + K * C] * Pg * (1 - Pg)).sum(0).view(1, K, C))
+        grads_w = _bank_backward(xn, ws, gP, P, D, saved, eps, mode)
+        grads_t = _threshold_grads(gP, P, ws, saved, xn.shape[1]) if mode & GATE_LTS else []
         return (None, None, None, None, None, *grads_w, *grads_t)
 
 
@@ -161,6 +205,87 @@ def shapelet_bank(xn, weights, eps, mode=DIST_L1 | GATE_RBF, strides=None, thres
     params = list(weights) + (list(thresholds) if (mode & GATE_LTS) else [])
     P, D, Tstar = ShapeletBankFn.apply(xn, eps, mode, tuple(strides), G, *params)
     return (P, D, Tstar) if return_tstar else (P, D)
+
+
+class SbmFn(torch.autograd.Function):
+    """The shapelet bottleneck model behind the instance norm as ONE autograd node: shapelet bank (every length group) ->
+    linear class head (optional) -> both regularisers (IGN/model/Shapelet.py:190-210, 217-230).
+
+    forward(xn, cfg, W, w_0..w_{G-1}[, thr_0..thr_{G-1}]) -> (P, Dmin, Tstar | None, reg, out | None)
+      cfg = (eps, mode, strides, G, lambda_reg, lambda_div, fuse_head, want_tstar, reg_workspace)
+      reg (1,) = lambda_reg * mean|W| + lambda_div * sum_g diversity_g -- value AND gradients from one launch
+      (ign_sbm_reg_fwd_bwd); out = P W^T when fuse_head.
+    Why one node: W and every w_g receive a gradient from the data path and one from a regulariser.  As separate nodes
+    autograd adds the two with one accumulate kernel per parameter and the regularisers cost ~30 small launches per step
+    (abs / mean / mul, four diversity launches, their sums and products, backward mirrors).  Here the head's weight-gradient
+    kernel and the bank's reduction launch add `upstream * regulariser gradient` in their epilogues: the backward is
+    head_bwd (2 launches) + G shapelet launches + 1 reduction, with no torch kernel in between."""
+
+    @staticmethod
+    def forward(ctx, xn, cfg, W, *params):
+        eps, mode, strides, G, lam_reg, lam_div, fuse_head, want_tstar, reg_ws = cfg
+        ws = [w.contiguous() for w in params[:G]]
+        thrs = [t.contiguous() for t in params[G:]] if (mode & GATE_LTS) else [None] * G
+        _need_gpu("sbm", xn, W, *ws, *[t for t in thrs if t is not None])
+        xn, W = xn.contiguous(), W.contiguous()
+        B, C, T = xn.shape
+        need_grad = any(ctx.needs_input_grad[2:])
+        L = _lib.lib()
+        P, D, saved = _bank_forward(xn, ws, thrs, eps, mode, strides, need_grad)
+        Tstar = _cat_tstar(saved, B) if want_tstar else None
+        # regularisers: value + gradients, one launch
+        use_div = lam_div > 0.0
+        gWreg = torch.empty_like(W)
+        gdiv = [torch.empty_like(w) for w in ws] if use_div else None
+        reg = torch.empty(1, device=xn.device, dtype=torch.float32)
+        Gd = G if use_div else 0
+        _, ia = _tables(max(G, 1))
+        _lib.check(L.ign_sbm_reg_fwd_bwd(_ptr(W), _ptr(gWreg), W.numel(), float(lam_reg), Gd, _pv(ws), _pv(gdiv) if use_div else None,
+                                         ia(*[w.shape[0] for w in ws]), ia(*[w.shape[2] for w in ws]), C, float(lam_div), 1e-6,
+                                         _ptr(reg), _ptr(reg_ws), _stream()), "ign_sbm_reg_fwd_bwd")
+        out = None
+        if fuse_head:
+            N, F_ = W.shape
+            out = torch.empty(B, N, device=xn.device, dtype=torch.float32)
+            _lib.check(L.ign_head_fwd(_ptr(P), _ptr(W), None, _ptr(out), B, F_, N, P.stride(0), _stream()), "ign_head_fwd")
+        ctx.set_materialize_grads(False)
+        nd = [D] + ([Tstar] if Tstar is not None else [])
+        ctx.mark_non_differentiable(*nd)
+        ctx.meta = (float(eps), int(mode), G, saved, need_grad, fuse_head, gdiv)
+        ctx.save_for_backward(xn, P, D, W, gWreg, *ws)
+        return P, D, Tstar, reg, out
+
+    @staticmethod
+    def backward(ctx, gP, gD, gT, greg, gout):
+        eps, mode, G, saved, had_grad, fuse_head, gdiv = ctx.meta
+        if not had_grad:
+            raise _lib.IgnError("shapelet backward called but the forward ran without saving distances")
+        xn, P, D, W, gWreg = ctx.saved_tensors[:5]
+        ws = ctx.saved_tensors[5:5 + G]
+        B, C, T = xn.shape
+        L = _lib.lib()
+        greg = greg.contiguous().reshape(1) if greg is not None else None
+        gW = None
+        if fuse_head and gout is not None:
+            N, F_ = W.shape
+            gout = gout.contiguous()
+            gPh = torch.empty_like(P)
+            gW = torch.empty_like(W)
+            _lib.check(L.ign_head_bwd_acc(_ptr(gout), _ptr(P), _ptr(W), _ptr(gPh), _ptr(gW), None,
+                                          _ptr(gWreg) if greg is not None else None, _ptr(greg), B, F_, N, P.stride(0), _stream()),
+                       "ign_head_bwd_acc")
+            gP = gPh if gP is None else gPh + gP
+        elif greg is not None and ctx.needs_input_grad[2]:
+            gW = gWreg * greg
+        if gP is None:             # nothing reached the gate outputs: only the regulariser moves the shapelets
+            grads_w = [(gd * greg if (gdiv is not None and greg is not None) else None) for gd in (gdiv or [None] * G)]
+            grads_t = [None] * G if mode & GATE_LTS else []
+        else:
+            gP = gP.contiguous()
+            add = gdiv if (gdiv is not None and greg is not None) else None
+            grads_w = _bank_backward(xn, ws, gP, P, D, saved, eps, mode, gw_add=add, add_scale=greg if add is not None else None)
+            grads_t = _threshold_grads(gP, P, ws, saved, C) if mode & GATE_LTS else []
+        return (None, None, gW, *grads_w, *grads_t)
 
 
 def _bl_strides(t, name):
@@ -556,33 +681,64 @@ def gini_gate(sbm_out, dnn_out, gating_value=None):
     return GiniGateFn.apply(sbm_out.float(), dnn_out.float(), gating_value)
 
 
+_UNIT = {}
+
+
+def unit_grad(device):
+    """The constant 1.0 on `device` (one cached 0-dim tensor): the root gradient of `backward(loss)`."""
+    t = _UNIT.get(device)
+    if t is None:
+        t = _UNIT[device] = torch.ones((), device=device, dtype=torch.float32)
+    return t
+
+
+def backward(loss):
+    """loss.backward() without the two launches autograd spends on the root of the graph: `ones_like(loss)` is replaced by a
+    cached constant, and ops.ign_loss recognises that constant (by address) and hands out its saved logit gradients unscaled."""
+    if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32:
+        loss.backward(gradient=unit_grad(loss.device))
+    else:
+        loss.backward()
+
+
 class IgnLossFn(torch.autograd.Function):
-    """CE(gate(sbm, dnn), y) + beta * CE(sbm, y) with both gradients from one launch (ign_loss_fwd_bwd)."""
+    """CE(gate(sbm, dnn), y) + beta * CE(sbm, y) [+ reg] with both logit gradients from one launch (ign_loss_fwd_bwd_reg)."""
 
     @staticmethod
-    def forward(ctx, sbm, dnn, y, beta):
-        _need_gpu("ign_loss", sbm, dnn)
+    def forward(ctx, sbm, dnn, y, beta, reg):
+        _need_gpu("ign_loss", sbm, dnn, reg)
         sbm, dnn = sbm.contiguous(), dnn.contiguous()
         y = y.contiguous().long()
         B, N = sbm.shape
-        out, gs, gd = torch.empty_like(sbm), torch.empty_like(sbm), torch.empty_like(sbm)
+        out = torch.empty_like(sbm)
+        gsd = torch.empty(2, B, N, device=sbm.device, dtype=torch.float32)       # (d loss / d sbm, d loss / d dnn), one buffer
         eta = torch.empty(B, 1, device=sbm.device, dtype=torch.float32)
         loss2 = torch.empty(3, device=sbm.device, dtype=torch.float32)
-        _lib.check(_lib.lib().ign_loss_fwd_bwd(_ptr(sbm), _ptr(dnn), _ptr(y), _ptr(out), _ptr(eta), _ptr(loss2), _ptr(gs), _ptr(gd),
-                                               B, N, float(beta), _stream()), "ign_loss_fwd_bwd")
-        ctx.save_for_backward(gs, gd)
+        if reg is not None:
+            reg = reg.contiguous().reshape(-1)
+            if reg.numel() != 1:
+                raise _lib.IgnError(f"ign_loss: the regulariser must be one value, got {tuple(reg.shape)}")
+        _lib.check(_lib.lib().ign_loss_fwd_bwd_reg(_ptr(sbm), _ptr(dnn), _ptr(y), _ptr(reg), _ptr(out), _ptr(eta), _ptr(loss2),
+                                                   _ptr(gsd[0]), _ptr(gsd[1]), B, N, float(beta), _stream()), "ign_loss_fwd_bwd")
+        ctx.save_for_backward(gsd)
+        ctx.reg_shape = None if reg is None else tuple(reg.shape)
         ctx.mark_non_differentiable(out, eta)
         return loss2[2], out, eta
 
     @staticmethod
     def backward(ctx, gl, gout, geta):
-        gs, gd = ctx.saved_tensors
-        return gl * gs, gl * gd, None, None
+        (gsd,) = ctx.saved_tensors
+        unit = _UNIT.get(gl.device)
+        # the root gradient of ops.backward(): exactly 1 -- no scaling launch; otherwise one launch for both logit gradients
+        g = gsd if (unit is not None and gl.data_ptr() == unit.data_ptr()) else gl * gsd
+        return g[0], g[1], None, None, (gl.reshape(ctx.reg_shape) if ctx.reg_shape is not None else None)
 
 
-def ign_loss(sbm_out, dnn_out, y, beta=1.0):
-    """-> (CE(mix, y) + beta*CE(sbm, y), mix, eta); mix / eta are reporting outputs (no gradient flows through them)."""
-    return IgnLossFn.apply(sbm_out.float(), dnn_out.float(), y, beta)
+def ign_loss(sbm_out, dnn_out, y, beta=1.0, reg=None):
+    """-> (CE(mix, y) + beta*CE(sbm, y) [+ reg], mix, eta); mix / eta are reporting outputs (no gradient flows through them).
+    `reg`: the model's regulariser value (ModelInfo.loss, one element) -- added on the device inside the same launch, i.e. the
+    whole training loss of IGN/exp/experiment_classification.py:325-329 (its gradient passes straight through)."""
+    return IgnLossFn.apply(sbm_out.float(), dnn_out.float(), y, beta, reg)
 
 
 class Conv1SumSqFn(torch.autograd.Function):

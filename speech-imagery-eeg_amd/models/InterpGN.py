@@ -56,9 +56,13 @@ class InterpGN(nn.Module):
     # times -- so what the second stream hides is only the memory- / latency-bound glue and the tails of the grids
     # (~1 ms of a 13.4 ms step), not the convolution GEMMs themselves.
     expert_streams = os.environ.get("IGN_EXPERT_STREAMS", "1") != "0"
+    # Below this many input elements (B*T*C) a step is launch-bound, not kernel-bound (run_uea.sh trains at B = 32 on series of a
+    # few thousand samples): the experts then run on ONE stream -- nothing to overlap, no fork / join events per step, and a
+    # captured hipGraph of the step (ign_hip/graph.py) is a plain chain instead of two branches that replay serialised.
+    two_stream_min_elems = 1 << 21
 
     def _experts(self, x, x_mark_enc, x_dec, x_mark_dec, mask):
-        if not (self.expert_streams and x.is_cuda):
+        if not (self.expert_streams and x.is_cuda and x.numel() >= self.two_stream_min_elems):
             sbm_out, info = self.sbm(x)
             return sbm_out, info, self.deep_model(x, x_mark_enc, x_dec, x_mark_dec, mask)
         main = torch.cuda.current_stream(x.device)

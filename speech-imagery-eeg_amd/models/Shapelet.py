@@ -145,7 +145,38 @@ class ShapeBottleneckModel(nn.Module):
             return self.output_layer(self.dropout(p)) + self.output_bilinear(self.dropout(p), self.dropout(p))
         return self.output_layer(self.dropout(self.attention(p)))
 
+    def _fused_forward(self, x, xn):
+        """Bank + linear head + both regularisers as ONE autograd node (ops.SbmFn): 1 instance-norm launch, G shapelet launches,
+        1 regulariser launch, 1 head launch -- and a backward without a single torch kernel.  Returns None when the
+        configuration is outside that node (pearson centring runs through autograd; > 8 groups; > 16 shapelets per group)."""
+        first = self.shapelets[0]
+        mode = first.mode()
+        G = len(self.shapelets)
+        if (mode & 0xf) == ops.DIST_PEARSON or G > 8 or max(s.n for s in self.shapelets) > 16 or not x.is_cuda \
+                or x.dtype != torch.float32:
+            return None
+        if xn is None:
+            xn, _ = ops.instance_norm(x)
+        lts = first.gate == ops.GATE_LTS
+        fuse_head = self.configs.sbm_cls == 'linear' and (self.dropout.p == 0.0 or not self.training)
+        W = self.output_layer.weight
+        ws = getattr(self, '_reg_ws', None)
+        need = ops._lib.lib().ign_sbm_reg_workspace_bytes(G, self.num_channel, W.numel()) // 4
+        if ws is None or ws.device != x.device or ws.numel() < need:
+            ws = self._reg_ws = torch.zeros(need, device=x.device, dtype=torch.float32)   # zero-filled once; the kernel re-arms it
+        cfg = (first.eps, mode, tuple(s.stride for s in self.shapelets), G, float(self.lambda_reg), float(self.lambda_div),
+               fuse_head, not self.training, ws)
+        params = [s.weights for s in self.shapelets] + ([s.threshold for s in self.shapelets] if lts else [])
+        p, d, t, reg, out = ops.SbmFn.apply(xn, cfg, W, *params)
+        if out is None:
+            out = self.head(p)
+        return out, ModelInfo(d=d, p=p, shapelet_preds=out, preds=out, loss=reg, t=t)
+
     def forward(self, x, *args, xn=None, **kwargs):
+        """-> (logits, ModelInfo).  ModelInfo.t (match locations) is filled in eval mode only: the training step never reads it."""
+        fused = self._fused_forward(x, xn)
+        if fused is not None:
+            return fused
         p, d, t = self.shapelet_features(x, xn)
         out = self.head(p)
         return out, ModelInfo(d=d, p=p, shapelet_preds=out, preds=out, loss=self.loss().unsqueeze(0), t=t)

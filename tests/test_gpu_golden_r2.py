@@ -241,7 +241,10 @@ def test_sbm_and_lts_at_the_chisco_shape_with_the_6x10_bank(name, lts):
         parity(k, v, g[k], kind="elem")
     # rows whose two best windows tie (from the oracle's distances), and the kernel's choice among them
     xn_o = O.instance_norm(torch.from_numpy(g["x"]))
-    t_hip = info.t.cpu().long()
+    m.eval()                                   # the match locations are an eval-mode output (the training step never reads them)
+    with torch.no_grad():
+        t_hip = m(x)[1].t.cpu().long()
+    m.train()
     C, col, tie_rows, n_tie = 122, 0, [], 0
     for gi, w in enumerate(w_cpu):
         K = w.shape[0]

@@ -160,6 +160,28 @@ def test_synthetic_and_npy_providers(tmp_path):
         EEGNpyDataset3Class(str(tmp_path / "nope"), "train")
 
 
+def test_tensor_batch_loader_yields_the_collate_contract():
+    """data_provider's in-memory fast path (TensorBatchLoader, `--data SYNTH`) against DataLoader + collate_fn on the same data set
+    and order: same tensors, dtypes and shapes, ragged last batch included; a sampler and a shuffled epoch cover every index once."""
+    from torch.utils.data import DataLoader
+    from data_provider.device_prefetch import TensorBatchLoader
+    from data_provider.synthetic import SyntheticEEG
+    from data_provider.uea import collate_fn
+    ds = SyntheticEEG(flag='val', n=21, seq_len=30, enc_in=4)
+    ref = list(DataLoader(ds, batch_size=8, shuffle=False, collate_fn=lambda b: collate_fn(b, max_len=30)))
+    got = list(TensorBatchLoader(ds, 8, shuffle=False))
+    assert len(got) == len(ref) == len(TensorBatchLoader(ds, 8)) == 3
+    for (x, y, m), (xr, yr, mr) in zip(got, ref):
+        assert x.dtype == xr.dtype and y.dtype == yr.dtype and m.dtype == mr.dtype
+        assert torch.equal(x, xr) and torch.equal(y, yr) and torch.equal(m, mr)
+    torch.manual_seed(0)
+    seen = torch.cat([y for _, y, _ in TensorBatchLoader(ds, 8, shuffle=True)])
+    assert seen.shape == (21, 1)
+    idx = [20, 3, 3, 7]
+    xs = torch.cat([x for x, _, _ in TensorBatchLoader(ds, 3, sampler=idx)])
+    assert torch.equal(xs, ds.x[idx])
+
+
 # ----------------------------------------------------------------------------------------------- harness
 def test_early_stopping_contract(tmp_path):
     from utils.tools import EarlyStopping, convert_to_hms, gini_coefficient
