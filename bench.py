@@ -191,8 +191,9 @@ def harness_leg(B, epochs=2):
             "--train_epochs", str(epochs + 1), "--num_workers", "0", "--seed", "0"]
     a = ign_run.get_args(argv)
     a.synthetic = f"{N_TRAIN},122,1000,3"
+    import contextlib
     cwd = os.getcwd()
-    with tempfile.TemporaryDirectory() as tmp:
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(sys.stderr):      # stdout carries ONE JSON line
         os.chdir(tmp)                                        # Experiment creates ./checkpoints
         try:
             ign_run.set_seed(0)
@@ -320,7 +321,7 @@ class Bench:
             return self.graphed(x, y)
         loss = self.loss_of(x, y)
         self.ops.backward(loss)                  # = loss.backward(), as Experiment.train_one_epoch calls it
-        if time_allreduce and self.world > 1:
+        if time_allreduce and (self.world > 1 or self.bucket.force_collective):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             self.bucket.allreduce()
@@ -334,7 +335,7 @@ class Bench:
 
     def fence(self):
         torch.cuda.synchronize()
-        if self.world > 1:
+        if self.dist is not None:
             self.dist.barrier()
         torch.cuda.synchronize()
 
@@ -545,7 +546,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # an explicit one-rank rendezvous (WORLD_SIZE=1 with RANK and MASTER_ADDR set, e.g. `torch.distributed.run --nproc-per-node 1`):
+    # the collective path runs on a one-rank RCCL communicator -- the part of config 5 a one-GPU box can exercise
+    solo_pg = world == 1 and all(k in os.environ for k in ("WORLD_SIZE", "RANK", "MASTER_ADDR", "MASTER_PORT"))
+    if world > 1 or solo_pg:
         import torch.distributed as dist
         if rehearsal:
             dist.init_process_group("gloo")
@@ -557,6 +561,7 @@ def main():
     from ign_hip import _lib
 
     b = Bench(args.config, args, dev, rank, world, dist)
+    b.bucket.force_collective = solo_pg
     B, T, C, cfg = b.B, b.T, b.C, b.cfg
     n_batches = min(args.steps + args.warmup, max(1, N_TRAIN // (B * world)))
     log(f"generating {n_batches} synthetic batches on the host ...")
@@ -653,7 +658,7 @@ def main():
                   "data": "resident in HBM (no H2D copy in the timed region; the harness path with the per-step copy is the "
                           "`harness` object)",
                   "parallelism": f"dp{world}", "final_loss": float(last), "hipgraph": bool(b.use_graph)}
-        if world > 1:
+        if world > 1 or solo_pg:
             common["collective"] = {"backend": "gloo (rehearsal)" if rehearsal else "nccl (RCCL over xGMI)", "ranks": world,
                                     "bucket_bytes": b.bucket.nbytes, "allreduce_ms_per_step": ar_ms,
                                     "what": "one all-reduce(sum) of the flat fp32 gradient bucket per optimizer step, then / ranks"}
@@ -778,7 +783,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline_ign(cfg, args.cpu_sample, host_cores())
         print(json.dumps(res), flush=True)
     _lib.timing_enable(False)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -15,8 +15,11 @@ import torch.distributed as dist
 class FlatParamBucket:
     ALIGN = 64          # floats
 
-    def __init__(self, module, world_size=None, process_group=None):
+    def __init__(self, module, world_size=None, process_group=None, force_collective=False):
         self.group = process_group
+        # run the all-reduce even at world size 1 (a one-rank RCCL communicator: exercises initialisation, stream ordering with
+        # the library's kernels and the timing fields on a one-GPU box; the result is unchanged -- sum over one rank, / 1)
+        self.force_collective = bool(force_collective)
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
         self.params = [p for p in module.parameters() if p.requires_grad]
         if not self.params:
@@ -83,10 +86,11 @@ class FlatParamBucket:
     def allreduce(self):
         """Average the gradients over ranks: one collective on the flat bucket."""
         self.gather()
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return
         dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat_grad.div_(self.world)
+        if self.world > 1:
+            self.flat_grad.div_(self.world)
 
     def zero_grad(self):
         """GPU: drop the gradients (``gather`` rebuilds the flat buffer at the next step, no zero-fill and no

@@ -158,7 +158,8 @@ class ShapeBottleneckModel(nn.Module):
         if xn is None:
             xn, _ = ops.instance_norm(x)
         lts = first.gate == ops.GATE_LTS
-        fuse_head = self.configs.sbm_cls == 'linear' and (self.dropout.p == 0.0 or not self.training)
+        fuse_head = self.configs.sbm_cls == 'linear' and (self.dropout.p == 0.0 or not self.training) \
+            and self.total_shapelets % 4 == 0          # the streaming head kernel reads float4 rows (else: ops.head_linear's route)
         W = self.output_layer.weight
         ws = getattr(self, '_reg_ws', None)
         need = ops._lib.lib().ign_sbm_reg_workspace_bytes(G, self.num_channel, W.numel()) // 4

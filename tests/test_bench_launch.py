@@ -53,6 +53,28 @@ def test_two_rank_rehearsal_end_to_end():
     assert "rehearsal" in res["config"] and res["scaling"] == "weak"
 
 
+@pytest.mark.gpu
+def test_one_rank_rccl_rendezvous_emits_the_collective_fields():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: an explicit WORLD_SIZE=1 rendezvous runs the gradient
+    all-reduce on a one-rank RCCL communicator and reports config.collective (backend nccl, bucket bytes, ms per step)."""
+    if not has_gpu():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--batch", "8", "--alt-steps", "0", "--iso-steps", "1", "--cpu-sample", "0", "--baseline-steps", "0",
+                        "--harness-epochs", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    col = res["config"]["collective"]
+    assert res["n_gpus"] == 1 and col["ranks"] == 1 and col["backend"].startswith("nccl") and col["bucket_bytes"] > 300_000
+    assert col["allreduce_ms_per_step"] > 0
+
+
 def test_committed_bench_line_carries_the_contract_fields():
     """The driver-facing JSON line (profiles/r2k_bench_line.json = the default `python bench.py` run of the round-end
     measurement pass): metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline /

@@ -93,3 +93,54 @@ def test_two_ranks_on_the_hip_models_equal_one_process_on_the_joint_batch(tmp_pa
         a, b = ddp[k].double().numpy(), v.double().cpu().numpy()
         diff = np.abs(a - b)
         assert (diff > 5e-4 + 5e-3 * np.abs(b)).mean() <= 0.05 and diff.max() <= 3 * 2 * 5e-3 + 1e-6, k
+
+
+# ---------------------------------------------------------------------------------------------------------------- RCCL, one rank
+def _rccl_worker(rank, port, out):
+    """A fresh process (nothing has touched the GPU before the process group exists): backend nccl (= RCCL), world size 1."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    from argparse import Namespace
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import speech_imagery_eeg_amd  # noqa: F401
+    from ign_hip import ops
+    from ign_hip.ddp import FlatAdam, FlatParamBucket
+    from models.InterpGN import InterpGN
+    cfg = Namespace(enc_in=6, seq_len=100, num_class=4, epsilon=1.0, distance_func='euclidean', memory_efficient=False,
+                    sbm_cls='linear', dropout=0.0, lambda_reg=0.1, lambda_div=0.1, dnn_type='FCN')
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(8, 100, 6, generator=g).to(dev) for _ in range(2)]
+    ys = [torch.randint(0, 4, (8,), generator=g).to(dev) for _ in range(2)]
+    finals = []
+    for collective in (True, False):
+        torch.manual_seed(11)
+        model = InterpGN(cfg).to(dev).train()
+        bucket = FlatParamBucket(model, 1, force_collective=collective)
+        opt = FlatAdam(bucket, lr=5e-3)
+        for x, y in zip(xs, ys):
+            _, info = model(x, None, None, None)
+            ops.backward(ops.ign_loss(info.shapelet_preds, info.dnn_preds, y, 1.0, reg=info.loss)[0])
+            bucket.allreduce()                        # on the compute stream, between the library's backward kernels and Adam
+            opt.step()
+            bucket.zero_grad()
+        torch.cuda.synchronize()
+        finals.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    same = all(torch.equal(finals[0][k], finals[1][k]) for k in finals[0])
+    torch.save({"same": same, "backend": dist.get_backend(), "n": len(finals[0])}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_allreduce_between_backward_and_adam_is_bitwise_neutral(tmp_path):
+    """RCCL smoke on one GPU (the only part of BASELINE.json config 5 a one-GPU box can exercise): torch.distributed backend
+    "nccl" with world size 1, FlatParamBucket.allreduce() forced through the communicator between the HIP backward kernels and
+    the flat Adam launch, two IGN(FCN) steps -- the parameters must equal the no-collective run bit for bit (sum over one rank)."""
+    if not has_gpu():
+        pytest.skip("needs a GPU")
+    out = str(tmp_path / "rccl.pt")
+    mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
+    res = torch.load(out, weights_only=True)
+    assert res["backend"] == "nccl" and res["same"] and res["n"] > 10
