@@ -602,7 +602,8 @@ def main():
     alt = None
     if args.config == "ign" and args.alt_steps > 0 and not args.planted:
         from ign_hip import fcn as _fcn_alt
-        if _fcn_alt.CONV_MATH == "bf16x6":
+        if _fcn_alt.CONV_MATH in ("bf16x6", "f16x3"):
+            _was_math = _fcn_alt.CONV_MATH
             _fcn_alt.CONV_MATH = "f32"
             try:
                 for i in range(2):
@@ -612,7 +613,7 @@ def main():
                        "ms_per_step": 1e3 * dt_alt / args.alt_steps,
                        "value": (args.alt_steps * B * world / N_TRAIN) / dt_alt, "unit": "epochs/s"}
             finally:
-                _fcn_alt.CONV_MATH = "bf16x6"
+                _fcn_alt.CONV_MATH = _was_math
 
     # Kernel durations free of co-running kernels: in the timed region the two experts of IGN run on two HIP streams, so
     # a kernel's event bracket also contains the time it shared the CUs with the other expert.  A short serial pass
@@ -693,10 +694,13 @@ def main():
                                  + f" IGN({args.dnn} expert), "
                                  + ("driver-default groups K=5 x L=" if args.groups == "4x5" else "stress bank K=10 x L=")
                                  + "{" + ",".join(str(L_) for _, L_ in groups) + "}" + ", Adam lr 5e-3, fp32",
-                                 conv_math=_fcn.CONV_MATH + (" (fp32 operands split exactly into 3 bf16 terms, 6 partial products "
-                                                            "accumulated in fp32; <= 3e-6 vs float64, same as the fp32-MFMA "
-                                                            "kernel; IGN_CONV_MATH=f32 selects that one)"
-                                                            if _fcn.CONV_MATH == "bf16x6" else ""))
+                                 conv_math=_fcn.CONV_MATH + {
+                                     "bf16x6": " (fp32 operands split exactly into 3 bf16 terms, 6 partial products accumulated in "
+                                               "fp32; <= 3e-6 vs float64, same as the fp32-MFMA kernel; IGN_CONV_MATH=f32 selects that one)",
+                                     "f16x3": " (fp32 operands scaled by a power of two from a device-side magnitude bound, split into 2 "
+                                              "fp16 terms, 3 partial products accumulated in fp32; <= 3e-6 vs float64, same as the "
+                                              "six-product bf16 and the fp32-MFMA kernels: IGN_CONV_MATH=bf16x6 / f32 select those)"
+                                 }.get(_fcn.CONV_MATH, ""))
             res["roofline"] = {"bound": "valu", "kernel": "shp_bwd_kernel", "achieved": bwd_tflops,
                                "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": bwd_tflops / PEAK_FP32_VALU_TFLOPS,
                                "traffic": traffic, "traffic_source": traffic_src,
@@ -712,14 +716,15 @@ def main():
             if iso and args.shape == "ch":
                 def _tf(flops, ms):
                     return flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-                x6 = _fcn.CONV_MATH == "bf16x6"
+                nprod = {"bf16x6": 6.0, "f16x3": 3.0}.get(_fcn.CONV_MATH)
 
                 def _conv_roof(tf_alg, ms):
-                    # split-bf16: six bf16 MFMA products per algorithmic fp32 product, priced against the dense bf16 peak
-                    if x6:
+                    # split operands: six bf16 (three fp16) MFMA products per algorithmic fp32 product, priced as EXECUTED 16-bit
+                    # flops against the dense bf16 / fp16 peak (the two run at the same rate on gfx950)
+                    if nprod:
                         return {"ms_per_step": ms, "achieved": tf_alg, "unit": "TFLOP/s fp32-equivalent (algorithmic)",
-                                "executed_bf16_tflops": 6.0 * tf_alg, "peak": PEAK_BF16_MFMA_TFLOPS,
-                                "frac": 6.0 * tf_alg / PEAK_BF16_MFMA_TFLOPS}
+                                "products_per_fp32_product": nprod, "executed_16bit_tflops": nprod * tf_alg,
+                                "peak": PEAK_BF16_MFMA_TFLOPS, "frac": nprod * tf_alg / PEAK_BF16_MFMA_TFLOPS}
                     if _fcn.CONV_MATH == "bf16":
                         # operands rounded to bf16, one product (the reference's autocast arithmetic): priced against the bf16 peak
                         return {"ms_per_step": ms, "achieved": tf_alg, "unit": "TFLOP/s bf16 (one product, fp32 accumulate)",

@@ -368,6 +368,43 @@ int ign_clconv_wgrad_reduce_multi(int n, const void* const* part, float* const* 
 int ign_clconv_pack_weights_x3_multi(int n, const float* const* w_oik, void* const* wt3_fwd, void* const* wt3_dgrad,
                                      const int* Co, const int* Ci, const int* k, long long* const* counters, void* stream);
 
+/* ---- Two-plane fp16 GEMMs ("h3"): fp32 accuracy from THREE products per element pair instead of six.
+ * Every fp32 operand x of a GEMM is first multiplied by a power of two s (exact) chosen from an upper bound of the tensor's
+ * magnitude so that 2^13 <= bound * s < 2^14, then split into two fp16 terms h0 = fp16(s x), h1 = fp16(s x - h0) (the residual
+ * is an exact fp32 subtraction), and the products a0 b0 + a0 b1 + a1 b0 are accumulated in fp32 by v_mfma_f32_32x32x16_f16; the
+ * epilogue multiplies by 1 / (s_a s_b) (exact).  What is dropped is O(2^-22 |a b|) per product -- at the level of the fp32
+ * accumulation error of a K ~ 1000 reduction; measured against float64 the results are as close as the six-product bf16 kernels
+ * and the fp32-MFMA kernels (tests/test_gpu_fcn.py runs every case on all three).  Without the scaling fp16's narrow exponent
+ * range would lose the second term of small operands (gradients of 1e-5: 5e-4 relative error); with it the absolute error of
+ * an element is <= 2^-22 of the tensor's bound.  Bounds are device scalars (`slots`: 4 floats per layer, see ign_fcn_scan):
+ *   weights        max |W|                       -- ign_fcn_scan, from the parameters
+ *   layer input    l = 0: max |x| (ign_absmax);  l > 0: max_c(|gamma_c| sqrt(R - 1) + |beta_c|) of the BatchNorm in front, a HARD
+ *                  bound of relu(gamma yhat + beta): a value standardised with the batch's own statistics over R rows cannot
+ *                  exceed sqrt(R - 1) (training mode only; eval mode keeps the bf16 kernels)
+ *   dL/dy          max |dL/dy|, taken by ign_bn_bwd_apply_amax as it writes the tensor (integer atomicMax on the bit patterns of
+ *                  non-negative floats: exact and order-independent, so results stay bitwise reproducible)
+ * Replaces the same reference lines as ign_clconv_fwd / _dgrad / _wgrad (IGN/model/FullyConvNet.py:31-59 and its autograd).   */
+int ign_absmax(const float* x, long long n, float* slot /* max'ed into, caller zeroes */, void* stream);
+int ign_fcn_scan(int nl, const float* const* w, const long long* nw, const float* const* gamma_prev, const float* const* beta_prev,
+                 const int* C_prev, const long long* R_prev, float* slots /* (nl, 4): written */, void* stream);
+int ign_clconv_pack_weights_h2_multi(int n, const float* const* w_oik, void* const* wt_fwd, void* const* wt_dgrad, const int* Co,
+                                     const int* Ci, const int* k, long long* const* counters, const float* const* w_bounds,
+                                     void* stream);
+int ign_clconv_fwd_h3(const float* x, const void* wt_h2, const float* bias, const float* pro_a, const float* pro_b, float* y,
+                      float* stat_part, const float* bound_in, const float* bound_w, int B, int Tin, int Ci, int Co, int k,
+                      void* stream);
+int ign_clconv_dgrad_h3(const float* dyp, const void* wt_h2_dgrad, const float* y_in, const float* a_in, const float* b_in,
+                        const float* mean_in, const float* invstd_in, float* g_in, float* stat_part, const float* bound_dy,
+                        const float* bound_w, int B, int Tin, int Ci, int Co, int k, void* stream);
+int ign_clconv_wgrad_h3(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b, float* dw_oik,
+                        void* workspace, const float* bound_dy, const float* bound_x, int B, int Tin, int Ci, int Co, int k,
+                        void* stream);
+int ign_linear_wgrad_h3(const float* dy, const float* x, float* dw, float* db, void* workspace, const float* bound_dy,
+                        const float* bound_x, long long M, int Ci, int Co, void* stream);
+int ign_bn_bwd_apply_amax(const float* g, const float* y, const float* a, const float* mean, const float* invstd,
+                          const float* dbeta, const float* dgamma, float* dyp, float* amax_slot, int B, int T, int C, int pad,
+                          int training, void* stream);
+
 /* The three split-bf16 GEMMs with ONE product per step: operands rounded to bf16 (round-to-nearest-even), products and sums in
  * fp32 -- the arithmetic of the reference's default bf16-autocast mode (IGN/exp/experiment_classification.py:319; `--amp`
  * switches it OFF).  Same packed weights (plane 0 is read), same arguments, same workspace as the *_x6 entry points.        */

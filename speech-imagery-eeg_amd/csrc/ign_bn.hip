@@ -3,6 +3,25 @@
 // and the elementwise BatchNorm-backward pass that writes dL/dy in the zero-padded layout the GEMMs read.
 #include "ign_clconv.h"
 
+// maxima of non-negative floats as unsigned integers on their bit patterns (see 'operand bounds' below)
+__device__ __forceinline__ void atomic_absmax(float* slot, float v) {                 // v >= 0
+    unsigned int* u = reinterpret_cast<unsigned int*>(slot);
+    const unsigned int b = __float_as_uint(v);
+    if (b > __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(u, b);
+}
+__device__ __forceinline__ float block_max_1024(float v, float* sh) {                // result valid in thread 0
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 1; i < nw; ++i) v = fmaxf(v, sh[i]);
+    }
+    return v;
+}
+
+
 // ------------------------------------------------------------------------------------------------ BatchNorm glue
 // Sum of the per-tile partials (nparts, 2, C) for BN_CH channels per block: BN_SL slices of the partials are summed in
 // parallel (ascending inside a slice, fp32 over <= 64 addends, then double), and the slice sums are combined in fixed order
@@ -165,10 +184,12 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ a, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ dbeta,
                                                            const float* __restrict__ dgamma, float* __restrict__ dyp, int T, int C,
-                                                           int pad, long long rows_padded, float invR, int training) {
+                                                           int pad, long long rows_padded, float invR, int training,
+                                                           float* __restrict__ amax_slot) {
     const int c4 = C / 4, rif = 256 / c4;
     const int col = (threadIdx.x % c4) * 4, rofs = threadIdx.x / c4;
     if (rofs >= rif) return;
+    float amax = 0.f;
     float ca[4], c1[4], c0[4];
     vload<4>(ca, a + col);
     if (training) {
@@ -196,10 +217,87 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
             vload<4>(gg, g + off);
             if (training) vload<4>(yy, y + off);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) out[q] = fmaf(ca[q], gg[q], fmaf(c1[q], yy[q], c0[q]));
+            for (int q = 0; q < 4; ++q) { out[q] = fmaf(ca[q], gg[q], fmaf(c1[q], yy[q], c0[q])); amax = fmaxf(amax, fabsf(out[q])); }
         }
         vstore<4>(dyp + (size_t)row * C + col, out);
     }
+    if (amax_slot) {              // max |dL/dy| for the fp16 GEMMs that read this tensor (bitwise reproducible: integer max)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if ((threadIdx.x & 63) == 0) atomic_absmax(amax_slot, amax);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ operand bounds (fp16 path)
+// The two-plane fp16 GEMMs (ign_clconv_*_h3) scale each operand tensor by a power of two taken from an upper bound of its
+// magnitude (ign_pow2_scale).  Bounds live in a small device array of `slots` (4 floats per layer):
+//   slot 4l + 0  max |W_l|                                    (fcn_scan_kernel, from the parameters)
+//   slot 4l + 1  bound of the layer's INPUT as the GEMM sees it: l = 0: max |x| (absmax_kernel, from the data); l > 0:
+//                max_c ( |gamma_c| sqrt(R - 1) + |beta_c| ) of the BatchNorm in front -- a hard bound of relu(gamma yhat + beta),
+//                because a value standardised with the batch's own mean and variance over R rows cannot exceed sqrt(R - 1)
+//   slot 4l + 2  max |dL/dy_l| (bn_bwd_apply_kernel, as it writes the tensor; zeroed by fcn_scan_kernel at the start of the step)
+// Maxima of non-negative floats are taken as unsigned integers on their bit patterns (order-preserving): atomicMax is exact
+// and order-independent, so the bounds -- and everything computed from them -- are bitwise reproducible.
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, long long n, float* __restrict__ slot) {
+    __shared__ float sh[16];
+    float m = 0.f;
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0)
+        for (long long i = (n4 << 2) + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
+    m = block_max_1024(m, sh);
+    if (threadIdx.x == 0) atomic_absmax(slot, m);
+}
+
+constexpr int SCAN_LMAX = 8;
+struct FcnScanTable {
+    const float* w[SCAN_LMAX]; long long nw[SCAN_LMAX];
+    const float* gamma[SCAN_LMAX]; const float* beta[SCAN_LMAX]; int C[SCAN_LMAX]; float sqrtR[SCAN_LMAX];
+};
+__global__ void __launch_bounds__(1024) fcn_scan_kernel(const FcnScanTable t, float* __restrict__ slots) {
+    __shared__ float sh[16];
+    const int l = blockIdx.x;
+    float m = 0.f;
+    for (long long i = threadIdx.x; i < t.nw[l]; i += 1024) m = fmaxf(m, fabsf(t.w[l][i]));
+    m = block_max_1024(m, sh);
+    if (threadIdx.x == 0) slots[4 * l + 0] = m;
+    __syncthreads();
+    float a = 0.f;
+    if (t.gamma[l])
+        for (int c = threadIdx.x; c < t.C[l]; c += 1024) a = fmaxf(a, fmaf(fabsf(t.gamma[l][c]), t.sqrtR[l], fabsf(t.beta[l][c])));
+    a = block_max_1024(a, sh);
+    if (threadIdx.x == 0) { slots[4 * l + 1] = a; slots[4 * l + 2] = 0.f; slots[4 * l + 3] = 0.f; }
+}
+
+extern "C" int ign_absmax(const float* x, long long n, float* slot, void* stream) {
+    if (!x || !slot || n <= 0 || ((uintptr_t)x & 15)) { ign_set_error("ign_absmax: null / unaligned pointer or n <= 0"); return IGN_E_ARG; }
+    const long long blocks = (n / 4 + 256 * 8 - 1) / (256 * 8);
+    IgnScopedTimer tm("absmax", (hipStream_t)stream);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0,
+                       (hipStream_t)stream, x, n, slot);
+    return ign_check_launch("absmax_kernel");
+}
+
+extern "C" int ign_fcn_scan(int nl, const float* const* w, const long long* nw, const float* const* gamma_prev,
+                            const float* const* beta_prev, const int* C_prev, const long long* R_prev, float* slots, void* stream) {
+    if (nl <= 0 || nl > SCAN_LMAX || !w || !nw || !slots) { ign_set_error("ign_fcn_scan: nl=%d outside 1..%d or null table", nl, SCAN_LMAX); return IGN_E_ARG; }
+    FcnScanTable t;
+    for (int l = 0; l < nl; ++l) {
+        if (!w[l] || nw[l] <= 0) { ign_set_error("ign_fcn_scan: layer %d: null weights", l); return IGN_E_ARG; }
+        t.w[l] = w[l]; t.nw[l] = nw[l];
+        const bool has = gamma_prev && gamma_prev[l];
+        if (has && (!beta_prev || !beta_prev[l] || !C_prev || !R_prev || C_prev[l] <= 0 || R_prev[l] <= 1)) {
+            ign_set_error("ign_fcn_scan: layer %d: BatchNorm in front needs beta, C > 0 and R > 1", l);
+            return IGN_E_ARG;
+        }
+        t.gamma[l] = has ? gamma_prev[l] : nullptr; t.beta[l] = has ? beta_prev[l] : nullptr;
+        t.C[l] = has ? C_prev[l] : 0; t.sqrtR[l] = has ? sqrtf((float)(R_prev[l] - 1)) : 0.f;
+    }
+    hipLaunchKernelGGL(fcn_scan_kernel, dim3(nl), dim3(1024), 0, (hipStream_t)stream, t, slots);
+    return ign_check_launch("fcn_scan_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -271,6 +369,12 @@ extern "C" int ign_bn_relu_pool_bwd(const float* y, const float* gpool, const fl
 extern "C" int ign_bn_bwd_apply(const float* g, const float* y, const float* a, const float* mean, const float* invstd,
                                 const float* dbeta, const float* dgamma, float* dyp, int B, int T, int C, int pad, int training,
                                 void* stream) {
+    return ign_bn_bwd_apply_amax(g, y, a, mean, invstd, dbeta, dgamma, dyp, nullptr, B, T, C, pad, training, stream);
+}
+
+extern "C" int ign_bn_bwd_apply_amax(const float* g, const float* y, const float* a, const float* mean, const float* invstd,
+                                     const float* dbeta, const float* dgamma, float* dyp, float* amax_slot, int B, int T, int C,
+                                     int pad, int training, void* stream) {
     int rc;
     if ((rc = bn_check("ign_bn_bwd_apply", (long long)B * T, C))) return rc;
     if (!g || !a || !dyp || pad < 0 || (training && (!y || !mean || !invstd || !dbeta || !dgamma))) {
@@ -280,7 +384,7 @@ extern "C" int ign_bn_bwd_apply(const float* g, const float* y, const float* a, 
     const long long rows = (long long)B * (T + 2 * pad);
     IgnScopedTimer tm("bn_bwd_apply", (hipStream_t)stream);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((rows + APPLY_ROWS - 1) / APPLY_ROWS)), dim3(256), 0, (hipStream_t)stream,
-                       g, y, a, mean, invstd, dbeta, dgamma, dyp, T, C, pad, rows, 1.0f / (float)((long long)B * T), training);
+                       g, y, a, mean, invstd, dbeta, dgamma, dyp, T, C, pad, rows, 1.0f / (float)((long long)B * T), training, amax_slot);
     return ign_check_launch("bn_bwd_apply_kernel");
 }
 

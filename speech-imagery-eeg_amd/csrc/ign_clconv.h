@@ -63,9 +63,11 @@ struct GemmNTArgs {
 // n = n0 + wn*64 + j*32 + l31 and the 16 rows m0 + wm*64 + i*32 + acc_row16(r, h).  `red` is >= 512 floats of LDS that no
 // wave still reads.  FULL = the whole 128x128 tile is inside the output: no per-element masks, and the 16 y values an
 // accumulator needs (EPI_MASK_STATS) are fetched as 16 independent loads before any of them is used.
-template <int EPI, bool FULL>
+// SC: the accumulators hold the product of two operands that were multiplied by powers of two before they were split (the
+// two-plane fp16 path, see ign_pow2_scale): every value is multiplied by `osc` = 1 / (scale_a * scale_b) first (exact).
+template <int EPI, bool FULL, bool SC = false>
 __device__ __forceinline__ void nt_epilogue_body(const GemmNTArgs& a, const f32x16 (&acc)[2][2], float (&s1)[2], float (&s2)[2],
-                                                 int m0, int n0, int m_lim) {
+                                                 int m0, int n0, int m_lim, float osc = 1.f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave & 1, wn = wave >> 1;
@@ -93,7 +95,7 @@ __device__ __forceinline__ void nt_epilogue_body(const GemmNTArgs& a, const f32x
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + acc_row16(r, h);
                 const bool ok = FULL || (n_ok && m < m_lim);
-                float v = acc[i][j][r];
+                float v = SC ? acc[i][j][r] * osc : acc[i][j][r];
                 if (EPI == EPI_BIAS_STATS) {
                     v += bv;
                     if (ok) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
@@ -107,15 +109,15 @@ __device__ __forceinline__ void nt_epilogue_body(const GemmNTArgs& a, const f32x
     }
 }
 
-template <int EPI>
+template <int EPI, bool SC = false>
 __device__ __forceinline__ void nt_epilogue(const GemmNTArgs& a, const f32x16 (&acc)[2][2], float* red, int mt, int m0, int n0,
-                                            int m_lim) {
+                                            int m_lim, float osc = 1.f) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave & 1, wn = wave >> 1;
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-    if (m0 + TM <= m_lim && n0 + TN <= a.N) nt_epilogue_body<EPI, true>(a, acc, s1, s2, m0, n0, m_lim);
-    else nt_epilogue_body<EPI, false>(a, acc, s1, s2, m0, n0, m_lim);
+    if (m0 + TM <= m_lim && n0 + TN <= a.N) nt_epilogue_body<EPI, true, SC>(a, acc, s1, s2, m0, n0, m_lim, osc);
+    else nt_epilogue_body<EPI, false, SC>(a, acc, s1, s2, m0, n0, m_lim, osc);
     if (a.part) {
         // combine the lane halves, then the two waves that share these columns, in a fixed order
         // red: [2 (wm)][2 (stat)][128 (col)]
@@ -146,8 +148,25 @@ struct ConvX6Args {
     int cin, cp, k;               // input channels, padded channels, taps
     int trows;                    // valid output rows per sample
     int tps;                      // m-tiles per sample
-    int nprod;                    // 6: three-way split, six partial products (fp32 accuracy); 1: operands rounded to bf16
+    int nprod;                    // 6: three-way bf16 split, six partial products (fp32 accuracy); 1: operands rounded to bf16;
+                                  // 3: two-way fp16 split of power-of-two-scaled operands, three partial products (fp32 accuracy)
+    const float* bound_a;         // nprod 3: device scalars, upper bounds of |A operand| (after the prologue) and of |weights|: the
+    const float* bound_b;         //          operands are scaled by ign_pow2_scale(bound) before the split (null: 1)
 };
+
+// Power-of-two scale for the two-plane fp16 split: 2^e with 2^13 <= bound * 2^e < 2^14, so that the leading fp16 term of every
+// element stays far from fp16's overflow (65504) and the second term of typical elements stays a NORMAL fp16 number
+// (1 for a null pointer, zero, or a non-finite bound; the exponent is clamped to +-60 so that products of two scales stay finite).
+__device__ __forceinline__ float ign_pow2_scale(const float* bound) {
+    if (!bound) return 1.f;
+    const float b = *bound;
+    if (!(b > 0.f) || !(b < INFINITY)) return 1.f;
+    int e;
+    (void)frexpf(b, &e);                     // b = m * 2^e, m in [0.5, 1)
+    e = 14 - e;
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);
+    return ldexpf(1.f, e);
+}
 
 inline int ign_vec_width(int c) { return (c % 4 == 0) ? 4 : (c % 2 == 0) ? 2 : 1; }
 

@@ -380,7 +380,8 @@ extern "C" int ign_clconv_pack_weights(const float* w_oik, float* wt_fwd, float*
 
 // x6: 0 = fp32 MFMA, 6 = split bf16 (six products), 1 = operands rounded to bf16 (one product)
 static int clconv_fwd_impl(const char* who, int x6, const float* x, const void* wt, const float* bias, const float* pro_a,
-                           const float* pro_b, float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream) {
+                           const float* pro_b, float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream,
+                           const float* bound_a = nullptr, const float* bound_w = nullptr) {
     const int Tout = Tin - k + 1;
     if (!x || !wt || !y || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || ((pro_a == nullptr) != (pro_b == nullptr))) {
         ign_set_error("%s: bad argument (B=%d Tin=%d Ci=%d Co=%d k=%d)", who, B, Tin, Ci, Co, k);
@@ -401,7 +402,7 @@ static int clconv_fwd_impl(const char* who, int x6, const float* x, const void* 
         c.g = a;
         c.cin = Ci; c.cp = (Ci + 15) / 16 * 16; c.k = k; c.g.Kp = k * c.cp;
         c.sample_pitch = (long long)Tin * Ci; c.rows_in = Tin; c.trows = Tout; c.tps = (Tout + TM - 1) / TM;
-        c.g.mtiles = B * c.tps; c.nprod = x6;
+        c.g.mtiles = B * c.tps; c.nprod = x6; c.bound_a = bound_a; c.bound_b = bound_w;
         return ign_clconv_launch_x6t(c, EPI_BIAS_STATS, ign_vec_width(Ci), pro_a != nullptr, (hipStream_t)stream);
     }
     return launch_nt<EPI_BIAS_STATS>(a, ign_vec_width(Ci), pro_a != nullptr, (hipStream_t)stream);
@@ -422,9 +423,18 @@ extern "C" int ign_clconv_fwd_bf16(const float* x, const void* wt3, const float*
     return clconv_fwd_impl("ign_clconv_fwd_bf16", 1, x, wt3, bias, pro_a, pro_b, y, stat_part, B, Tin, Ci, Co, k, stream);
 }
 
+extern "C" int ign_clconv_fwd_h3(const float* x, const void* wt_h2, const float* bias, const float* pro_a, const float* pro_b,
+                                 float* y, float* stat_part, const float* bound_in, const float* bound_w, int B, int Tin, int Ci,
+                                 int Co, int k, void* stream) {
+    if (!bound_in || !bound_w) { ign_set_error("ign_clconv_fwd_h3: null operand bound"); return IGN_E_ARG; }
+    return clconv_fwd_impl("ign_clconv_fwd_h3", 3, x, wt_h2, bias, pro_a, pro_b, y, stat_part, B, Tin, Ci, Co, k, stream, bound_in,
+                           bound_w);
+}
+
 static int clconv_dgrad_impl(const char* who, int x6, const float* dyp, const void* wt_dgrad, const float* y_in, const float* a_in,
                              const float* b_in, const float* mean_in, const float* invstd_in, float* g_in, float* stat_part, int B,
-                             int Tin, int Ci, int Co, int k, void* stream) {
+                             int Tin, int Ci, int Co, int k, void* stream, const float* bound_a = nullptr,
+                             const float* bound_w = nullptr) {
     const int Tout = Tin - k + 1;
     if (!dyp || !wt_dgrad || !y_in || !a_in || !b_in || !mean_in || !invstd_in || !g_in || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 ||
         Tout <= 0) {
@@ -447,7 +457,7 @@ static int clconv_dgrad_impl(const char* who, int x6, const float* dyp, const vo
         c.g = a;
         c.cin = Co; c.cp = (Co + 15) / 16 * 16; c.k = k; c.g.Kp = k * c.cp;
         c.sample_pitch = (long long)(Tout + 2 * (k - 1)) * Co; c.rows_in = Tout + 2 * (k - 1); c.trows = Tin; c.tps = (Tin + TM - 1) / TM;
-        c.g.mtiles = B * c.tps; c.nprod = x6;
+        c.g.mtiles = B * c.tps; c.nprod = x6; c.bound_a = bound_a; c.bound_b = bound_w;
         return ign_clconv_launch_x6t(c, EPI_MASK_STATS, ign_vec_width(Co), false, (hipStream_t)stream);
     }
     return launch_nt<EPI_MASK_STATS>(a, ign_vec_width(Co), false, (hipStream_t)stream);
@@ -472,6 +482,14 @@ extern "C" int ign_clconv_dgrad_bf16(const float* dyp, const void* wt3_dgrad, co
                                      int Ci, int Co, int k, void* stream) {
     return clconv_dgrad_impl("ign_clconv_dgrad_bf16", 1, dyp, wt3_dgrad, y_in, a_in, b_in, mean_in, invstd_in, g_in, stat_part, B,
                              Tin, Ci, Co, k, stream);
+}
+
+extern "C" int ign_clconv_dgrad_h3(const float* dyp, const void* wt_h2_dgrad, const float* y_in, const float* a_in, const float* b_in,
+                                   const float* mean_in, const float* invstd_in, float* g_in, float* stat_part, const float* bound_dy,
+                                   const float* bound_w, int B, int Tin, int Ci, int Co, int k, void* stream) {
+    if (!bound_dy || !bound_w) { ign_set_error("ign_clconv_dgrad_h3: null operand bound"); return IGN_E_ARG; }
+    return clconv_dgrad_impl("ign_clconv_dgrad_h3", 3, dyp, wt_h2_dgrad, y_in, a_in, b_in, mean_in, invstd_in, g_in, stat_part, B,
+                             Tin, Ci, Co, k, stream, bound_dy, bound_w);
 }
 
 static int wgrad_splits(long long M, int tiles) {

@@ -66,12 +66,45 @@ __device__ __forceinline__ void split3_store<4>(const float (&t)[4], __bf16* d, 
     *reinterpret_cast<bf16x4*>(d + 2 * plane) = __builtin_shufflevector(a2, b2, 0, 1, 2, 3);
 }
 
-// NP = number of bf16 planes an operand is split into: 3 (six partial products, fp32 accuracy) or 1 (the operand rounded to
-// bf16, one product: the arithmetic of the reference's default bf16-autocast mode, fp32 accumulation).
+// Two fp16 planes: x = h0 + h1 + O(2^-22 |x|), h0 = fp16(x), h1 = fp16(x - h0) (the residual is an exact fp32 subtraction).
+// The caller has scaled x by a power of two so that h0 stays below fp16's overflow and h1 stays a normal number for typical
+// elements (ign_pow2_scale).  Planes are 16-bit slots of the same LDS layout as the bf16 planes.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2h_pair(f32x2 v, f16x2& x0, f16x2& x1) {
+    x0 = __builtin_convertvector(v, f16x2);
+    x1 = __builtin_convertvector(v - __builtin_convertvector(x0, f32x2), f16x2);
+}
+template <int V>
+__device__ __forceinline__ void split2h_store(const float (&t)[V], __bf16* d, int plane) {
+    _Float16* dh = reinterpret_cast<_Float16*>(d);
+    if constexpr (V == 1) {
+        const _Float16 x0 = (_Float16)t[0];
+        dh[0] = x0; dh[plane] = (_Float16)(t[0] - (float)x0);
+    } else if constexpr (V == 2) {
+        f16x2 x0, x1;
+        split2h_pair(f32x2{t[0], t[1]}, x0, x1);
+        *reinterpret_cast<f16x2*>(dh) = x0;
+        *reinterpret_cast<f16x2*>(dh + plane) = x1;
+    } else {
+        f16x2 a0, a1, b0, b1;
+        split2h_pair(f32x2{t[0], t[1]}, a0, a1);
+        split2h_pair(f32x2{t[2], t[3]}, b0, b1);
+        *reinterpret_cast<f16x4*>(dh) = __builtin_shufflevector(a0, b0, 0, 1, 2, 3);
+        *reinterpret_cast<f16x4*>(dh + plane) = __builtin_shufflevector(a1, b1, 0, 1, 2, 3);
+    }
+}
+
+// NP = number of 16-bit planes an operand is split into: 3 (bf16, six partial products, fp32 accuracy), 2 (fp16 planes of a
+// power-of-two-scaled operand, three partial products, fp32 accuracy) or 1 (the operand rounded to bf16, one product: the
+// arithmetic of the reference's default bf16-autocast mode, fp32 accumulation).
 template <int V, int NP>
 __device__ __forceinline__ void split_store(const float (&t)[V], __bf16* d, int plane) {
     if constexpr (NP == 3) {
         split3_store<V>(t, d, plane);
+    } else if constexpr (NP == 2) {
+        split2h_store<V>(t, d, plane);
     } else if constexpr (V == 1) {
         d[0] = (__bf16)t[0];
     } else if constexpr (V == 2) {
@@ -81,6 +114,15 @@ __device__ __forceinline__ void split_store(const float (&t)[V], __bf16* d, int 
         const bf16x2 a = __builtin_convertvector(f32x2{t[0], t[1]}, bf16x2), b = __builtin_convertvector(f32x2{t[2], t[3]}, bf16x2);
         *reinterpret_cast<bf16x4*>(d) = __builtin_shufflevector(a, b, 0, 1, 2, 3);
     }
+}
+
+// one 32x32x16 MFMA step on a pair of 16-bit operand fragments: bf16 planes (NP 3 / 1) or fp16 planes (NP 2)
+template <int NP>
+__device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    if constexpr (NP == 2)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // ---- split-bf16 convolution with tap reuse.  The im2col rows of 128 consecutive output positions of one sample overlap:
@@ -145,10 +187,19 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
     const int ncc = ca.cp / KC;
     const int nstep = ncc * ca.k;
 
+    // two-plane fp16 path: operand scales (powers of two) from device-side bounds; the epilogue divides them out again
+    const float sa = (NP == 2) ? ign_pow2_scale(ca.bound_a) : 1.f;
+    const float osc = (NP == 2) ? 1.f / (sa * ign_pow2_scale(ca.bound_b)) : 1.f;
     auto aload = [&](int cc) {
         const int ch = cc * KC + (tid % VPR) * V;          // 256 % VPR == 0: a thread keeps its channel offset in every pass
         a_ok = ch < ca.cin;                                  // V divides cin: a vector is entirely inside or outside
-        if (PRO && a_ok) { vload<V>(pa, a.pro_a + ch); vload<V>(pb, a.pro_b + ch); }
+        if (PRO && a_ok) {
+            vload<V>(pa, a.pro_a + ch); vload<V>(pb, a.pro_b + ch);
+            if constexpr (NP == 2) {                         // relu(sa (a y + b)) = sa relu(a y + b): the scale rides on a, b
+#pragma unroll
+                for (int v = 0; v < V; ++v) { pa[v] *= sa; pb[v] *= sa; }
+            }
+        }
 #pragma unroll
         for (int p = 0; p < APASS; ++p) {
             const int idx = tid + p * 256;
@@ -172,6 +223,7 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
                 for (int v = 0; v < V; ++v) {
                     tv[v] = ra[p][v];
                     if (PRO && a_ok) tv[v] = fmaxf(fmaf(pa[v], tv[v], pb[v]), 0.f);
+                    else if (NP == 2) tv[v] *= sa;
                 }
                 split_store<V, NP>(tv, st + row * X6_PITCH + q * V, X6T_APLANE);
             }
@@ -186,19 +238,15 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
     auto bstore = [&](int buf, const uint4& r0, const uint4& r1, const uint4& r2) {
         __bf16* st = Bbuf + buf * X6T_BBUF + brw * X6_PITCH + 8 * bh;
         *reinterpret_cast<uint4*>(st) = r0;
-        if constexpr (NP == 3) {
-            *reinterpret_cast<uint4*>(st + X6_PLANE) = r1;
-            *reinterpret_cast<uint4*>(st + 2 * X6_PLANE) = r2;
-        }
+        if constexpr (NP >= 2) *reinterpret_cast<uint4*>(st + X6_PLANE) = r1;
+        if constexpr (NP == 3) *reinterpret_cast<uint4*>(st + 2 * X6_PLANE) = r2;
     };
-#define IGN_BLOAD(r0, r1, r2, st)                                                       \
-    do {                                                                                \
-        const size_t off_ = boff(st);                                                   \
-        r0 = *reinterpret_cast<const uint4*>(bsrc + off_);                              \
-        if constexpr (NP == 3) {                                                        \
-            r1 = *reinterpret_cast<const uint4*>(bsrc + bplane + off_);                 \
-            r2 = *reinterpret_cast<const uint4*>(bsrc + 2 * bplane + off_);             \
-        }                                                                               \
+#define IGN_BLOAD(r0, r1, r2, st)                                                                       \
+    do {                                                                                                \
+        const size_t off_ = boff(st);                                                                   \
+        r0 = *reinterpret_cast<const uint4*>(bsrc + off_);                                              \
+        if constexpr (NP >= 2) r1 = *reinterpret_cast<const uint4*>(bsrc + bplane + off_);              \
+        if constexpr (NP == 3) r2 = *reinterpret_cast<const uint4*>(bsrc + 2 * bplane + off_);          \
     } while (0)
 
     aload(0);
@@ -230,11 +278,12 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
         // the prefetched operands behind them
         __builtin_amdgcn_sched_barrier(0);
 #define IGN_X6(pa_, pb_)                                                                                   \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[0][pb_], acc[0][0], 0, 0, 0);   \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[1][pb_], acc[0][1], 0, 0, 0);   \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[0][pb_], acc[1][0], 0, 0, 0);   \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[1][pb_], acc[1][1], 0, 0, 0);
+        acc[0][0] = mfma16<NP>(af[0][pa_], bf[0][pb_], acc[0][0]);                                         \
+        acc[0][1] = mfma16<NP>(af[0][pa_], bf[1][pb_], acc[0][1]);                                         \
+        acc[1][0] = mfma16<NP>(af[1][pa_], bf[0][pb_], acc[1][0]);                                         \
+        acc[1][1] = mfma16<NP>(af[1][pa_], bf[1][pb_], acc[1][1]);
         if constexpr (NP == 3) { IGN_X6(2, 0) IGN_X6(0, 2) IGN_X6(1, 1) IGN_X6(1, 0) IGN_X6(0, 1) }
+        if constexpr (NP == 2) { IGN_X6(1, 0) IGN_X6(0, 1) }
         IGN_X6(0, 0)
 #undef IGN_X6
         __builtin_amdgcn_sched_barrier(0);
@@ -255,7 +304,7 @@ __global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca)
     }
 #undef IGN_BLOAD
     const int m0 = bi * ca.trows + t0;
-    nt_epilogue<EPI>(a, acc, reinterpret_cast<float*>(smem16), mt, m0, n0, bi * ca.trows + min(ca.trows, t0 + TM));
+    nt_epilogue<EPI, NP == 2>(a, acc, reinterpret_cast<float*>(smem16), mt, m0, n0, bi * ca.trows + min(ca.trows, t0 + TM), osc);
 }
 
 // ---- the k = 1 case with wide outputs (a Linear layer: N % 256 == 0): 128 x 256 output tile, eight waves (2 x 4 of 64 x 64).
@@ -309,29 +358,34 @@ __global__ void __launch_bounds__(512, 2) clconv_x6w_kernel(const ConvX6Args ca)
     constexpr size_t bplane = (size_t)TN * KC;
     uint4 rb00, rb01 = {}, rb02 = {}, rb10, rb11 = {}, rb12 = {};
 
+    const float sa = (NP == 2) ? ign_pow2_scale(ca.bound_a) : 1.f;
+    const float osc = (NP == 2) ? 1.f / (sa * ign_pow2_scale(ca.bound_b)) : 1.f;
 #define IGN_ALOADW(ra_, cc_)                                                                 \
     do {                                                                                     \
         const int c_ = min((cc_), ncc - 1);                                                  \
         if (c_ * KC + ach < ca.cin) vload<4>(ra_, ap + c_ * KC);  /* cin % 4 == 0 */         \
         else ra_[0] = ra_[1] = ra_[2] = ra_[3] = 0.f;                                        \
     } while (0)
-    auto astore = [&](int buf, const float (&r)[4]) { split_store<4, NP>(r, Abuf + buf * X6W_ABUF + arow * X6_PITCH + ach, APLANE); };
+    auto astore = [&](int buf, const float (&r)[4]) {
+        if constexpr (NP == 2) {
+            const float rs[4] = {r[0] * sa, r[1] * sa, r[2] * sa, r[3] * sa};
+            split_store<4, NP>(rs, Abuf + buf * X6W_ABUF + arow * X6_PITCH + ach, APLANE);
+        } else {
+            split_store<4, NP>(r, Abuf + buf * X6W_ABUF + arow * X6_PITCH + ach, APLANE);
+        }
+    };
     auto bstore = [&](int buf, const uint4& r0, const uint4& r1, const uint4& r2) {
         __bf16* st = Bbuf + buf * X6W_BBUF + bt * 3 * X6_PLANE + brw * X6_PITCH + 8 * bh;
         *reinterpret_cast<uint4*>(st) = r0;
-        if constexpr (NP == 3) {
-            *reinterpret_cast<uint4*>(st + X6_PLANE) = r1;
-            *reinterpret_cast<uint4*>(st + 2 * X6_PLANE) = r2;
-        }
+        if constexpr (NP >= 2) *reinterpret_cast<uint4*>(st + X6_PLANE) = r1;
+        if constexpr (NP == 3) *reinterpret_cast<uint4*>(st + 2 * X6_PLANE) = r2;
     };
-#define IGN_BLOADW(r0, r1, r2, st)                                                      \
-    do {                                                                                \
-        const size_t off_ = (size_t)min((st), ncc - 1) * X6_BLOCK;                      \
-        r0 = *reinterpret_cast<const uint4*>(bsrc + off_);                              \
-        if constexpr (NP == 3) {                                                        \
-            r1 = *reinterpret_cast<const uint4*>(bsrc + bplane + off_);                 \
-            r2 = *reinterpret_cast<const uint4*>(bsrc + 2 * bplane + off_);             \
-        }                                                                               \
+#define IGN_BLOADW(r0, r1, r2, st)                                                                      \
+    do {                                                                                                \
+        const size_t off_ = (size_t)min((st), ncc - 1) * X6_BLOCK;                                      \
+        r0 = *reinterpret_cast<const uint4*>(bsrc + off_);                                              \
+        if constexpr (NP >= 2) r1 = *reinterpret_cast<const uint4*>(bsrc + bplane + off_);              \
+        if constexpr (NP == 3) r2 = *reinterpret_cast<const uint4*>(bsrc + 2 * bplane + off_);          \
     } while (0)
 
     IGN_ALOADW(ra0, 0);
@@ -360,11 +414,12 @@ __global__ void __launch_bounds__(512, 2) clconv_x6w_kernel(const ConvX6Args ca)
             }
         __builtin_amdgcn_sched_barrier(0);
 #define IGN_X6(pa_, pb_)                                                                                   \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[0][pb_], acc[0][0], 0, 0, 0);   \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[1][pb_], acc[0][1], 0, 0, 0);   \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[0][pb_], acc[1][0], 0, 0, 0);   \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[1][pb_], acc[1][1], 0, 0, 0);
-        if constexpr (NP == 3) { IGN_X6(2, 0) IGN_X6(0, 2) IGN_X6(1, 1) IGN_X6(1, 0) IGN_X6(0, 1) }
+        acc[0][0] = mfma16<NP>(af[0][pa_], bf[0][pb_], acc[0][0]);                                         \
+        acc[0][1] = mfma16<NP>(af[0][pa_], bf[1][pb_], acc[0][1]);                                         \
+        acc[1][0] = mfma16<NP>(af[1][pa_], bf[0][pb_], acc[1][0]);                                         \
+        acc[1][1] = mfma16<NP>(af[1][pa_], bf[1][pb_], acc[1][1]);
+        if constexpr (NP == 3) { IGN_X6(2, 0) IGN_X6(0, 2) IGN_X6(1, 1) }
+        if constexpr (NP >= 2) { IGN_X6(1, 0) IGN_X6(0, 1) }
         IGN_X6(0, 0)
 #undef IGN_X6
         __builtin_amdgcn_sched_barrier(0);
@@ -391,16 +446,18 @@ __global__ void __launch_bounds__(512, 2) clconv_x6w_kernel(const ConvX6Args ca)
     // epilogue: bias + store (nt_epilogue_body derives wm / wn from the thread index: wn 0..3 covers the 256 columns)
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
     const int m_lim = a.M;
-    if (m0 + TM <= m_lim) nt_epilogue_body<EPI_BIAS_STATS, true>(a, acc, s1, s2, m0, n0, m_lim);
-    else nt_epilogue_body<EPI_BIAS_STATS, false>(a, acc, s1, s2, m0, n0, m_lim);
+    if (m0 + TM <= m_lim) nt_epilogue_body<EPI_BIAS_STATS, true, NP == 2>(a, acc, s1, s2, m0, n0, m_lim, osc);
+    else nt_epilogue_body<EPI_BIAS_STATS, false, NP == 2>(a, acc, s1, s2, m0, n0, m_lim, osc);
 }
 
 // Step-block-major planes for the kernel above: block (n-tile, chunk cc, tap j) = [plane][row 0..127][16 channels of chunk cc]
 // of tap j, contiguous; rows past N and channels past C are zero.
 //   forward: rows = co, value W[co][ci][j];   data gradient: rows = ci, channels = co, value W[co][ci][k-1-jj].
+// `bound` (nullable): pack for the two-plane fp16 kernels instead -- planes 0 / 1 hold the fp16 split of w * ign_pow2_scale(bound)
+// (plane 2 of the block is left untouched; the layout is the three-plane one so that both paths share their addressing).
 __device__ __forceinline__ void pack_weights_x3t_body(const float* __restrict__ w, unsigned short* __restrict__ wt3,
                                                       unsigned short* __restrict__ wd3, int Co, int Ci, int k, int Cip, int Cop,
-                                                      long long i) {
+                                                      long long i, const float* __restrict__ bound = nullptr) {
     const long long nf = (long long)((Co + TN - 1) / TN) * (Cip / KC) * k * (TN * KC);        // elements per plane set / 3
     const long long nd = wd3 ? (long long)((Ci + TN - 1) / TN) * (Cop / KC) * k * (TN * KC) : 0;
     const bool fwd = i < nf;
@@ -420,9 +477,16 @@ __device__ __forceinline__ void pack_weights_x3t_body(const float* __restrict__ 
     float v = 0.f;
     if (fwd) { if (n < Co && c < Ci) v = w[((long long)n * Ci + c) * k + j]; }
     else     { if (n < Ci && c < Co) v = w[((long long)c * Ci + n) * k + (k - 1 - j)]; }
+    const long long blk = ((long long)(nt * ncc + cc) * k + j) * X6_BLOCK + (long long)row * KC + q;
+    if (bound) {
+        const float sv = v * ign_pow2_scale(bound);
+        const _Float16 h0 = (_Float16)sv;
+        _Float16* dh = reinterpret_cast<_Float16*>(fwd ? wt3 : wd3) + blk;
+        dh[0] = h0; dh[TN * KC] = (_Float16)(sv - (float)h0);
+        return;
+    }
     __bf16 x0, x1, x2;
     split3(v, x0, x1, x2);
-    const long long blk = ((long long)(nt * ncc + cc) * k + j) * X6_BLOCK + (long long)row * KC + q;
     __bf16* dst = reinterpret_cast<__bf16*>(fwd ? wt3 : wd3) + blk;
     dst[0] = x0; dst[TN * KC] = x1; dst[2 * TN * KC] = x2;
 }
@@ -441,13 +505,14 @@ struct PackMultiTable {
     unsigned short* wt3[PACK_LMAX];
     unsigned short* wd3[PACK_LMAX];
     long long* counter[PACK_LMAX];
+    const float* bound[PACK_LMAX];             // non-null: two-plane fp16 packing, scaled by ign_pow2_scale(bound)
     int Co[PACK_LMAX], Ci[PACK_LMAX], k[PACK_LMAX];
 };
 __global__ void __launch_bounds__(256) pack_weights_x3t_multi_kernel(const PackMultiTable t) {
     const int l = blockIdx.y;
     if (blockIdx.x == 0 && threadIdx.x == 0 && t.counter[l]) *t.counter[l] += 1;
     pack_weights_x3t_body(t.w[l], t.wt3[l], t.wd3[l], t.Co[l], t.Ci[l], t.k[l], (t.Ci[l] + 15) / 16 * 16, (t.Co[l] + 15) / 16 * 16,
-                          (long long)blockIdx.x * 256 + threadIdx.x);
+                          (long long)blockIdx.x * 256 + threadIdx.x, t.bound[l]);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient, split bf16
@@ -470,6 +535,7 @@ struct WgradX6Args {
     int B, Tin, Tout, Ci, Co, k;
     int cps;                                                       // units per sample
     int nunits, nsplit, citiles;
+    const float* bound_dy; const float* bound_x;                   // NP = 2 (fp16 planes): operand bounds (ign_pow2_scale), else null
 };
 
 __device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
@@ -510,6 +576,14 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Ar
     const bool x_ok = ci0 + xq < a.Ci;                        // VX divides Ci
     float pa[VX], pb[VX];
     if (PRO && x_ok) { vload<VX>(pa, a.pro_a + ci0 + xq); vload<VX>(pb, a.pro_b + ci0 + xq); }
+    // two-plane fp16 path: both operands are scaled by powers of two before the split, the partial sums are scaled back
+    const float sdy = (NP == 2) ? ign_pow2_scale(a.bound_dy) : 1.f;
+    const float sx = (NP == 2) ? ign_pow2_scale(a.bound_x) : 1.f;
+    const float osc = (NP == 2) ? 1.f / (sdy * sx) : 1.f;
+    if (NP == 2 && PRO && x_ok) {
+#pragma unroll
+        for (int v = 0; v < VX; ++v) { pa[v] *= sx; pb[v] *= sx; }
+    }
 
     f32x16 acc[KT];
 #pragma unroll
@@ -542,7 +616,13 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Ar
         __bf16* P = smem + buf * STAGE;
         __bf16* Q = P + 3 * PPLANE;
 #pragma unroll
-        for (int p = 0; p < DPASS; ++p) split_store<4, NP>(rd[p], P + (dr + 16 * p) * WG_PITCH + dc, PPLANE);
+        for (int p = 0; p < DPASS; ++p) {
+            if constexpr (NP == 2) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) rd[p][v] *= sdy;
+            }
+            split_store<4, NP>(rd[p], P + (dr + 16 * p) * WG_PITCH + dc, PPLANE);
+        }
 #pragma unroll
         for (int p = 0; p < XPASS; ++p) {
             const int row = (tid + p * 256) / XVPR;
@@ -552,6 +632,7 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Ar
                 for (int v = 0; v < VX; ++v) {
                     tv[v] = rx[p][v];
                     if (PRO && x_ok) tv[v] = fmaxf(fmaf(pa[v], tv[v], pb[v]), 0.f);
+                    else if (NP == 2) tv[v] *= sx;
                 }
                 split_store<VX, NP>(tv, Q + row * WG_PITCH + xq, QPLANE);
             }
@@ -603,13 +684,15 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Ar
                 __builtin_amdgcn_sched_barrier(0);
                 const bf16x8(&b)[NP] = bf[j & 1];
                 if constexpr (NP == 3) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[1], acc[j], 0, 0, 0);
+                    acc[j] = mfma16<NP>(af[2], b[0], acc[j]);
+                    acc[j] = mfma16<NP>(af[0], b[2], acc[j]);
+                    acc[j] = mfma16<NP>(af[1], b[1], acc[j]);
                 }
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[0], acc[j], 0, 0, 0);
+                if constexpr (NP >= 2) {
+                    acc[j] = mfma16<NP>(af[1], b[0], acc[j]);
+                    acc[j] = mfma16<NP>(af[0], b[1], acc[j]);
+                }
+                acc[j] = mfma16<NP>(af[0], b[0], acc[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -625,7 +708,7 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Ar
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wco * 32 + acc_row16(r, h);
-                if (co < a.Co) out[((long long)co * a.k + j) * a.Ci + ci] = acc[j][r];
+                if (co < a.Co) out[((long long)co * a.k + j) * a.Ci + ci] = (NP == 2) ? acc[j][r] * osc : acc[j][r];
             }
     }
 }
@@ -643,6 +726,7 @@ struct Wgrad1Args {
     float* part_b;                                     // (nsplit, Co) column sums of dy (the bias gradient) or null
     long long M;
     int Ci, Co, nunits, nsplit, citiles, ntiles;
+    const float* bound_dy; const float* bound_x;        // NP = 2 (fp16 planes): operand bounds (ign_pow2_scale), else null
 };
 
 template <int NP>
@@ -678,6 +762,9 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float rd[2][4], rx[2][4];
+    const float sdy = (NP == 2) ? ign_pow2_scale(a.bound_dy) : 1.f;
+    const float sx = (NP == 2) ? ign_pow2_scale(a.bound_x) : 1.f;
+    const float osc = (NP == 2) ? 1.f / (sdy * sx) : 1.f;
     // bias gradient = column sums of dy: the tiles of the first ci-column see every dy value of their co-block once
     const bool want_b = a.part_b != nullptr && cit == 0;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -700,6 +787,10 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
+            if constexpr (NP == 2) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { rd[p][v] *= sdy; rx[p][v] *= sx; }
+            }
             split_store<4, NP>(rd[p], P + (sr + 8 * p) * W1_PITCH + sc, W1_PLANE);
             split_store<4, NP>(rx[p], Q + (sr + 8 * p) * W1_PITCH + sc, W1_PLANE);
         }
@@ -729,11 +820,12 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1
             }
         __builtin_amdgcn_sched_barrier(0);
 #define IGN_W1(pa_, pb_)                                                                                   \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[0][pb_], acc[0][0], 0, 0, 0);   \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[1][pb_], acc[0][1], 0, 0, 0);   \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[0][pb_], acc[1][0], 0, 0, 0);   \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[1][pb_], acc[1][1], 0, 0, 0);
-        if constexpr (NP == 3) { IGN_W1(2, 0) IGN_W1(0, 2) IGN_W1(1, 1) IGN_W1(1, 0) IGN_W1(0, 1) }
+        acc[0][0] = mfma16<NP>(af[0][pa_], bf[0][pb_], acc[0][0]);                                         \
+        acc[0][1] = mfma16<NP>(af[0][pa_], bf[1][pb_], acc[0][1]);                                         \
+        acc[1][0] = mfma16<NP>(af[1][pa_], bf[0][pb_], acc[1][0]);                                         \
+        acc[1][1] = mfma16<NP>(af[1][pa_], bf[1][pb_], acc[1][1]);
+        if constexpr (NP == 3) { IGN_W1(2, 0) IGN_W1(0, 2) IGN_W1(1, 1) }
+        if constexpr (NP >= 2) { IGN_W1(1, 0) IGN_W1(0, 1) }
         IGN_W1(0, 0)
 #undef IGN_W1
         __builtin_amdgcn_sched_barrier(0);
@@ -750,7 +842,7 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) t += red[r * 128 + tid];
-            a.part_b[(long long)split * a.Co + co0 + tid] = t;
+            a.part_b[(long long)split * a.Co + co0 + tid] = t;          // (accumulated from the unscaled dy values)
         }
     }
     float* out = a.part + (long long)split * a.Co * a.Ci;
@@ -763,7 +855,7 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + wco * 64 + 32 * i + acc_row16(r, h);
-                    if (co < a.Co) out[(long long)co * a.Ci + ci] = acc[i][j][r];
+                    if (co < a.Co) out[(long long)co * a.Ci + ci] = (NP == 2) ? acc[i][j][r] * osc : acc[i][j][r];
                 }
         }
     }
@@ -807,11 +899,13 @@ static int launch_x6w(const ConvX6Args& a, hipStream_t s) {
 int ign_clconv_launch_x6t(const ConvX6Args& a, int epi, int V, bool pro, hipStream_t s) {
     // Linear layers with wide outputs: the 128 x 256 tile kernel (see clconv_x6w_kernel)
     static const bool wide = !(getenv("IGN_X6_WIDE") && atoi(getenv("IGN_X6_WIDE")) == 0);
-    if (wide && a.k == 1 && a.g.N % 256 == 0 && V == 4 && !pro && epi == EPI_BIAS_STATS && !a.g.part && a.tps * 1 == a.g.mtiles &&
-        a.trows == a.g.M)
-        return a.nprod == 1 ? launch_x6w<1>(a, s) : launch_x6w<3>(a, s);
+    if (wide && a.k == 1 && a.g.N % 256 == 0 && V == 4 && !pro && epi == EPI_BIAS_STATS && !a.g.part &&
+        a.tps * 1 == a.g.mtiles && a.trows == a.g.M)
+        return a.nprod == 1 ? launch_x6w<1>(a, s) : a.nprod == 3 ? launch_x6w<2>(a, s) : launch_x6w<3>(a, s);
     if (a.nprod == 1)
         return epi == EPI_BIAS_STATS ? launch_x6t<EPI_BIAS_STATS, 1>(a, V, pro, s) : launch_x6t<EPI_MASK_STATS, 1>(a, V, pro, s);
+    if (a.nprod == 3)
+        return epi == EPI_BIAS_STATS ? launch_x6t<EPI_BIAS_STATS, 2>(a, V, pro, s) : launch_x6t<EPI_MASK_STATS, 2>(a, V, pro, s);
     return epi == EPI_BIAS_STATS ? launch_x6t<EPI_BIAS_STATS, 3>(a, V, pro, s) : launch_x6t<EPI_MASK_STATS, 3>(a, V, pro, s);
 }
 
@@ -834,8 +928,25 @@ extern "C" int ign_clconv_pack_weights_x3(const float* w_oik, void* wt3_fwd, voi
     return ign_check_launch("pack_weights_x3t_kernel");
 }
 
+static int pack_multi_impl(int n, const float* const* w_oik, void* const* wt3_fwd, void* const* wt3_dgrad, const int* Co, const int* Ci,
+                           const int* k, long long* const* counters, const float* const* bounds, void* stream);
+
 extern "C" int ign_clconv_pack_weights_x3_multi(int n, const float* const* w_oik, void* const* wt3_fwd, void* const* wt3_dgrad,
                                                const int* Co, const int* Ci, const int* k, long long* const* counters, void* stream) {
+    return pack_multi_impl(n, w_oik, wt3_fwd, wt3_dgrad, Co, Ci, k, counters, nullptr, stream);
+}
+
+extern "C" int ign_clconv_pack_weights_h2_multi(int n, const float* const* w_oik, void* const* wt_fwd, void* const* wt_dgrad,
+                                               const int* Co, const int* Ci, const int* k, long long* const* counters,
+                                               const float* const* w_bounds, void* stream) {
+    if (!w_bounds) { ign_set_error("ign_clconv_pack_weights_h2_multi: null bound table"); return IGN_E_ARG; }
+    for (int l = 0; l < n && l < PACK_LMAX; ++l)
+        if (!w_bounds[l]) { ign_set_error("ign_clconv_pack_weights_h2_multi: layer %d: null weight bound", l); return IGN_E_ARG; }
+    return pack_multi_impl(n, w_oik, wt_fwd, wt_dgrad, Co, Ci, k, counters, w_bounds, stream);
+}
+
+static int pack_multi_impl(int n, const float* const* w_oik, void* const* wt3_fwd, void* const* wt3_dgrad, const int* Co, const int* Ci,
+                           const int* k, long long* const* counters, const float* const* bounds, void* stream) {
     if (n <= 0 || n > PACK_LMAX || !w_oik || !wt3_fwd || !Co || !Ci || !k) {
         ign_set_error("ign_clconv_pack_weights_x3_multi: n=%d outside 1..%d or null table", n, PACK_LMAX);
         return IGN_E_ARG;
@@ -849,6 +960,7 @@ extern "C" int ign_clconv_pack_weights_x3_multi(int n, const float* const* w_oik
         }
         t.w[l] = w_oik[l]; t.wt3[l] = (unsigned short*)wt3_fwd[l]; t.wd3[l] = wt3_dgrad ? (unsigned short*)wt3_dgrad[l] : nullptr;
         t.counter[l] = counters ? counters[l] : nullptr;
+        t.bound[l] = bounds ? bounds[l] : nullptr;
         t.Co[l] = Co[l]; t.Ci[l] = Ci[l]; t.k[l] = k[l];
         const long long e = ign_clconv_x3_elems(Co[l], Ci[l], k[l]) / 3 + (t.wd3[l] ? ign_clconv_x3_elems(Ci[l], Co[l], k[l]) / 3 : 0);
         nmax = e > nmax ? e : nmax;
@@ -910,7 +1022,7 @@ extern "C" size_t ign_clconv_wgrad_x6_workspace_bytes(int B, int Tin, int Ci, in
 template <int NP>
 static int wgrad_x6_impl(const char* who, const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
                          float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream,
-                         float* db = nullptr) {
+                         float* db = nullptr, const float* bound_dy = nullptr, const float* bound_x = nullptr) {
     const int Tout = Tin - k + 1, ru = wgrad_x6_rows_per_unit(k);
     const bool defer = dw_oik == nullptr && k > 1;       // partials only: the caller reduces several layers in one launch
     if (!dyp || !x || (!dw_oik && !defer) || !workspace || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || dy_pad < 0 ||
@@ -931,6 +1043,7 @@ static int wgrad_x6_impl(const char* who, const float* dyp, int dy_pad, const fl
         w.nsplit = wgrad_x6_k1_splits(w.M, Ci, Co, &w.nunits, &tiles);
         w.citiles = (Ci + 127) / 128; w.ntiles = tiles;
         w.part_b = db ? (float*)workspace + (size_t)w.nsplit * Co * Ci : nullptr;
+        w.bound_dy = bound_dy; w.bound_x = bound_x;
         static bool once = false;
         if (!once) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_wgrad_x6_k1_kernel<NP>),
@@ -953,6 +1066,7 @@ static int wgrad_x6_impl(const char* who, const float* dyp, int dy_pad, const fl
     a.x = x; a.x_sample_pitch = (long long)Tin * Ci; a.pro_a = pro_a; a.pro_b = pro_b;
     a.part = (float*)workspace; a.B = B; a.Tin = Tin; a.Tout = Tout; a.Ci = Ci; a.Co = Co; a.k = k;
     a.cps = (Tout + ru - 1) / ru; a.nunits = B * a.cps;
+    a.bound_dy = bound_dy; a.bound_x = bound_x;
     a.citiles = (Ci + 63) / 64;
     const int tiles = ((Co + 63) / 64) * a.citiles;
     a.nsplit = wgrad_x6_splits(a.nunits, tiles);
@@ -989,6 +1103,23 @@ extern "C" int ign_clconv_wgrad_x6(const float* dyp, int dy_pad, const float* x,
 extern "C" int ign_clconv_wgrad_bf16(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
                                      float* dw_oik, void* workspace, int B, int Tin, int Ci, int Co, int k, void* stream) {
     return wgrad_x6_impl<1>("ign_clconv_wgrad_bf16", dyp, dy_pad, x, pro_a, pro_b, dw_oik, workspace, B, Tin, Ci, Co, k, stream);
+}
+
+// Two fp16 planes, three products (see include/ign_abi.h, "h3"): bound_dy / bound_x are the device-side magnitude bounds of the
+// two operands (after the prologue for x).  Workspace and result as for ign_clconv_wgrad_x6.
+extern "C" int ign_clconv_wgrad_h3(const float* dyp, int dy_pad, const float* x, const float* pro_a, const float* pro_b,
+                                   float* dw_oik, void* workspace, const float* bound_dy, const float* bound_x, int B, int Tin,
+                                   int Ci, int Co, int k, void* stream) {
+    if (!bound_dy || !bound_x) { ign_set_error("ign_clconv_wgrad_h3: null operand bound"); return IGN_E_ARG; }
+    return wgrad_x6_impl<2>("ign_clconv_wgrad_h3", dyp, dy_pad, x, pro_a, pro_b, dw_oik, workspace, B, Tin, Ci, Co, k, stream, nullptr,
+                            bound_dy, bound_x);
+}
+extern "C" int ign_linear_wgrad_h3(const float* dy, const float* x, float* dw, float* db, void* workspace, const float* bound_dy,
+                                   const float* bound_x, long long M, int Ci, int Co, void* stream) {
+    if (M <= 0 || M > 0x7fffffffLL) { ign_set_error("ign_linear_wgrad_h3: M = %lld rows out of range", M); return IGN_E_ARG; }
+    if (!bound_dy || !bound_x) { ign_set_error("ign_linear_wgrad_h3: null operand bound"); return IGN_E_ARG; }
+    return wgrad_x6_impl<2>("ign_linear_wgrad_h3", dy, 0, x, nullptr, nullptr, dw, workspace, 1, (int)M, Ci, Co, 1, stream, db, bound_dy,
+                            bound_x);
 }
 
 // A Linear layer's weight AND bias gradient in one pass over dy: dW = dy^T x, db = column sums of dy (the tiles of the first

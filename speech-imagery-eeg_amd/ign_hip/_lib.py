@@ -93,6 +93,14 @@ SIGNATURES = {
     "ign_clconv_wgrad_x6_nsplit": (ci, [ci, ci, ci, ci, ci]),
     "ign_clconv_wgrad_reduce_multi": (ci, [ci, vp, vp, vp, vp, vp, vp, vp]),
     "ign_clconv_pack_weights_x3_multi": (ci, [ci, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ign_absmax": (ci, [vp, ll, vp, vp]),
+    "ign_fcn_scan": (ci, [ci, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ign_clconv_pack_weights_h2_multi": (ci, [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ign_clconv_fwd_h3": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ign_clconv_dgrad_h3": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ign_clconv_wgrad_h3": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ign_linear_wgrad_h3": (ci, [vp, vp, vp, vp, vp, vp, vp, ll, ci, ci, vp]),
+    "ign_bn_bwd_apply_amax": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ign_head_bwd_acc": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]),
     "ign_loss_fwd_bwd_reg": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp]),
     "ign_sbm_reg_workspace_bytes": (sz, [ci, ci, ll]),

@@ -23,7 +23,12 @@ from . import _lib
 #   "f32":    v_mfma_f32_32x32x2_f32 (runs at the fp32 VECTOR rate on gfx950);
 #   "bf16":   operands rounded to bf16, ONE product, fp32 accumulation -- what torch.autocast(bfloat16) computes for a
 #             convolution; selected automatically inside an autocast region (the reference's default mode, `--amp` not passed).
-CONV_MATH = os.environ.get("IGN_CONV_MATH", "bf16x6")
+#   "f16x3":  every operand tensor scaled by a power of two (from a device-side bound of its magnitude), split into TWO fp16
+#             terms, THREE partial products accumulated in fp32 on the fp16 matrix cores -- the same fp32-level accuracy against
+#             float64 as "bf16x6" with half the matrix instructions and two operand planes instead of three (1.5-1.6x its speed;
+#             include/ign_abi.h, "h3").  The default in training mode; blocks that normalise with running statistics (eval mode)
+#             have no hard bound on their activations and use "bf16x6".
+CONV_MATH = os.environ.get("IGN_CONV_MATH", "f16x3")
 DEBUG = None       # set to a dict to capture the backward intermediates (tests/diag_fcn.py)
 
 
@@ -74,8 +79,13 @@ class FcnBodyFn(torch.autograd.Function):
         dev = x.device
         f32 = dict(device=dev, dtype=torch.float32)
         need_grad = any(ctx.needs_input_grad[2:])
-        x6 = math in ("bf16x6", "bf16")
+        if math == "f16x3" and not (all(st.use_batch_stats for st in states) and nl <= 8):
+            math = "bf16x6"           # running statistics: no hard bound on the normalised activations
+        h3 = math == "f16x3"
+        x6 = math in ("bf16x6", "bf16", "f16x3")
         conv_fwd = L.ign_clconv_fwd_bf16 if math == "bf16" else L.ign_clconv_fwd_x6
+        slots = None
+        fp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off)        # address of float `off` of a float32 tensor
         inputs, affine, wds, shapes = [x], [], [], []
         pa = pb = None
         packed = None
@@ -87,13 +97,31 @@ class FcnBodyFn(torch.autograd.Function):
                    for w in ws_]
             wds_ = [torch.empty(int(L.ign_clconv_x3_elems(w.shape[1], w.shape[0], w.shape[2])), device=dev, dtype=torch.bfloat16)
                     if (l > 0 and need_grad) else None for l, w in enumerate(ws_)]
-            vpa, ia = ctypes.c_void_p * nl, ctypes.c_int * nl
+            vpa, ia, lla = ctypes.c_void_p * nl, ctypes.c_int * nl, ctypes.c_longlong * nl
             pv = lambda ts: vpa(*[(t.data_ptr() if t is not None else None) for t in ts])
             bumps = [st.bump for st in states]
-            _lib.check(L.ign_clconv_pack_weights_x3_multi(nl, pv(ws_), pv(wts), pv(wds_), ia(*[w.shape[0] for w in ws_]),
-                                                          ia(*[w.shape[1] for w in ws_]), ia(*[w.shape[2] for w in ws_]),
-                                                          pv(bumps) if any(b is not None for b in bumps) else None, _stream()),
-                       "ign_clconv_pack_weights_x3_multi")
+            bump_tab = pv(bumps) if any(b is not None for b in bumps) else None
+            dims = (ia(*[w.shape[0] for w in ws_]), ia(*[w.shape[1] for w in ws_]), ia(*[w.shape[2] for w in ws_]))
+            if h3:
+                # operand bounds (4 floats per block: |W|, |block input|, |dL/dy|, spare): weights and the BatchNorm-derived
+                # activation bounds from the parameters in one launch, the raw input's from one pass over x
+                slots = torch.empty(4 * nl, **f32)
+                gam = [None] + [params[4 * (l - 1) + 2].contiguous() for l in range(1, nl)]
+                bet = [None] + [params[4 * (l - 1) + 3].contiguous() for l in range(1, nl)]
+                Touts, T_ = [], x.shape[1]
+                for w in ws_:
+                    T_ = T_ - w.shape[2] + 1
+                    Touts.append(T_)
+                _lib.check(L.ign_fcn_scan(nl, pv(ws_), lla(*[w.numel() for w in ws_]), pv(gam), pv(bet),
+                                          ia(*([0] + [ws_[l - 1].shape[0] for l in range(1, nl)])),
+                                          lla(*([0] + [B * Touts[l - 1] for l in range(1, nl)])), _ptr(slots), _stream()), "ign_fcn_scan")
+                _lib.check(L.ign_absmax(_ptr(x), x.numel(), fp(slots, 1), _stream()), "ign_absmax")
+                _lib.check(L.ign_clconv_pack_weights_h2_multi(nl, pv(ws_), pv(wts), pv(wds_), *dims, bump_tab,
+                                                              vpa(*[slots.data_ptr() + 16 * l for l in range(nl)]), _stream()),
+                           "ign_clconv_pack_weights_h2_multi")
+            else:
+                _lib.check(L.ign_clconv_pack_weights_x3_multi(nl, pv(ws_), pv(wts), pv(wds_), *dims, bump_tab, _stream()),
+                           "ign_clconv_pack_weights_x3_multi")
             packed = (wts, wds_)
         else:
             bumps = [st.bump for st in states if st.bump is not None]
@@ -120,8 +148,12 @@ class FcnBodyFn(torch.autograd.Function):
                     wd = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, k)), device=dev, dtype=torch.bfloat16) if want_wd else None
                     _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt), _ptr(wd), Co, Ci, k, _stream()),
                                "ign_clconv_pack_weights_x3")
-                _lib.check(conv_fwd(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part), B, Tin, Ci, Co, k, _stream()),
-                           "ign_clconv_fwd_x6")
+                if h3:
+                    _lib.check(L.ign_clconv_fwd_h3(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part), fp(slots, 4 * l + 1),
+                                                   fp(slots, 4 * l), B, Tin, Ci, Co, k, _stream()), "ign_clconv_fwd_h3")
+                else:
+                    _lib.check(conv_fwd(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part), B, Tin, Ci, Co, k,
+                                        _stream()), "ign_clconv_fwd_x6")
             else:
                 wt = torch.empty(Co, k * Ci, **f32)
                 wd = torch.empty(Ci, k * Co, **f32) if want_wd else None
@@ -147,7 +179,7 @@ class FcnBodyFn(torch.autograd.Function):
         pooled = torch.empty(B, Cl, **f32)
         _lib.check(L.ign_bn_relu_pool_fwd(_ptr(y_last), _ptr(pa), _ptr(pb), _ptr(pooled), B, Tl, Cl, _stream()),
                    "ign_bn_relu_pool_fwd")
-        ctx.saved = (inputs, affine, wds, shapes, [st.use_batch_stats for st in states], math) if need_grad else None
+        ctx.saved = (inputs, affine, wds, shapes, [st.use_batch_stats for st in states], math, slots) if need_grad else None
         return pooled
 
     @staticmethod
@@ -157,8 +189,10 @@ class FcnBodyFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise _lib.IgnError("fcn_body: gradient w.r.t. the input series is not implemented (inputs are data)")
         L = _lib.lib()
-        inputs, affine, wds, shapes, batch_stats, math = ctx.saved
-        x6 = math in ("bf16x6", "bf16")
+        inputs, affine, wds, shapes, batch_stats, math, slots = ctx.saved
+        h3 = math == "f16x3"
+        x6 = math in ("bf16x6", "bf16", "f16x3")
+        fp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off)
         nl = len(shapes)
         B = inputs[0].shape[0]
         dev = gpool.device
@@ -194,8 +228,10 @@ class FcnBodyFn(torch.autograd.Function):
             pad = (k - 1) if l > 0 else 0
             dyp = torch.empty(B, Tout + 2 * pad, Co, **f32)
             training = 1 if batch_stats[l] else 0
-            _lib.check(L.ign_bn_bwd_apply(_ptr(g), _ptr(y), _ptr(a), _ptr(mean), _ptr(invstd), _ptr(dbeta), _ptr(dgamma), _ptr(dyp),
-                                          B, Tout, Co, pad, training, _stream()), "ign_bn_bwd_apply")
+            # (fp16 path: the kernel also takes max |dL/dy| as it writes the tensor -- the bound its two consumers scale by)
+            _lib.check(L.ign_bn_bwd_apply_amax(_ptr(g), _ptr(y), _ptr(a), _ptr(mean), _ptr(invstd), _ptr(dbeta), _ptr(dgamma), _ptr(dyp),
+                                               fp(slots, 4 * l + 2) if h3 else None, B, Tout, Co, pad, training, _stream()),
+                       "ign_bn_bwd_apply")
             if DEBUG is not None:
                 DEBUG[f"g{l}"], DEBUG[f"dyp{l}"], DEBUG[f"dbeta{l}"], DEBUG[f"dgamma{l}"] = g.clone(), dyp.clone(), dbeta.clone(), dgamma.clone()
             del g
@@ -206,8 +242,13 @@ class FcnBodyFn(torch.autograd.Function):
             ws = torch.empty(int(ws_bytes) // 4, **f32)
             dw = torch.empty(Co, Ci, k, **f32)
             wgrad = (L.ign_clconv_wgrad_bf16 if math == "bf16" else L.ign_clconv_wgrad_x6) if wx6 else L.ign_clconv_wgrad
-            _lib.check(wgrad(_ptr(dyp), pad, _ptr(inputs[l]), _ptr(pa), _ptr(pb), None if defer else _ptr(dw), _ptr(ws), B, Tin, Ci,
-                             Co, k, _stream()), "ign_clconv_wgrad")
+            if h3 and wx6:
+                _lib.check(L.ign_clconv_wgrad_h3(_ptr(dyp), pad, _ptr(inputs[l]), _ptr(pa), _ptr(pb), None if defer else _ptr(dw), _ptr(ws),
+                                                 fp(slots, 4 * l + 2), fp(slots, 4 * l + 1), B, Tin, Ci, Co, k, _stream()),
+                           "ign_clconv_wgrad_h3")
+            else:
+                _lib.check(wgrad(_ptr(dyp), pad, _ptr(inputs[l]), _ptr(pa), _ptr(pb), None if defer else _ptr(dw), _ptr(ws), B, Tin,
+                                 Ci, Co, k, _stream()), "ign_clconv_wgrad")
             if defer:
                 deferred.append((ws, dw, int(L.ign_clconv_wgrad_x6_nsplit(B, Tin, Ci, Co, k)), Co, Ci, k))
             del ws
@@ -222,8 +263,13 @@ class FcnBodyFn(torch.autograd.Function):
                 nparts = int(L.ign_clconv_x6_mtiles(B, Tin) if x6 else L.ign_clconv_mtiles(B * Tin))
                 part = torch.empty(nparts, 2, Ci, **f32)
                 dgrad = (L.ign_clconv_dgrad_bf16 if math == "bf16" else L.ign_clconv_dgrad_x6) if x6 else L.ign_clconv_dgrad
-                _lib.check(dgrad(_ptr(dyp), _ptr(wds[l]), _ptr(inputs[l]), _ptr(pa_), _ptr(pb_), _ptr(pm_), _ptr(pi_),
-                                              _ptr(g), _ptr(part), B, Tin, Ci, Co, k, _stream()), "ign_clconv_dgrad")
+                if h3:
+                    _lib.check(L.ign_clconv_dgrad_h3(_ptr(dyp), _ptr(wds[l]), _ptr(inputs[l]), _ptr(pa_), _ptr(pb_), _ptr(pm_), _ptr(pi_),
+                                                     _ptr(g), _ptr(part), fp(slots, 4 * l + 2), fp(slots, 4 * l), B, Tin, Ci, Co, k,
+                                                     _stream()), "ign_clconv_dgrad_h3")
+                else:
+                    _lib.check(dgrad(_ptr(dyp), _ptr(wds[l]), _ptr(inputs[l]), _ptr(pa_), _ptr(pb_), _ptr(pm_), _ptr(pi_),
+                                     _ptr(g), _ptr(part), B, Tin, Ci, Co, k, _stream()), "ign_clconv_dgrad")
             del dyp
         if deferred:
             n = len(deferred)

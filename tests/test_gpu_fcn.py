@@ -44,30 +44,43 @@ def _s():
     (3, 77, 256, 128, 3, True),      # third block, ragged m-tiles
     (5, 9, 128, 256, 3, True),       # seq_len <= 10 kernels
 ])
-@pytest.mark.parametrize("math", ["f32", "bf16x6"])
+@pytest.mark.parametrize("math", ["f32", "bf16x6", "f16x3", "f16x3 tiny", "f16x3 huge"])
 def test_clconv_fwd_matches_conv1d(B, T, Ci, Co, k, pro, math):
+    """"f16x3": two fp16 planes of power-of-two-scaled operands, three products (ign_clconv_fwd_h3) -- same bound as the other two;
+    "tiny" / "huge": inputs of magnitude 1e-6 / 3e6 with a loose magnitude bound (4x): fp16's exponent range must not matter."""
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
     from ign_hip import _lib
     L = _lib.lib()
     g = torch.Generator().manual_seed(B * 1000 + T + Ci + k)
-    x = torch.randn(B, T, Ci, generator=g)
-    w = torch.randn(Co, Ci, k, generator=g) / (Ci * k) ** 0.5
-    bias = torch.randn(Co, generator=g)
+    xs = 1e-6 if math.endswith("tiny") else 3e6 if math.endswith("huge") else 1.0
+    math = math.split()[0]
+    x = torch.randn(B, T, Ci, generator=g) * xs
+    w = torch.randn(Co, Ci, k, generator=g) / (Ci * k) ** 0.5 / xs ** 0.5
+    bias = torch.randn(Co, generator=g) * xs ** 0.5
     pa = (torch.rand(Ci, generator=g) + 0.5) if pro else None
-    pb = torch.randn(Ci, generator=g) * 0.3 if pro else None
+    pb = torch.randn(Ci, generator=g) * 0.3 * xs if pro else None
     xin = torch.relu(x.double() * pa.double() + pb.double()) if pro else x.double()
     ref = F.conv1d(xin.permute(0, 2, 1), w.double(), bias.double()).permute(0, 2, 1)      # (B,Tout,Co)
     Tout = T - k + 1
     xd, wd_, bd = x.to(dev), w.to(dev), bias.to(dev)
     pad, pbd = (pa.to(dev), pb.to(dev)) if pro else (None, None)
     y = torch.full((B, Tout, Co), float("nan"), device=dev)
-    nparts = int(L.ign_clconv_x6_mtiles(B, Tout) if math == "bf16x6" else L.ign_clconv_mtiles(B * Tout))
+    nparts = int(L.ign_clconv_x6_mtiles(B, Tout) if math != "f32" else L.ign_clconv_mtiles(B * Tout))
     part = torch.full((nparts, 2, Co), float("nan"), device=dev)
     if math == "f32":
         wt = torch.empty(Co, k * Ci, device=dev)
         _lib.check(L.ign_clconv_pack_weights(_p(wd_), _p(wt), None, Co, Ci, k, _s()), "pack")
         _lib.check(L.ign_clconv_fwd(_p(xd), _p(wt), _p(bd), _p(pad), _p(pbd), _p(y), _p(part), B, T, Ci, Co, k, _s()), "fwd")
+    elif math == "f16x3":
+        import ctypes
+        wt = torch.zeros(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
+        slots = torch.tensor([float(w.abs().max()), 4.0 * float(xin.abs().max()), 0.0, 0.0], device=dev)     # |W| exact, |input| loose
+        v1, i1 = ctypes.c_void_p * 1, ctypes.c_int * 1
+        _lib.check(L.ign_clconv_pack_weights_h2_multi(1, v1(wd_.data_ptr()), v1(wt.data_ptr()), None, i1(Co), i1(Ci), i1(k), None,
+                                                      v1(slots.data_ptr()), _s()), "pack_h2")
+        _lib.check(L.ign_clconv_fwd_h3(_p(xd), _p(wt), _p(bd), _p(pad), _p(pbd), _p(y), _p(part), ctypes.c_void_p(slots.data_ptr() + 4),
+                                       _p(slots), B, T, Ci, Co, k, _s()), "fwd_h3")
     else:       # split-bf16 product on the bf16 matrix cores: must be as accurate as the fp32 kernel
         wt = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
         _lib.check(L.ign_clconv_pack_weights_x3(_p(wd_), _p(wt), None, Co, Ci, k, _s()), "pack_x3")
@@ -104,7 +117,7 @@ def _ref_blocks(cfg_in, widths, ks, seed):
     (1, 140, 1, (128, 256, 128), (8, 5, 3), True),       # univariate series (several UEA sets), one sample
     (5, 30, 2, (128, 256, 128), (8, 5, 3), True),        # T barely above the kernel sizes
 ])
-@pytest.mark.parametrize("math", ["f32", "bf16x6"])
+@pytest.mark.parametrize("math", ["f32", "bf16x6", "f16x3"])
 def test_fcn_body_forward_backward(B, T, C, widths, ks, training, math, monkeypatch):
     dev = _dev()
     import copy
@@ -155,7 +168,7 @@ def _away_from_kink(y, a, b, margin=1e-3):
 
 @pytest.mark.parametrize("B,Tin,Ci,Co,k", [(2, 989, 256, 128, 3), (2, 993, 128, 256, 5), (3, 50, 64, 128, 3), (1, 9, 128, 256, 2),
                                            (2, 100, 120, 128, 8), (3, 77, 36, 64, 8)])
-@pytest.mark.parametrize("math", ["f32", "bf16x6"])
+@pytest.mark.parametrize("math", ["f32", "bf16x6", "f16x3", "f16x3 tiny"])
 def test_clconv_dgrad_and_wgrad_kernels(B, Tin, Ci, Co, k, math):
     """ign_clconv_dgrad (ReLU mask + BatchNorm-backward sums in the epilogue) and ign_clconv_wgrad (prologue recomputes
     relu(bn(y))) against float64 autograd of the same maths, with pre-activations kept off the ReLU kink."""
@@ -171,7 +184,8 @@ def test_clconv_dgrad_and_wgrad_kernels(B, Tin, Ci, Co, k, math):
     invstd = torch.rand(Ci, generator=g) + 0.5
     y_in = _away_from_kink(torch.randn(B, Tin, Ci, generator=g), a, b)
     w = torch.randn(Co, Ci, k, generator=g) / (Ci * k) ** 0.5
-    dy = torch.randn(B, Tout, Co, generator=g)
+    dy = torch.randn(B, Tout, Co, generator=g) * (1e-7 if math.endswith("tiny") else 1.0)     # "tiny": gradients of a late epoch
+    math = math.split()[0]
 
     yd = y_in.double().requires_grad_(True)
     pre = yd * a.double() + b.double()
@@ -193,11 +207,23 @@ def test_clconv_dgrad_and_wgrad_kernels(B, Tin, Ci, Co, k, math):
     wdg = torch.empty(Ci, k * Co, device=dev)
     _lib.check(L.ign_clconv_pack_weights(_p(wd_), _p(wt), _p(wdg), Co, Ci, k, _s()), "pack")
     gin = torch.full((B, Tin, Ci), float("nan"), device=dev)
-    nparts = int(L.ign_clconv_x6_mtiles(B, Tin) if math == "bf16x6" else L.ign_clconv_mtiles(B * Tin))
+    nparts = int(L.ign_clconv_x6_mtiles(B, Tin) if math != "f32" else L.ign_clconv_mtiles(B * Tin))
     part = torch.full((nparts, 2, Ci), float("nan"), device=dev)
     if math == "f32":
         _lib.check(L.ign_clconv_dgrad(_p(dypd), _p(wdg), _p(yind), _p(ad), _p(bd), _p(md), _p(isd), _p(gin), _p(part),
                                       B, Tin, Ci, Co, k, _s()), "dgrad")
+    elif math == "f16x3":
+        import ctypes
+        wt3 = torch.zeros(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
+        wd3 = torch.zeros(int(L.ign_clconv_x3_elems(Ci, Co, k)), device=dev, dtype=torch.bfloat16)
+        # bounds: |W|, |relu(a y + b)| (a loose one), |dy| (taken by the producer kernel in the product; here from the tensor)
+        slots = torch.tensor([float(w.abs().max()), 3.0 * float(z.detach().abs().max()), float(dy.abs().max()), 0.0], device=dev)
+        v1, i1 = ctypes.c_void_p * 1, ctypes.c_int * 1
+        sp = lambda i: ctypes.c_void_p(slots.data_ptr() + 4 * i)
+        _lib.check(L.ign_clconv_pack_weights_h2_multi(1, v1(wd_.data_ptr()), v1(wt3.data_ptr()), v1(wd3.data_ptr()), i1(Co), i1(Ci), i1(k),
+                                                      None, v1(slots.data_ptr()), _s()), "pack_h2")
+        _lib.check(L.ign_clconv_dgrad_h3(_p(dypd), _p(wd3), _p(yind), _p(ad), _p(bd), _p(md), _p(isd), _p(gin), _p(part), sp(2), sp(0),
+                                         B, Tin, Ci, Co, k, _s()), "dgrad_h3")
     else:
         wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
         wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, k)), device=dev, dtype=torch.bfloat16)
@@ -207,12 +233,16 @@ def test_clconv_dgrad_and_wgrad_kernels(B, Tin, Ci, Co, k, math):
     assert _rel(gin, g_ref) < 3e-6
     assert _rel(part[:, 0].double().sum(0), s1_ref) < TOL and _rel(part[:, 1].double().sum(0), s2_ref) < TOL
 
-    x6w = math == "bf16x6" and k in (2, 3, 5, 8)
+    x6w = math != "f32" and k in (2, 3, 5, 8)
     nbytes = (L.ign_clconv_wgrad_x6_workspace_bytes if x6w else L.ign_clconv_wgrad_workspace_bytes)(B, Tin, Ci, Co, k)
     ws = torch.empty(int(nbytes) // 4, device=dev)
     dw = torch.full((Co, Ci, k), float("nan"), device=dev)
-    wgrad = L.ign_clconv_wgrad_x6 if x6w else L.ign_clconv_wgrad
-    _lib.check(wgrad(_p(dypd), pad, _p(yind), _p(ad), _p(bd), _p(dw), _p(ws), B, Tin, Ci, Co, k, _s()), "wgrad")
+    if math == "f16x3" and x6w:
+        _lib.check(L.ign_clconv_wgrad_h3(_p(dypd), pad, _p(yind), _p(ad), _p(bd), _p(dw), _p(ws), sp(2), sp(1), B, Tin, Ci, Co, k, _s()),
+                   "wgrad_h3")
+    else:
+        wgrad = L.ign_clconv_wgrad_x6 if x6w else L.ign_clconv_wgrad
+        _lib.check(wgrad(_p(dypd), pad, _p(yind), _p(ad), _p(bd), _p(dw), _p(ws), B, Tin, Ci, Co, k, _s()), "wgrad")
     assert _rel(dw, wdbl.grad) < 3e-6
 
 
