@@ -438,6 +438,48 @@ def head_linear(x, w, bias=None):
     return HeadLinearFn.apply(x, w, bias)
 
 
+# Arithmetic of the dense-layer / convolution GEMMs outside an autocast region (include/ign_abi.h, "h3"):
+#   "f16x3"  (default) operands scaled by a power of two from a device-side magnitude bound, split into two fp16 planes, three
+#            products -- fp32-level accuracy against float64 like "bf16x6", at 1.5-1.6x its speed;
+#   "bf16x6" three bf16 planes, six products.
+GEMM_MATH = os.environ.get("IGN_GEMM_MATH", "f16x3")
+
+_SLOT_POOL = {}
+
+
+def _new_slot(device):
+    """One zero-initialised float on `device`, cut from a pooled zero buffer (one fill launch per 256 slots)."""
+    pool = _SLOT_POOL.get(device)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = _SLOT_POOL[device] = [torch.zeros(256, device=device, dtype=torch.float32), 0]
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0][i:i + 1]
+
+
+def tensor_bound(t):
+    """A one-element device tensor holding an upper bound of max |t| -- what the fp16 GEMMs scale their operands by.  A producer
+    that knows a bound attaches it (`set_bound`: LayerNorm's hard bound from its parameters); otherwise ONE pass over the tensor
+    takes the exact maximum (ign_absmax), cached on the tensor object for as long as it is not modified in place."""
+    cached = getattr(t, "_ign_bound", None)
+    if cached is not None and cached[1] == t._version and cached[2] == t.data_ptr():
+        return cached[0]
+    tc = t if t.is_contiguous() else t.contiguous()
+    slot = _new_slot(t.device)
+    _lib.check(_lib.lib().ign_absmax(_ptr(tc), tc.numel(), _ptr(slot), _stream()), "ign_absmax")
+    try:
+        t._ign_bound = (slot, t._version, t.data_ptr())
+    except Exception:
+        pass
+    return slot
+
+
+def set_bound(t, slot):
+    """Attach a known magnitude bound (one-element device tensor) to `t`; see tensor_bound."""
+    t._ign_bound = (slot, t._version, t.data_ptr())
+    return t
+
+
 def _gemm(L, bf16):
     """(forward / input-gradient GEMM, weight-gradient GEMM) entry points: the split-bf16 kernels (fp32 accuracy), or inside a
     torch.autocast(bfloat16) region -- the reference's default mode -- the same kernels with their operands rounded to bf16 and
@@ -465,11 +507,24 @@ class LinearFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, 1)), device=dev, dtype=torch.bfloat16)
         wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, 1)), device=dev, dtype=torch.bfloat16) if need_dx else None
-        _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt3), _ptr(wd3), Co, Ci, 1, _stream()), "ign_clconv_pack_weights_x3")
         y = torch.empty(M, Co, device=dev, dtype=torch.float32)
         ctx.bf16 = torch.is_autocast_enabled()          # autocast region: operands rounded to bf16, one product (see _gemm)
-        _lib.check(_gemm(L, ctx.bf16)[0](_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, 1, M, Ci, Co, 1, _stream()),
-                   "ign_clconv_fwd_x6")
+        ctx.h3 = (not ctx.bf16) and GEMM_MATH == "f16x3"
+        ctx.bx = ctx.bw = None
+        if ctx.h3:
+            # two fp16 planes, three products: operand bounds on the device (the input's is inherited from x when x2 is a view)
+            ctx.bw = tensor_bound(w)
+            ctx.bx = tensor_bound(x) if x2.data_ptr() == x.data_ptr() and x.is_contiguous() else tensor_bound(x2)
+            v1, i1 = _tables(1)
+            _lib.check(L.ign_clconv_pack_weights_h2_multi(1, v1(w.data_ptr()), v1(wt3.data_ptr()), v1(wd3.data_ptr()) if need_dx else None,
+                                                          i1(Co), i1(Ci), i1(1), None, v1(ctx.bw.data_ptr()), _stream()),
+                       "ign_clconv_pack_weights_h2_multi")
+            _lib.check(L.ign_clconv_fwd_h3(_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, _ptr(ctx.bx), _ptr(ctx.bw), 1, M, Ci,
+                                           Co, 1, _stream()), "ign_clconv_fwd_h3")
+        else:
+            _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt3), _ptr(wd3), Co, Ci, 1, _stream()), "ign_clconv_pack_weights_x3")
+            _lib.check(_gemm(L, ctx.bf16)[0](_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, 1, M, Ci, Co, 1, _stream()),
+                       "ign_clconv_fwd_x6")
         ctx.save_for_backward(x2)
         ctx.wd3, ctx.dims, ctx.has_bias, ctx.xshape = wd3, (M, Ci, Co), bias is not None, x.shape
         return y.view(*x.shape[:-1], Co)
@@ -482,10 +537,15 @@ class LinearFn(torch.autograd.Function):
         g2 = gy.reshape(M, Co)
         g2 = g2 if g2.is_contiguous() else g2.contiguous()
         dx = dw = db = None
+        bg = tensor_bound(g2) if ctx.h3 else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, Ci, device=g2.device, dtype=torch.float32)
-            _lib.check(_gemm(L, ctx.bf16)[0](_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, 1, M, Co, Ci, 1, _stream()),
-                       "ign_clconv_fwd_x6(dx)")
+            if ctx.h3:
+                _lib.check(L.ign_clconv_fwd_h3(_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, _ptr(bg), _ptr(ctx.bw), 1, M, Co,
+                                               Ci, 1, _stream()), "ign_clconv_fwd_h3(dx)")
+            else:
+                _lib.check(_gemm(L, ctx.bf16)[0](_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, 1, M, Co, Ci, 1, _stream()),
+                           "ign_clconv_fwd_x6(dx)")
             dx = dx.view(ctx.xshape)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
@@ -496,8 +556,12 @@ class LinearFn(torch.autograd.Function):
                                  dtype=torch.float32)
                 if want_db:
                     db = torch.empty(Co, device=g2.device, dtype=torch.float32)
-                fn = L.ign_linear_wgrad_bf16 if ctx.bf16 else L.ign_linear_wgrad_x6
-                _lib.check(fn(_ptr(g2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(ws), M, Ci, Co, _stream()), "ign_linear_wgrad_x6")
+                if ctx.h3:
+                    _lib.check(L.ign_linear_wgrad_h3(_ptr(g2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(ws), _ptr(bg), _ptr(ctx.bx), M, Ci, Co,
+                                                     _stream()), "ign_linear_wgrad_h3")
+                else:
+                    fn = L.ign_linear_wgrad_bf16 if ctx.bf16 else L.ign_linear_wgrad_x6
+                    _lib.check(fn(_ptr(g2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(ws), M, Ci, Co, _stream()), "ign_linear_wgrad_x6")
             else:
                 ws = torch.empty(int(L.ign_clconv_wgrad_workspace_bytes(1, M, Ci, Co, 1)) // 4, device=g2.device,
                                  dtype=torch.float32)
@@ -568,7 +632,17 @@ def layer_norm(x, norm):
     if (not x.is_cuda or x.dtype != torch.float32 or norm.weight is None or len(norm.normalized_shape) != 1 or D % 4 or D > 2048
             or x.numel() == 0 or x.numel() < LAYERNORM_MIN_ROWS * D):
         return norm(x)
-    return LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
+    out = LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
+    if GEMM_MATH == "f16x3" and norm.bias is not None and not torch.is_autocast_enabled():
+        # a row standardised with its own mean and (biased) variance over D elements cannot exceed sqrt(D - 1): the output is
+        # bounded by max_d(|gamma_d| sqrt(D - 1) + |beta_d|) -- from the parameters alone, one tiny launch instead of a pass over
+        # the activations when a dense layer behind it asks for its operand's magnitude (tensor_bound)
+        slots = torch.empty(4, device=x.device, dtype=torch.float32)
+        v1, i1, l1 = ctypes.c_void_p * 1, ctypes.c_int * 1, ctypes.c_longlong * 1
+        wp, bp = norm.weight.data_ptr(), norm.bias.data_ptr()
+        _lib.check(_lib.lib().ign_fcn_scan(1, v1(wp), l1(D), v1(wp), v1(bp), i1(D), l1(max(D, 2)), _ptr(slots), _stream()), "ign_fcn_scan")
+        set_bound(out, slots[1:2])
+    return out
 
 
 class ConvCLFn(torch.autograd.Function):

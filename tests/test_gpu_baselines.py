@@ -260,20 +260,23 @@ def test_eegcnn_train_step_at_short_rows_with_many_samples(T, k1):
 
 @pytest.mark.parametrize("shape,Co,bias", [((256, 100, 512), 256, True), ((3, 77, 64), 512, True), ((5, 130), 12, False),
                                            ((2, 1000, 512), 2048, True)])
-@pytest.mark.parametrize("wgrad", ["bf16x6", "f32"])
-def test_linear_on_own_gemm_kernels(shape, Co, bias, wgrad, monkeypatch):
-    """ops.linear (split-bf16 forward / input gradient; weight gradient on the split-bf16 k = 1 kernel or the fp32-MFMA TN
-    kernel) against float64 torch."""
+@pytest.mark.parametrize("wgrad,gmath,scale", [("bf16x6", "bf16x6", 1.0), ("f32", "bf16x6", 1.0), ("bf16x6", "f16x3", 1.0),
+                                               ("bf16x6", "f16x3", 1e-6), ("bf16x6", "f16x3", 1e5)])
+def test_linear_on_own_gemm_kernels(shape, Co, bias, wgrad, gmath, scale, monkeypatch):
+    """ops.linear (forward / input gradient / weight gradient on the split kernels: six-product bf16 or three-product fp16 with
+    power-of-two operand scaling; weight gradient alternatively on the fp32-MFMA TN kernel) against float64 torch.  `scale`:
+    activations of magnitude 1e5 and output gradients of 1e-6 (and the other way round) -- fp16's exponent range must not show."""
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
     from ign_hip import ops
     monkeypatch.setattr(ops, "LINEAR_WGRAD", wgrad)
+    monkeypatch.setattr(ops, "GEMM_MATH", gmath)
     g = torch.Generator().manual_seed(sum(shape) + Co)
     Ci = shape[-1]
-    x = torch.randn(*shape, generator=g)
+    x = torch.randn(*shape, generator=g) * scale
     w = torch.randn(Co, Ci, generator=g) / Ci ** 0.5
-    b = torch.randn(Co, generator=g) if bias else None
-    gy = torch.randn(*shape[:-1], Co, generator=g)
+    b = torch.randn(Co, generator=g) * scale if bias else None
+    gy = torch.randn(*shape[:-1], Co, generator=g) / scale
     xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
     bd = b.double().requires_grad_(True) if bias else None
     (F.linear(xd, wd, bd) * gy.double()).sum().backward()
