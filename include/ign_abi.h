@@ -172,6 +172,22 @@ int ign_attn_bwd_x6_strided(const float* q, const float* k, const float* v, cons
                  float scale, void* stream,
                             long long g_sb, long long g_sl, int bf16);
 
+/* The attention core on two fp16 planes / three products per element pair (the "h3" arithmetic described at ign_clconv_fwd_h3;
+ * E <= 64): Q, K, V, dO are scaled by powers of two from the device-side bounds bq / bk / bv / bgo (upper bounds of their maxima),
+ * scores are un-scaled inside the exp2, probabilities (<= 1) are split after a multiplication by 2^14, the score gradient by its
+ * hard bound 2 E max|dO| max|V|.  Same results as ign_attn_fwd_x6 / ign_attn_bwd_x6 at the fp32 rounding level.  g_sb = g_sl = 0:
+ * contiguous gradients, else the strided outputs of ign_attn_bwd_x6_strided.                                                  */
+int ign_attn_fwd_h3(const float* q, const float* k, const float* v, float* out, float* lse,
+                    int B, int L, int S, int H, int E,
+                    long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl,
+                    float scale, void* stream, const float* bq, const float* bk, const float* bv);
+int ign_attn_bwd_h3(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* gout,
+                    float* gq, float* gk, float* gv, float* delta_ws,
+                    int B, int L, int S, int H, int E,
+                    long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl,
+                    float scale, void* stream, long long g_sb, long long g_sl,
+                    const float* bq, const float* bk, const float* bv, const float* bgo);
+
 /* Skinny expert-head GEMM  out[b,n] = sum_f X[b,f] W[n,f] (+ bias[n]),  N <= 16 classes, F % 4 == 0, row pitch ldx.
  * Replaces nn.Linear at IGN/model/Shapelet.py:171,200 (SBM head), IGN/model/Transformer.py:72,109,
  * IGN/model/FullyConvNet.py:50,58.  Backward: gX (B,ldx) and/or gW (N,F), gbias (N) (any may be NULL); sums over the

@@ -29,9 +29,35 @@ struct AttnX6Args {
     long long q_sb, q_sl, k_sb, k_sl, v_sb, v_sl;
     int B, L, S, H, E;
     float scale;
+    const float *bq, *bk, *bv;               // NP = 2 (two fp16 planes, three products): device-side bounds of |q|, |k|, |v|
 };
 
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+// ---- NP = 2: two fp16 planes of power-of-two-scaled operands, THREE products (include/ign_abi.h, "h3").  Scales come from
+// device-side magnitude bounds (pow2_scale); scores are un-scaled inside the exp2 (an FMA instead of a subtraction), the
+// probabilities (<= 1) are split after a multiplication by 2^14, products of bounds give hard bounds for derived operands
+// (|dS| <= 2 E max|dO| max|V|).  The planes are 16-bit slots of the same LDS / register layouts as the bf16 planes.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int NP>
+__device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    if constexpr (NP == 2)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+#define MFMA16(a, b, c) mfma16<NP>((a), (b), (c))
+__device__ __forceinline__ float pow2_scale_v(float b) {      // 2^e with 2^13 <= b 2^e < 2^14 (1 for zero / non-finite b)
+    if (!(b > 0.f) || !(b < INFINITY)) return 1.f;
+    int e;
+    (void)frexpf(b, &e);
+    e = 14 - e;
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);
+    return ldexpf(1.f, e);
+}
+__device__ __forceinline__ void split2h_pair(f32x2 v, f16x2& x0, f16x2& x1) {
+    x0 = __builtin_convertvector(v, f16x2);
+    x1 = __builtin_convertvector(v - __builtin_convertvector(x0, f32x2), f16x2);
+}
 
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -47,6 +73,17 @@ __device__ __forceinline__ void split3_pair(f32x2 v, bf16x2& x0, bf16x2& x1, bf1
 // NP = 1: the values rounded to bf16 (one product: the arithmetic of the reference's bf16-autocast mode); p1, p2 stay unused.
 template <int NP>
 __device__ __forceinline__ void splitN_x8(const float (&t)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    if constexpr (NP == 2) {
+        f16x2 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split2h_pair(f32x2{t[2 * i], t[2 * i + 1]}, a[i], b[i]);
+        p0 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(__builtin_shufflevector(a[0], a[1], 0, 1, 2, 3),
+                                                                __builtin_shufflevector(a[2], a[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7));
+        p1 = __builtin_bit_cast(bf16x8, __builtin_shufflevector(__builtin_shufflevector(b[0], b[1], 0, 1, 2, 3),
+                                                                __builtin_shufflevector(b[2], b[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7));
+        p2 = p0;
+        return;
+    }
     if constexpr (NP == 1) {
         bf16x2 a[4];
 #pragma unroll
@@ -79,6 +116,16 @@ __device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
 template <int NP>
 __device__ __forceinline__ void splitN_store4(const float4 t, __bf16* d, int plane) {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    if constexpr (NP == 2) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        f16x2 a0, a1, b0, b1;
+        split2h_pair(f32x2{t.x, t.y}, a0, a1);
+        split2h_pair(f32x2{t.z, t.w}, b0, b1);
+        _Float16* dh = reinterpret_cast<_Float16*>(d);
+        *reinterpret_cast<f16x4*>(dh) = __builtin_shufflevector(a0, b0, 0, 1, 2, 3);
+        *reinterpret_cast<f16x4*>(dh + plane) = __builtin_shufflevector(a1, b1, 0, 1, 2, 3);
+        return;
+    }
     if constexpr (NP == 1) {
         const bf16x2 a = __builtin_convertvector(f32x2{t.x, t.y}, bf16x2), b = __builtin_convertvector(f32x2{t.z, t.w}, bf16x2);
         *reinterpret_cast<bf16x4*>(d) = __builtin_shufflevector(a, b, 0, 1, 2, 3);
@@ -112,7 +159,14 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
     const bool q_ok = qi < a.L;
 
     // Q^T operand: lane (query, h) holds e = 16s + 8h .. +7 of slab s, three planes, scale folded in before the split
-    const float sc2 = a.scale * 1.44269504088896341f;
+    const float sc2u = a.scale * 1.44269504088896341f;
+    // NP = 2: operand scales; `us` un-scales a score inside the exp2, `pexp` = 14 makes the exp2 return 2^14 p
+    const float sq = (NP == 2) ? pow2_scale_v(*a.bq * fabsf(sc2u)) : 1.f;
+    const float sk = (NP == 2) ? pow2_scale_v(*a.bk) : 1.f;
+    const float sv = (NP == 2) ? pow2_scale_v(*a.bv) : 1.f;
+    const float us = (NP == 2) ? 1.f / (sq * sk) : 1.f;
+    constexpr float pexp = (NP == 2) ? 14.f : 0.f;
+    const float sc2 = sc2u * sq;
     bf16x8 Qf[3][NS];
     {
         const float* qp = a.q + b * a.q_sb + (long long)(q_ok ? qi : a.L - 1) * a.q_sl + head * E + 8 * h;
@@ -149,6 +203,10 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
         float4 tk_ = *reinterpret_cast<const float4*>(kbase + (long long)rc_ * a.k_sl + sc);         \
         float4 tv_ = *reinterpret_cast<const float4*>(vbase + (long long)rc_ * a.v_sl + sc);         \
         if (r_ >= a.S) tk_ = tv_ = make_float4(0.f, 0.f, 0.f, 0.f);                                  \
+        if constexpr (NP == 2) {                                                                     \
+            tk_ = make_float4(tk_.x * sk, tk_.y * sk, tk_.z * sk, tk_.w * sk);                       \
+            tv_ = make_float4(tv_.x * sv, tv_.y * sv, tv_.z * sv, tv_.w * sv);                       \
+        }                                                                                            \
         rk[p] = tk_; rv[p] = tv_;                                                                    \
     }
     IGN_GLOAD(0)
@@ -182,6 +240,11 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
                         acc2 = MFMA16(k1, Qf[0][s], acc2);
                         acc = MFMA16(k0, Qf[1][s], acc);
                         acc2 = MFMA16(k0, Qf[0][s], acc2);
+                    } else if constexpr (NP == 2) {
+                        acc = MFMA16(k1, Qf[0][s], acc);
+                        acc2 = MFMA16(k0, Qf[1][s], acc2);
+                        if (s & 1) acc2 = MFMA16(k0, Qf[0][s], acc2);
+                        else acc = MFMA16(k0, Qf[0][s], acc);
                     } else {
                         if (s & 1) acc2 = MFMA16(k0, Qf[0][s], acc2);
                         else acc = MFMA16(k0, Qf[0][s], acc);
@@ -199,13 +262,15 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, acc[r]);
                 mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                if constexpr (NP == 2) mloc *= us;               // the accumulators hold sq sk S: the maximum commutes with a positive scale
                 const float mnew = fmaxf(m, mloc);
                 const float alpha = __builtin_amdgcn_exp2f(m - mnew);
                 const bool rescale = __builtin_amdgcn_ballot_w64(mnew != m) != 0;     // wave-uniform: the running max moved
                 float psum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    acc[r] = __builtin_amdgcn_exp2f(acc[r] - mnew);
+                    if constexpr (NP == 2) acc[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], us, pexp - mnew));    // 2^14 p
+                    else acc[r] = __builtin_amdgcn_exp2f(acc[r] - mnew);
                     psum += acc[r];
                 }
                 psum += __shfl_xor(psum, 32, 64);
@@ -232,14 +297,13 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
                     for (int d = 0; d < ED; ++d) {
                         const __bf16* vp = Vs + (kb + 16 * s2) * PV + voff + d * 32;
                         vf[d][0] = lds_tr8(vp, vp + 8 * PV);
-                        if constexpr (NP == 3) {
-                            vf[d][1] = lds_tr8(vp + VPLANE, vp + VPLANE + 8 * PV);
-                            vf[d][2] = lds_tr8(vp + 2 * VPLANE, vp + 2 * VPLANE + 8 * PV);
-                        }
+                        if constexpr (NP >= 2) vf[d][1] = lds_tr8(vp + VPLANE, vp + VPLANE + 8 * PV);
+                        if constexpr (NP == 3) vf[d][2] = lds_tr8(vp + 2 * VPLANE, vp + 2 * VPLANE + 8 * PV);
                     }
                     // the feature blocks are independent accumulators: alternate them
 #define IGN_PV(pa_, pb_) _Pragma("unroll") for (int d = 0; d < ED; ++d) O[d] = MFMA16(vf[d][pa_], Pf[pb_][s2], O[d]);
-                    if constexpr (NP == 3) { IGN_PV(2, 0) IGN_PV(0, 2) IGN_PV(1, 1) IGN_PV(1, 0) IGN_PV(0, 1) }
+                    if constexpr (NP == 3) { IGN_PV(2, 0) IGN_PV(0, 2) IGN_PV(1, 1) }
+                    if constexpr (NP >= 2) { IGN_PV(1, 0) IGN_PV(0, 1) }
                     IGN_PV(0, 0)
 #undef IGN_PV
                 }
@@ -247,7 +311,9 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_x6_kernel(const AttnX6Args a)
         }
     }
     if (q_ok) {
-        const float inv = 1.f / l;
+        // NP = 2: O holds sv * 2^14 * sum p v and l holds 2^14 * sum p
+        const float inv = (NP == 2) ? 1.f / (l * sv) : 1.f / l;
+        if constexpr (NP == 2) l *= 6.103515625e-05f;              // 2^-14: the log-sum-exp below is of the unscaled sum
         float* op = a.out + (((long long)b * a.L + qi) * a.H + head) * E;
 #pragma unroll
         for (int d = 0; d < ED; ++d)
@@ -276,6 +342,7 @@ struct AttnX6BwdArgs {
     long long gq_sb, gkv_sb, g_sl;                 // element strides of the gradient outputs (batch for gq / gk, gv; sequence)
     int B, L, S, H, E;
     float scale;
+    const float *bq, *bk, *bv, *bg;                // NP = 2: device-side bounds of |q|, |k|, |v|, |dO|
 };
 
 constexpr int AB_T = 32;                                          // rows per staged tile
@@ -327,6 +394,12 @@ __device__ __forceinline__ void x6_rows_times_regs(f32x16& acc, const __bf16* T,
             acc2 = MFMA16(t1, F[0][s], acc2);
             acc = MFMA16(t0, F[1][s], acc);
             acc2 = MFMA16(t0, F[0][s], acc2);
+        } else if constexpr (NP == 2) {
+            const bf16x8 t1 = *reinterpret_cast<const bf16x8*>(tr + PLANE + 16 * s);
+            acc = MFMA16(t1, F[0][s], acc);
+            acc2 = MFMA16(t0, F[1][s], acc2);
+            if (s & 1) acc2 = MFMA16(t0, F[0][s], acc2);
+            else acc = MFMA16(t0, F[0][s], acc);
         } else {
             if (s & 1) acc2 = MFMA16(t0, F[0][s], acc2);
             else acc = MFMA16(t0, F[0][s], acc);
@@ -357,14 +430,13 @@ __device__ __forceinline__ void x6_tileT_times_acc(f32x16 (&G)[(E + 31) / 32], c
         for (int d = 0; d < ED; ++d) {
             const __bf16* tp = T + (16 * s2) * P + off + d * 32;
             tf[d][0] = lds_tr8(tp, tp + 8 * P);
-            if constexpr (NP == 3) {
-                tf[d][1] = lds_tr8(tp + PLANE, tp + PLANE + 8 * P);
-                tf[d][2] = lds_tr8(tp + 2 * PLANE, tp + 2 * PLANE + 8 * P);
-            }
+            if constexpr (NP >= 2) tf[d][1] = lds_tr8(tp + PLANE, tp + PLANE + 8 * P);
+            if constexpr (NP == 3) tf[d][2] = lds_tr8(tp + 2 * PLANE, tp + 2 * PLANE + 8 * P);
         }
         // the feature blocks are independent accumulators: alternate them
 #define IGN_TW(pa_, pb_) _Pragma("unroll") for (int d = 0; d < ED; ++d) G[d] = MFMA16(tf[d][pa_], W[pb_][s2], G[d]);
-        if constexpr (NP == 3) { IGN_TW(2, 0) IGN_TW(0, 2) IGN_TW(1, 1) IGN_TW(1, 0) IGN_TW(0, 1) }
+        if constexpr (NP == 3) { IGN_TW(2, 0) IGN_TW(0, 2) IGN_TW(1, 1) }
+        if constexpr (NP >= 2) { IGN_TW(1, 0) IGN_TW(0, 1) }
         IGN_TW(0, 0)
 #undef IGN_TW
     }
@@ -378,6 +450,10 @@ __device__ __forceinline__ void x6_tileT_times_acc(f32x16 (&G)[(E + 31) / 32], c
         float4 ta_ = *reinterpret_cast<const float4*>((basea_) + (long long)rc_ * (sla_) + sc);      \
         float4 tb_ = *reinterpret_cast<const float4*>((baseb_) + (long long)rc_ * (slb_) + sc);      \
         if (r_ >= (nrows_) || !stg) ta_ = tb_ = make_float4(0.f, 0.f, 0.f, 0.f);                     \
+        if constexpr (NP == 2) {                                                                     \
+            ta_ = make_float4(ta_.x * sta, ta_.y * sta, ta_.z * sta, ta_.w * sta);                   \
+            tb_ = make_float4(tb_.x * stb, tb_.y * stb, tb_.z * stb, tb_.w * stb);                   \
+        }                                                                                            \
         ra[p] = ta_; rb[p] = tb_;                                                                    \
     }
 #define IGN_AB_STORE(Ta_, Tb_)                                                                       \
@@ -417,6 +493,14 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_x6_kernel(const AttnX6BwdA
     const bool q_ok = qi < a.L;
     const long long qrow = q_ok ? qi : a.L - 1;
 
+    // NP = 2 scales: registers Q (sq, incl. the softmax scale) and dO (sg); staged tiles K (sta = sk) and V (stb = sv);
+    // dS by the hard bound |dS| <= p (|dP| + |delta|) <= 2 E max|dO| max|V|
+    const float sc2u = a.scale * 1.44269504088896341f;
+    const float sq = (NP == 2) ? pow2_scale_v(*a.bq * fabsf(sc2u)) : 1.f;
+    const float sg = (NP == 2) ? pow2_scale_v(*a.bg) : 1.f;
+    const float sta = (NP == 2) ? pow2_scale_v(*a.bk) : 1.f, stb = (NP == 2) ? pow2_scale_v(*a.bv) : 1.f;
+    const float sds = (NP == 2) ? pow2_scale_v(2.f * (float)E * *a.bg * *a.bv) : 1.f;
+    const float us = (NP == 2) ? 1.f / (sq * sta) : 1.f, up = (NP == 2) ? 1.f / (sg * stb) : 1.f;
     bf16x8 Qf[3][NS], Gf[3][NS];
     float del_q = 0.f;                                         // delta = rowsum(dO * O): this lane's half of the row, then lane ^ 32
     {
@@ -425,11 +509,11 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_x6_kernel(const AttnX6BwdA
         const float* op = a.o + (((long long)b * a.L + qrow) * a.H + head) * E + 8 * h;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            load_split8<NP>(qp + 16 * s, a.scale * 1.44269504088896341f, Qf[0][s], Qf[1][s], Qf[2][s]);   // base-2 softmax
+            load_split8<NP>(qp + 16 * s, sc2u * sq, Qf[0][s], Qf[1][s], Qf[2][s]);   // base-2 softmax
             const float4 g0 = *reinterpret_cast<const float4*>(gp + 16 * s), g1 = *reinterpret_cast<const float4*>(gp + 16 * s + 4);
             const float4 o0 = *reinterpret_cast<const float4*>(op + 16 * s), o1 = *reinterpret_cast<const float4*>(op + 16 * s + 4);
             del_q += g0.x * o0.x + g0.y * o0.y + g0.z * o0.z + g0.w * o0.w + g1.x * o1.x + g1.y * o1.y + g1.z * o1.z + g1.w * o1.w;
-            const float t[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float t[8] = {g0.x * sg, g0.y * sg, g0.z * sg, g0.w * sg, g1.x * sg, g1.y * sg, g1.z * sg, g1.w * sg};
             splitN_x8<NP>(t, Gf[0][s], Gf[1][s], Gf[2][s]);
         }
     }
@@ -465,10 +549,15 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_x6_kernel(const AttnX6BwdA
                 if (kt0 + acc_row(r, h) >= a.S) st[r] = -INFINITY;
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(st[r] - lse_q) * (dp[r] - del_q);
+        for (int r = 0; r < 16; ++r) {
+            if constexpr (NP == 2) dp[r] = __builtin_amdgcn_exp2f(fmaf(st[r], us, -lse_q)) * fmaf(dp[r], up * sds, -del_q * sds);
+            else dp[r] = __builtin_amdgcn_exp2f(st[r] - lse_q) * (dp[r] - del_q);
+        }
         x6_tileT_times_acc<E, NP>(dQ, Ks, dp, lane);
     }
-    if (q_ok) store_grad_rows<E>(a.gq + b * a.gq_sb + (long long)qi * a.g_sl + head * E, dQ, a.scale, h);
+    // NP = 2: dQ holds sk sds K^T dS
+    if (q_ok) store_grad_rows<E>(a.gq + b * a.gq_sb + (long long)qi * a.g_sl + head * E, dQ,
+                                 (NP == 2) ? a.scale / (sta * sds) : a.scale, h);
 }
 
 // ---- dK / dV: block = 4 waves x 32 keys (lanes); loops over query tiles.  S = Q K^T (rows = queries), P = exp(S - lse);
@@ -491,14 +580,23 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
     const float kmask = k_ok ? 0.f : -INFINITY;                   // a lane past S contributes p = 2^-inf = 0
     const long long krow = k_ok ? ki : a.S - 1;
 
+    // NP = 2 scales: registers K (sk, incl. the softmax scale) and V (sv); staged tiles Q (sta = sq) and dO (stb = sg);
+    // P (<= 1) by 2^14, dS by its hard bound 2 E max|dO| max|V|
+    const float sc2u = a.scale * 1.44269504088896341f;
+    const float sk = (NP == 2) ? pow2_scale_v(*a.bk * fabsf(sc2u)) : 1.f;
+    const float sv = (NP == 2) ? pow2_scale_v(*a.bv) : 1.f;
+    const float sta = (NP == 2) ? pow2_scale_v(*a.bq) : 1.f, stb = (NP == 2) ? pow2_scale_v(*a.bg) : 1.f;
+    const float sds = (NP == 2) ? pow2_scale_v(2.f * (float)E * *a.bg * *a.bv) : 1.f;
+    const float us = (NP == 2) ? 1.f / (sk * sta) : 1.f, up = (NP == 2) ? 1.f / (sv * stb) : 1.f;
+    const float pexp = (NP == 2 && DV) ? 14.f : 0.f;              // the dV product takes 2^14 p as its operand
     bf16x8 Kf[3][NS], Vf[3][DV ? 1 : NS];
     {
         const float* kp = a.k + b * a.k_sb + krow * a.k_sl + head * E + 8 * h;
         const float* vp = a.v + b * a.v_sb + krow * a.v_sl + head * E + 8 * h;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            load_split8<NP>(kp + 16 * s, a.scale * 1.44269504088896341f, Kf[0][s], Kf[1][s], Kf[2][s]);   // base-2 softmax
-            if constexpr (!DV) load_split8<NP>(vp + 16 * s, 1.f, Vf[0][s], Vf[1][s], Vf[2][s]);
+            load_split8<NP>(kp + 16 * s, sc2u * sk, Kf[0][s], Kf[1][s], Kf[2][s]);   // base-2 softmax
+            if constexpr (!DV) load_split8<NP>(vp + 16 * s, sv, Vf[0][s], Vf[1][s], Vf[2][s]);
         }
     }
     f32x16 G[ED];
@@ -541,10 +639,18 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 lv = *reinterpret_cast<const float4*>(Ls + 8 * g + 4 * h);
-            s[4 * g] = __builtin_amdgcn_exp2f(s[4 * g] - lv.x + kmask);
-            s[4 * g + 1] = __builtin_amdgcn_exp2f(s[4 * g + 1] - lv.y + kmask);
-            s[4 * g + 2] = __builtin_amdgcn_exp2f(s[4 * g + 2] - lv.z + kmask);
-            s[4 * g + 3] = __builtin_amdgcn_exp2f(s[4 * g + 3] - lv.w + kmask);
+            if constexpr (NP == 2) {
+                const float km = kmask + pexp;
+                s[4 * g] = __builtin_amdgcn_exp2f(fmaf(s[4 * g], us, km - lv.x));
+                s[4 * g + 1] = __builtin_amdgcn_exp2f(fmaf(s[4 * g + 1], us, km - lv.y));
+                s[4 * g + 2] = __builtin_amdgcn_exp2f(fmaf(s[4 * g + 2], us, km - lv.z));
+                s[4 * g + 3] = __builtin_amdgcn_exp2f(fmaf(s[4 * g + 3], us, km - lv.w));
+            } else {
+                s[4 * g] = __builtin_amdgcn_exp2f(s[4 * g] - lv.x + kmask);
+                s[4 * g + 1] = __builtin_amdgcn_exp2f(s[4 * g + 1] - lv.y + kmask);
+                s[4 * g + 2] = __builtin_amdgcn_exp2f(s[4 * g + 2] - lv.z + kmask);
+                s[4 * g + 3] = __builtin_amdgcn_exp2f(s[4 * g + 3] - lv.w + kmask);
+            }
         }
         if constexpr (DV) {
             x6_tileT_times_acc<E, NP>(G, Gs, s, lane);
@@ -556,17 +662,26 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 dv = *reinterpret_cast<const float4*>(Ds + 8 * g + 4 * h);
-                dp[4 * g] = s[4 * g] * (dp[4 * g] - dv.x);
-                dp[4 * g + 1] = s[4 * g + 1] * (dp[4 * g + 1] - dv.y);
-                dp[4 * g + 2] = s[4 * g + 2] * (dp[4 * g + 2] - dv.z);
-                dp[4 * g + 3] = s[4 * g + 3] * (dp[4 * g + 3] - dv.w);
+                if constexpr (NP == 2) {
+                    const float ups = up * sds;
+                    dp[4 * g] = s[4 * g] * fmaf(dp[4 * g], ups, -dv.x * sds);
+                    dp[4 * g + 1] = s[4 * g + 1] * fmaf(dp[4 * g + 1], ups, -dv.y * sds);
+                    dp[4 * g + 2] = s[4 * g + 2] * fmaf(dp[4 * g + 2], ups, -dv.z * sds);
+                    dp[4 * g + 3] = s[4 * g + 3] * fmaf(dp[4 * g + 3], ups, -dv.w * sds);
+                } else {
+                    dp[4 * g] = s[4 * g] * (dp[4 * g] - dv.x);
+                    dp[4 * g + 1] = s[4 * g + 1] * (dp[4 * g + 1] - dv.y);
+                    dp[4 * g + 2] = s[4 * g + 2] * (dp[4 * g + 2] - dv.z);
+                    dp[4 * g + 3] = s[4 * g + 3] * (dp[4 * g + 3] - dv.w);
+                }
             }
             x6_tileT_times_acc<E, NP>(G, Qs, dp, lane);
         }
     }
     if (k_ok) {
         float* dst = (DV ? a.gv : a.gk) + b * a.gkv_sb + (long long)ki * a.g_sl + head * E;
-        store_grad_rows<E>(dst, G, DV ? 1.f : a.scale, h);
+        // NP = 2: dV holds sg 2^14 dO^T P; dK holds sq sds Q^T dS
+        store_grad_rows<E>(dst, G, DV ? ((NP == 2) ? 6.103515625e-05f / stb : 1.f) : ((NP == 2) ? a.scale / (sta * sds) : a.scale), h);
     }
 }
 
@@ -574,7 +689,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
 template <int NP>
 static int attn_fwd_x6_impl(const char* who, const float* q, const float* k, const float* v, float* out, float* lse, int B, int L,
                             int S, int H, int E, long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb,
-                            long long v_sl, float scale, void* stream) {
+                            long long v_sl, float scale, void* stream, const float* const* bounds = nullptr) {
     if (B <= 0 || L <= 0 || S <= 0 || H <= 0 || H > 65535 || B > 65535) {
         ign_set_error("%s: bad dimensions B=%d L=%d S=%d H=%d", who, B, L, S, H);
         return IGN_E_ARG;
@@ -583,6 +698,7 @@ static int attn_fwd_x6_impl(const char* who, const float* q, const float* k, con
         ign_set_error("%s: head dimension E=%d not instantiated (16, 32, 64, 128)", who, E);
         return IGN_E_UNSUP;
     }
+    if (NP == 2 && (!bounds || !bounds[0] || !bounds[1] || !bounds[2])) { ign_set_error("%s: null operand bound", who); return IGN_E_ARG; }
     const void* ptrs[5] = {q, k, v, out, lse};
     for (int i = 0; i < 5; ++i)
         if (!ptrs[i] || ((uintptr_t)ptrs[i] & 15)) {
@@ -600,6 +716,7 @@ static int attn_fwd_x6_impl(const char* who, const float* q, const float* k, con
     a.q = q; a.k = k; a.v = v; a.out = out; a.lse_out = lse;
     a.q_sb = q_sb; a.q_sl = q_sl; a.k_sb = k_sb; a.k_sl = k_sl; a.v_sb = v_sb; a.v_sl = v_sl;
     a.B = B; a.L = L; a.S = S; a.H = H; a.E = E; a.scale = scale;
+    if (NP == 2) { a.bq = bounds[0]; a.bk = bounds[1]; a.bv = bounds[2]; }
     const dim3 grid((L + 127) / 128, H, B);
     IgnScopedTimer tm("attn_fwd", s);
 #define IGN_AX(EE)                                                                                                            \
@@ -627,7 +744,12 @@ template <int NP>
 static int attn_bwd_x6_impl(const char* who, const float* q, const float* k, const float* v, const float* out, const float* lse,
                             const float* gout, float* gq, float* gk, float* gv, float* delta_ws, int B, int L, int S, int H,
                             int E, long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb,
-                            long long v_sl, float scale, void* stream, long long g_sb = 0, long long g_sl = 0) {
+                            long long v_sl, float scale, void* stream, long long g_sb = 0, long long g_sl = 0,
+                            const float* const* bounds = nullptr) {
+    if (NP == 2 && (!bounds || !bounds[0] || !bounds[1] || !bounds[2] || !bounds[3])) {
+        ign_set_error("%s: null operand bound", who);
+        return IGN_E_ARG;
+    }
     if (B <= 0 || L <= 0 || S <= 0 || H <= 0 || H > 65535 || B > 65535) {
         ign_set_error("%s: bad dimensions B=%d L=%d S=%d H=%d", who, B, L, S, H);
         return IGN_E_ARG;
@@ -658,6 +780,7 @@ static int attn_bwd_x6_impl(const char* who, const float* q, const float* k, con
     a.gq = gq; a.gk = gk; a.gv = gv;
     a.q_sb = q_sb; a.q_sl = q_sl; a.k_sb = k_sb; a.k_sl = k_sl; a.v_sb = v_sb; a.v_sl = v_sl;
     a.B = B; a.L = L; a.S = S; a.H = H; a.E = E; a.scale = scale;
+    if (NP == 2) { a.bq = bounds[0]; a.bk = bounds[1]; a.bv = bounds[2]; a.bg = bounds[3]; }
     a.g_sl = g_sl ? g_sl : (long long)H * E;
     a.gq_sb = g_sb ? g_sb : (long long)L * H * E;
     a.gkv_sb = g_sb ? g_sb : (long long)S * H * E;
@@ -712,6 +835,21 @@ extern "C" int ign_attn_fwd_bf16(IGN_ATTN_FWD_ARGS) {
 extern "C" int ign_attn_bwd_bf16(IGN_ATTN_BWD_ARGS) {
     return attn_bwd_x6_impl<1>("ign_attn_bwd_bf16", q, k, v, out, lse, gout, gq, gk, gv, delta_ws, B, L, S, H, E, q_sb, q_sl, k_sb,
                                k_sl, v_sb, v_sl, scale, stream);
+}
+
+// Two fp16 planes, three products (include/ign_abi.h, "h3"): bq / bk / bv / bgo are device scalars holding upper bounds of
+// max|q|, max|k|, max|v|, max|dO|.  g_sb = g_sl = 0: contiguous gradients; else the strided form of ign_attn_bwd_x6_strided.
+extern "C" int ign_attn_fwd_h3(IGN_ATTN_FWD_ARGS, const float* bq, const float* bk, const float* bv) {
+    if (E > 64) { ign_set_error("ign_attn_fwd_h3: E=%d > 64", E); return IGN_E_UNSUP; }
+    const float* bounds[3] = {bq, bk, bv};
+    return attn_fwd_x6_impl<2>("ign_attn_fwd_h3", q, k, v, out, lse, B, L, S, H, E, q_sb, q_sl, k_sb, k_sl, v_sb, v_sl, scale, stream, bounds);
+}
+extern "C" int ign_attn_bwd_h3(IGN_ATTN_BWD_ARGS, long long g_sb, long long g_sl, const float* bq, const float* bk, const float* bv,
+                               const float* bgo) {
+    if (E > 64) { ign_set_error("ign_attn_bwd_h3: E=%d > 64", E); return IGN_E_UNSUP; }
+    const float* bounds[4] = {bq, bk, bv, bgo};
+    return attn_bwd_x6_impl<2>("ign_attn_bwd_h3", q, k, v, out, lse, gout, gq, gk, gv, delta_ws, B, L, S, H, E, q_sb, q_sl, k_sb, k_sl,
+                               v_sb, v_sl, scale, stream, g_sb, g_sl, bounds);
 }
 
 // The same backward writing gq / gk / gv with the caller's batch and sequence strides (elements; head stride E): lets the three

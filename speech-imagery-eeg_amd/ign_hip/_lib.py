@@ -37,6 +37,9 @@ SIGNATURES = {
                                      ci]),
     "ign_attn_fwd_bf16": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
     "ign_attn_bwd_bf16": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
+    "ign_attn_fwd_h3": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp, vp, vp, vp]),
+    "ign_attn_bwd_h3": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp, ll, ll,
+                             vp, vp, vp, vp]),
     "ign_head_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ll, vp]),
     "ign_head_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]),
     "ign_gate_fwd": (ci, [vp, vp, vp, vp, ci, ci, cf, ci, vp]),

@@ -314,9 +314,17 @@ class AttentionFn(torch.autograd.Function):
         # "bf16x6": split-bf16 products on the bf16 matrix cores (fp32 accuracy); "f32": the fp32-MFMA kernel; inside an
         # autocast region (the reference's default mode): operands rounded to bf16, one product
         ctx.bf16 = torch.is_autocast_enabled() and E <= 64
-        fwd = L_.ign_attn_fwd_bf16 if ctx.bf16 else (L_.ign_attn_fwd_x6 if ATTN_MATH == "bf16x6" else L_.ign_attn_fwd)
-        _lib.check(fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, L, S, H, E, qb, ql, kb, kl, vb, vl, float(scale),
-                       _stream()), "ign_attn_fwd")
+        # "f16x3": two fp16 planes of power-of-two-scaled operands, three products (ign_attn_fwd_h3); needs the magnitude bounds
+        ctx.h3 = (not ctx.bf16) and ATTN_MATH == "bf16x6" and GEMM_MATH == "f16x3" and E <= 64
+        ctx.bounds = None
+        if ctx.h3:
+            ctx.bounds = (tensor_bound(q), tensor_bound(k), tensor_bound(v))
+            _lib.check(L_.ign_attn_fwd_h3(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, L, S, H, E, qb, ql, kb, kl, vb, vl,
+                                          float(scale), _stream(), *[_ptr(t) for t in ctx.bounds]), "ign_attn_fwd_h3")
+        else:
+            fwd = L_.ign_attn_fwd_bf16 if ctx.bf16 else (L_.ign_attn_fwd_x6 if ATTN_MATH == "bf16x6" else L_.ign_attn_fwd)
+            _lib.check(fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, L, S, H, E, qb, ql, kb, kl, vb, vl, float(scale),
+                           _stream()), "ign_attn_fwd")
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.scale = float(scale)
         return out
@@ -332,6 +340,11 @@ class AttentionFn(torch.autograd.Function):
         gv = torch.empty_like(gk)
         delta = torch.empty(B, H, L, device=q.device, dtype=torch.float32)
         (qb, ql), (kb, kl), (vb, vl) = _bl_strides(q, "q"), _bl_strides(k, "k"), _bl_strides(v, "v")
+        if ctx.h3:
+            _lib.check(_lib.lib().ign_attn_bwd_h3(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(gout), _ptr(gq), _ptr(gk), _ptr(gv),
+                                                  _ptr(delta), B, L, S, H, E, qb, ql, kb, kl, vb, vl, ctx.scale, _stream(), 0, 0,
+                                                  *[_ptr(t) for t in ctx.bounds], _ptr(tensor_bound(gout))), "ign_attn_bwd_h3")
+            return gq, gk, gv, None
         # split-bf16 kernels up to E = 64 (E = 128 exceeds their register budget: the fp32-MFMA backward is faster there)
         bwd = (_lib.lib().ign_attn_bwd_bf16 if ctx.bf16 else
                _lib.lib().ign_attn_bwd_x6 if (ATTN_MATH == "bf16x6" and E <= 64) else _lib.lib().ign_attn_bwd)
@@ -360,9 +373,17 @@ class PackedAttentionFn(torch.autograd.Function):
         sb, sl = qkv.stride(0), qkv.stride(1)
         L_ = _lib.lib()
         ctx.bf16 = torch.is_autocast_enabled()
-        fwd = L_.ign_attn_fwd_bf16 if ctx.bf16 else L_.ign_attn_fwd_x6
-        _lib.check(fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, L, L, H, E, sb, sl, sb, sl, sb, sl, float(scale),
-                       _stream()), "ign_attn_fwd_x6")
+        ctx.h3 = (not ctx.bf16) and GEMM_MATH == "f16x3"
+        ctx.bound = None
+        if ctx.h3:
+            ctx.bound = tensor_bound(qkv)             # one pass: a bound of the packed tensor bounds q, k and v alike
+            bp = _ptr(ctx.bound)
+            _lib.check(L_.ign_attn_fwd_h3(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, L, L, H, E, sb, sl, sb, sl, sb, sl,
+                                          float(scale), _stream(), bp, bp, bp), "ign_attn_fwd_h3")
+        else:
+            fwd = L_.ign_attn_fwd_bf16 if ctx.bf16 else L_.ign_attn_fwd_x6
+            _lib.check(fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, L, L, H, E, sb, sl, sb, sl, sb, sl, float(scale),
+                           _stream()), "ign_attn_fwd_x6")
         ctx.save_for_backward(qkv, out, lse)
         ctx.scale = float(scale)
         return out
@@ -376,6 +397,13 @@ class PackedAttentionFn(torch.autograd.Function):
         gqkv = torch.empty_like(qkv)
         delta = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32)
         sb, sl = qkv.stride(0), qkv.stride(1)
+        if ctx.h3:
+            bp = _ptr(ctx.bound)
+            _lib.check(_lib.lib().ign_attn_bwd_h3(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(gout), _ptr(gqkv[:, :, 0]),
+                                                  _ptr(gqkv[:, :, 1]), _ptr(gqkv[:, :, 2]), _ptr(delta), B, L, L, H, E, sb, sl, sb, sl,
+                                                  sb, sl, ctx.scale, _stream(), sb, sl, bp, bp, bp, _ptr(tensor_bound(gout))),
+                       "ign_attn_bwd_h3")
+            return gqkv, None
         _lib.check(_lib.lib().ign_attn_bwd_x6_strided(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(gout),
                                                       _ptr(gqkv[:, :, 0]), _ptr(gqkv[:, :, 1]), _ptr(gqkv[:, :, 2]), _ptr(delta),
                                                       B, L, L, H, E, sb, sl, sb, sl, sb, sl, ctx.scale, _stream(), sb, sl,
@@ -464,6 +492,10 @@ def tensor_bound(t):
     cached = getattr(t, "_ign_bound", None)
     if cached is not None and cached[1] == t._version and cached[2] == t.data_ptr():
         return cached[0]
+    if not t.is_contiguous():
+        base = getattr(t, "_base", None)
+        if base is not None and base.is_contiguous() and base.dtype == t.dtype and base.numel() <= 4 * t.numel():
+            return tensor_bound(base)         # a strided view (q / k / v of a packed projection): the base tensor's bound bounds it
     tc = t if t.is_contiguous() else t.contiguous()
     slot = _new_slot(t.device)
     _lib.check(_lib.lib().ign_absmax(_ptr(tc), tc.numel(), _ptr(slot), _stream()), "ign_absmax")

@@ -35,12 +35,18 @@ def _attn_ref(q, k, v, scale):
     return torch.einsum("bhls,bshd->blhd", torch.softmax(scale * s, dim=-1), v)
 
 
-@pytest.mark.parametrize("amath", ["bf16x6", "f32"])
+def _set_attn_math(monkeypatch, ops, amath):
+    """"f16x3": two fp16 planes, three products (the default); "bf16x6": three bf16 planes, six products; "f32": fp32 MFMA"""
+    monkeypatch.setattr(ops, "ATTN_MATH", "bf16x6" if amath == "f16x3" else amath)
+    monkeypatch.setattr(ops, "GEMM_MATH", "f16x3" if amath == "f16x3" else "bf16x6")
+
+
+@pytest.mark.parametrize("amath", ["f16x3", "bf16x6", "f32"])
 def test_attention_core_golden(amath, monkeypatch):
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
     from ign_hip import ops
-    monkeypatch.setattr(ops, "ATTN_MATH", amath)
+    _set_attn_math(monkeypatch, ops, amath)
     g = golden("attention_core")
     q, k, v = (_t(g[n], dev).requires_grad_(True) for n in ("q", "k", "v"))
     o = ops.attention(q, k, v, 1.0 / math.sqrt(q.shape[-1]))
@@ -51,17 +57,20 @@ def test_attention_core_golden(amath, monkeypatch):
 
 @pytest.mark.parametrize("B,L,S,H,E", [(2, 1000, 1000, 8, 64), (3, 100, 100, 8, 64), (2, 130, 75, 2, 32),
                                        (1, 33, 257, 3, 16), (2, 64, 64, 1, 128)])
-@pytest.mark.parametrize("amath", ["bf16x6", "f32"])
+@pytest.mark.parametrize("amath", ["f16x3", "f16x3 scaled", "bf16x6", "f32"])
 def test_attention_vs_fp64_reference(B, L, S, H, E, amath, monkeypatch):
+    """"f16x3 scaled": q of magnitude 1e3 against k of 1e-3, v of 1e4 and an output gradient of 1e-6 -- the operand scaling of the
+    fp16 kernels must make fp16's exponent range invisible."""
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
     from ign_hip import ops
-    monkeypatch.setattr(ops, "ATTN_MATH", amath)
+    sq, sk, sv, sg = (1e3, 1e-3, 1e4, 1e-6) if amath.endswith("scaled") else (1.0, 1.0, 1.0, 1.0)
+    _set_attn_math(monkeypatch, ops, amath.split()[0])
     g = torch.Generator().manual_seed(L * 7 + E)
-    q = torch.randn(B, L, H, E, generator=g).to(dev).requires_grad_(True)
-    k = torch.randn(B, S, H, E, generator=g).to(dev).requires_grad_(True)
-    v = torch.randn(B, S, H, E, generator=g).to(dev).requires_grad_(True)
-    go = torch.randn(B, L, H, E, generator=g)
+    q = (torch.randn(B, L, H, E, generator=g) * sq).to(dev).requires_grad_(True)
+    k = (torch.randn(B, S, H, E, generator=g) * sk).to(dev).requires_grad_(True)
+    v = (torch.randn(B, S, H, E, generator=g) * sv).to(dev).requires_grad_(True)
+    go = torch.randn(B, L, H, E, generator=g) * sg
     scale = 1.0 / math.sqrt(E)
     o = ops.attention(q, k, v, scale)
     (o * go.to(dev)).sum().backward()
@@ -74,18 +83,22 @@ def test_attention_vs_fp64_reference(B, L, S, H, E, amath, monkeypatch):
         assert _rel(a, b) < 5e-5, name
 
 
-def test_attention_packed_qkv_strides_and_determinism():
+@pytest.mark.parametrize("amath", ["f16x3", "bf16x6"])
+def test_attention_packed_qkv_strides_and_determinism(amath, monkeypatch):
     """q/k/v as strided views of one packed (B,S,3,H,E) projection (the nn.MultiheadAttention in_proj layout)."""
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
     from ign_hip import ops
+    _set_attn_math(monkeypatch, ops, amath)
     torch.manual_seed(3)
     B, S, H, E = 4, 100, 8, 64
     qkv = torch.randn(B, S, 3, H, E, device=dev, requires_grad=True)
     o1 = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0.125)
     g1, = torch.autograd.grad(o1.sum() + (o1 * o1).sum(), qkv, retain_graph=True)
     o2 = ops.attention(qkv[:, :, 0].contiguous(), qkv[:, :, 1].contiguous(), qkv[:, :, 2].contiguous(), 0.125)
-    assert torch.equal(o1, o2)
+    # bf16 planes: layout-independent to the bit.  fp16 planes: the strided views share the packed tensor's bound, the copies
+    # have their own -- a different power-of-two scale moves which tiny elements round in fp16's subnormal range
+    assert torch.equal(o1, o2) if amath == "bf16x6" else _rel(o1, o2) < 1e-6
     g2, = torch.autograd.grad(o1.sum() + (o1 * o1).sum(), qkv)
     assert torch.equal(g1, g2), "backward not bitwise reproducible"
     oref = _attn_ref(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0.125)
