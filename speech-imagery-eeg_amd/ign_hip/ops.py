@@ -700,11 +700,22 @@ class ConvCLFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
         wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, k)), device=dev, dtype=torch.bfloat16) if need_dx else None
-        _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt3), _ptr(wd3), Co, Ci, k, _stream()), "ign_clconv_pack_weights_x3")
         y = torch.empty(B, Tin - k + 1, Co, device=dev, dtype=torch.float32)
         ctx.bf16 = torch.is_autocast_enabled()
-        _lib.check(_gemm(L, ctx.bf16)[0](_ptr(x), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, B, Tin, Ci, Co, k, _stream()),
-                   "ign_clconv_fwd_x6")
+        ctx.h3 = (not ctx.bf16) and GEMM_MATH == "f16x3"
+        ctx.bx = ctx.bw = None
+        if ctx.h3:          # two fp16 planes, three products (see LinearFn)
+            ctx.bw, ctx.bx = tensor_bound(w), tensor_bound(x)
+            v1, i1 = _tables(1)
+            _lib.check(L.ign_clconv_pack_weights_h2_multi(1, v1(w.data_ptr()), v1(wt3.data_ptr()), v1(wd3.data_ptr()) if need_dx else None,
+                                                          i1(Co), i1(Ci), i1(k), None, v1(ctx.bw.data_ptr()), _stream()),
+                       "ign_clconv_pack_weights_h2_multi")
+            _lib.check(L.ign_clconv_fwd_h3(_ptr(x), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, _ptr(ctx.bx), _ptr(ctx.bw), B, Tin, Ci,
+                                           Co, k, _stream()), "ign_clconv_fwd_h3")
+        else:
+            _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt3), _ptr(wd3), Co, Ci, k, _stream()), "ign_clconv_pack_weights_x3")
+            _lib.check(_gemm(L, ctx.bf16)[0](_ptr(x), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, B, Tin, Ci, Co, k, _stream()),
+                       "ign_clconv_fwd_x6")
         ctx.save_for_backward(x)
         ctx.wd3, ctx.dims, ctx.has_bias = wd3, (B, Tin, Ci, Co, k), bias is not None
         return y
@@ -718,10 +729,15 @@ class ConvCLFn(torch.autograd.Function):
         dx = dw = db = None
         # dy zero-padded by k-1 rows per side: the operand of the input gradient, and the layout the weight gradient reads
         gyp = torch.nn.functional.pad(gy, (0, 0, k - 1, k - 1)) if k > 1 else gy.contiguous()
+        bg = tensor_bound(gyp) if ctx.h3 else None            # (the zero rows do not change the maximum)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(B, Tin, Ci, device=gy.device, dtype=torch.float32)
-            _lib.check(_gemm(L, ctx.bf16)[0](_ptr(gyp), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, B, Tout + 2 * (k - 1), Co, Ci,
-                                             k, _stream()), "ign_clconv_fwd_x6(dx)")
+            if ctx.h3:
+                _lib.check(L.ign_clconv_fwd_h3(_ptr(gyp), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, _ptr(bg), _ptr(ctx.bw), B,
+                                               Tout + 2 * (k - 1), Co, Ci, k, _stream()), "ign_clconv_fwd_h3(dx)")
+            else:
+                _lib.check(_gemm(L, ctx.bf16)[0](_ptr(gyp), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, B, Tout + 2 * (k - 1), Co,
+                                                 Ci, k, _stream()), "ign_clconv_fwd_x6(dx)")
         if ctx.needs_input_grad[1]:
             x6 = k in (2, 3, 5, 8) and LINEAR_WGRAD == "bf16x6"
             if not x6 and k > 1 and Ci % 4 == 0 and LINEAR_WGRAD == "bf16x6":
@@ -736,15 +752,23 @@ class ConvCLFn(torch.autograd.Function):
                                  dtype=torch.float32)
                 fn = L.ign_linear_wgrad_bf16 if ctx.bf16 else L.ign_linear_wgrad_x6
                 for j in range(k):
-                    _lib.check(fn(_ptr(dye), ctypes.c_void_p(x.data_ptr() + 4 * j * Ci), _ptr(dwt[j]), None, _ptr(ws), M - j, Ci, Co,
-                                  _stream()), "ign_linear_wgrad_x6(tap)")
+                    xj = ctypes.c_void_p(x.data_ptr() + 4 * j * Ci)
+                    if ctx.h3:
+                        _lib.check(L.ign_linear_wgrad_h3(_ptr(dye), xj, _ptr(dwt[j]), None, _ptr(ws), _ptr(bg), _ptr(ctx.bx), M - j, Ci, Co,
+                                                         _stream()), "ign_linear_wgrad_h3(tap)")
+                    else:
+                        _lib.check(fn(_ptr(dye), xj, _ptr(dwt[j]), None, _ptr(ws), M - j, Ci, Co, _stream()), "ign_linear_wgrad_x6(tap)")
                 dw = dwt.permute(1, 2, 0).contiguous()
             else:
                 dw = torch.empty(Co, Ci, k, device=gy.device, dtype=torch.float32)
                 wsb, fn, name = ((L.ign_clconv_wgrad_x6_workspace_bytes, _gemm(L, ctx.bf16)[1], "ign_clconv_wgrad_x6") if x6 else
                                  (L.ign_clconv_wgrad_workspace_bytes, L.ign_clconv_wgrad, "ign_clconv_wgrad"))
                 ws = torch.empty(max(1, int(wsb(B, Tin, Ci, Co, k)) // 4), device=gy.device, dtype=torch.float32)
-                _lib.check(fn(_ptr(gyp), k - 1, _ptr(x), None, None, _ptr(dw), _ptr(ws), B, Tin, Ci, Co, k, _stream()), name)
+                if ctx.h3 and x6:
+                    _lib.check(L.ign_clconv_wgrad_h3(_ptr(gyp), k - 1, _ptr(x), None, None, _ptr(dw), _ptr(ws), _ptr(bg), _ptr(ctx.bx), B,
+                                                     Tin, Ci, Co, k, _stream()), "ign_clconv_wgrad_h3")
+                else:
+                    _lib.check(fn(_ptr(gyp), k - 1, _ptr(x), None, None, _ptr(dw), _ptr(ws), B, Tin, Ci, Co, k, _stream()), name)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = gy.sum(dim=(0, 1))
         return dx, dw, db

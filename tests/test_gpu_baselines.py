@@ -307,11 +307,14 @@ def test_linear_on_own_gemm_kernels(shape, Co, bias, wgrad, gmath, scale, monkey
 @pytest.mark.parametrize("B,Tin,Ci,Co,k,bias", [(3, 40, 6, 64, 3, False), (2, 130, 12, 64, 4, True), (4, 27, 64, 128, 3, False),
                                                 (2, 300, 122, 512, 3, False), (1, 17, 5, 8, 7, True), (2, 64, 128, 128, 1, True),
                                                 (3, 33, 7, 12, 11, False)])
-def test_conv1d_cl_against_float64(B, Tin, Ci, Co, k, bias):
-    """ops.conv1d_cl (valid, stride 1, channels-last) forward / input gradient / weight gradient against float64 torch."""
+@pytest.mark.parametrize("gmath", ["f16x3", "bf16x6"])
+def test_conv1d_cl_against_float64(B, Tin, Ci, Co, k, bias, gmath, monkeypatch):
+    """ops.conv1d_cl (valid, stride 1, channels-last) forward / input gradient / weight gradient against float64 torch, on the
+    three-product fp16 kernels (default) and the six-product bf16 kernels."""
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
     from ign_hip import ops
+    monkeypatch.setattr(ops, "GEMM_MATH", gmath)
     g = torch.Generator().manual_seed(B * 1000 + Tin + Ci + Co + k)
     x = torch.randn(B, Tin, Ci, generator=g)
     w = torch.randn(Co, Ci, k, generator=g) / (Ci * k) ** 0.5
