@@ -898,8 +898,7 @@ static int launch_x6w(const ConvX6Args& a, hipStream_t s) {
 
 int ign_clconv_launch_x6t(const ConvX6Args& a, int epi, int V, bool pro, hipStream_t s) {
     // Linear layers with wide outputs: the 128 x 256 tile kernel (see clconv_x6w_kernel)
-    static const bool wide = !(getenv("IGN_X6_WIDE") && atoi(getenv("IGN_X6_WIDE")) == 0);
-    if (wide && a.k == 1 && a.g.N % 256 == 0 && V == 4 && !pro && epi == EPI_BIAS_STATS && !a.g.part &&
+    if (a.k == 1 && a.g.N % 256 == 0 && V == 4 && !pro && epi == EPI_BIAS_STATS && !a.g.part &&
         a.tps * 1 == a.g.mtiles && a.trows == a.g.M)
         return a.nprod == 1 ? launch_x6w<1>(a, s) : a.nprod == 3 ? launch_x6w<2>(a, s) : launch_x6w<3>(a, s);
     if (a.nprod == 1)

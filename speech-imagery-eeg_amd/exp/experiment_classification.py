@@ -198,6 +198,8 @@ class Experiment(object):
         amp = a.amp and self.device.type == 'cuda'
         self.model.train()
         losses = []
+        if self._graph_eligible(amp):
+            return self._train_one_epoch_graphed(epoch, train_step)
         for batch_x, label, padding_mask in self.train_loader:
             train_step += 1
             batch_x, label, padding_mask = self._to_device(batch_x, label, padding_mask)
@@ -231,6 +233,52 @@ class Experiment(object):
                 else:
                     self.optimizer.zero_grad()
             losses.append(loss.detach())
+        return losses, train_step
+
+    # -- `--hipgraph`: the same step as above, captured once per (beta, lr) and replayed per batch ---------------------------------
+    def _graph_eligible(self, amp):
+        a = self.args
+        return (getattr(a, 'hipgraph', False) and self.device.type == 'cuda' and not amp and not self.distributed
+                and a.gradient_accumulation_steps == 1 and a.gradient_clip <= 0 and a.model in ('InterpGN', 'SBM', 'LTS')
+                and isinstance(self.optimizer, FlatAdam))
+
+    def _train_one_epoch_graphed(self, epoch, train_step):
+        from ign_hip.graph import GraphedTrainStep
+        a = self.args
+        beta = float(compute_beta(epoch, a.train_epochs, a.beta_schedule)) if a.model == 'InterpGN' else 0.0
+        lr = float(self.optimizer.param_groups[0]['lr'])
+        if not self.optimizer.capturable:          # the step count moves to the device so that a captured launch sequence stays valid
+            self.optimizer.make_capturable()
+
+        def step_fn(batch_x, label, padding_mask):
+            logits, info = self._forward(batch_x, padding_mask)
+            if a.model == 'InterpGN':
+                loss = ign_ops.ign_loss(info.shapelet_preds, info.dnn_preds, label, beta, reg=info.loss)[0]
+            else:
+                loss = F.cross_entropy(logits, label) + info.loss.mean()
+            ign_ops.backward(loss)
+            self.bucket.allreduce()
+            self.optimizer.step()
+            if a.pos_weight:
+                self.model.step()
+            self.bucket.zero_grad()
+            return loss.detach()
+
+        losses, graphed, key = [], getattr(self, '_graphed', None), (beta, lr, a.batch_size)
+        for batch_x, label, padding_mask in self.train_loader:
+            train_step += 1
+            batch_x, label, padding_mask = self._to_device(batch_x, label, padding_mask)
+            if batch_x.shape[0] != a.batch_size:                  # ragged last batch: eager
+                losses.append(step_fn(batch_x, label, padding_mask).clone())
+                continue
+            if graphed is None or graphed[0] != key:
+                # beta and lr are kernel ARGUMENTS: a new value needs a new capture.  This batch runs eagerly (which also performs
+                # every first-call initialisation outside the capture); the capture that follows records the launch sequence
+                # without executing it, so the parameter trajectory is exactly the eager one
+                losses.append(step_fn(batch_x, label, padding_mask).clone())
+                graphed = self._graphed = (key, GraphedTrainStep(step_fn, (batch_x, label, padding_mask), warmup=0))
+                continue
+            losses.append(graphed[1](batch_x, label, padding_mask).clone())
         return losses, train_step
 
     def train(self):

@@ -147,6 +147,15 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_dev = torch.zeros(1, device=self.flat_param.device, dtype=torch.int32) if capturable else None
         self.bc_dev = torch.zeros(2, device=self.flat_param.device, dtype=torch.float32) if capturable else None
 
+    def make_capturable(self):
+        """Move the step count to the device (ign_adam_step_dev) so that the optimizer step can be captured into a hipGraph;
+        the trajectory is unchanged (same update rule, the count continues where the host count stands)."""
+        if not self.capturable:
+            dev = self.flat_param.device
+            self.step_dev = torch.full((1,), self.step_count, device=dev, dtype=torch.int32)
+            self.bc_dev = torch.zeros(2, device=dev, dtype=torch.float32)
+            self.capturable = True
+
     @torch.no_grad()
     def step(self, closure=None):
         import ctypes

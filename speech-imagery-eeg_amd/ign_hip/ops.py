@@ -11,7 +11,7 @@ import os
 DIST_L1, DIST_MSE, DIST_COS, DIST_PEARSON = 0, 1, 2, 3
 ATTN_MATH = os.environ.get("IGN_ATTN_MATH", "bf16x6")          # "f32": attention core on the fp32-MFMA kernels
 LAYERNORM_MIN_ROWS = 0        # round 1 kept torch below 64k rows; with the row-count-aware grid and the parallel reduce the HIP kernels win everywhere
-LINEAR_WGRAD = os.environ.get("IGN_LINEAR_WGRAD", "bf16x6")   # "f32": weight gradient of ops.linear on the fp32-MFMA TN kernel
+LINEAR_WGRAD = "bf16x6"       # weight gradient of ops.linear on the split kernels; "f32" (set by tests / diag scripts): the fp32-MFMA TN kernel
 GATE_RBF, GATE_LTS = 0x00, 0x10
 
 
@@ -525,7 +525,7 @@ class LinearFn(torch.autograd.Function):
     GEMM kernels instead of hipBLASLt: a Linear layer is the k = 1 case of the channels-last convolution, so forward and the
     input gradient run on the split-bf16 kernel (fp32 accuracy on the bf16 matrix cores, ign_clconv_fwd_x6 with the weight
     resp. its transpose), and so does the weight gradient (ign_clconv_wgrad_x6, k = 1: 128 x 128 tiles, transposing LDS reads);
-    IGN_LINEAR_WGRAD=f32 keeps it on the fp32-MFMA TN kernel (ign_clconv_wgrad)."""
+    `LINEAR_WGRAD = "f32"` (tests) keeps it on the fp32-MFMA TN kernel (ign_clconv_wgrad)."""
 
     @staticmethod
     def forward(ctx, x, w, bias):

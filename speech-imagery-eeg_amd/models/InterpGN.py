@@ -68,7 +68,7 @@ class InterpGN(nn.Module):
         main = torch.cuda.current_stream(x.device)
         side = _SIDE_STREAMS.get(x.device)
         if side is None:
-            side = _SIDE_STREAMS[x.device] = torch.cuda.Stream(x.device, priority=int(os.environ.get('IGN_SIDE_PRIO', '-1')))
+            side = _SIDE_STREAMS[x.device] = torch.cuda.Stream(x.device, priority=-1)
         side.wait_stream(main)                      # x and the parameters are ready
         with torch.cuda.stream(side):
             deep_out = self.deep_model(x, x_mark_enc, x_dec, x_mark_dec, mask)

@@ -12,7 +12,6 @@ in_proj_weight`` ... ``classifier.weight``).  The encoder layers are evaluated e
 attention core can run on the fused fp32-MFMA kernel instead of ``nn.MultiheadAttention``'s materialised scores.
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -58,14 +57,6 @@ class EEGcnn(nn.Module):
         self.block2_elu = nn.ELU()
         self.block2_pool = nn.AvgPool2d((1, P2))
         self.block2_drop = nn.Dropout(p=dropoutRate)
-
-    @staticmethod
-    def _bn_apply(bn, h):
-        """BatchNorm over (B, T) per channel of a (B, C, T) tensor with the BatchNorm2d module's parameters/buffers."""
-        if bn.training and bn.track_running_stats:
-            bn.num_batches_tracked.add_(1)
-        return F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training or not bn.track_running_stats,
-                            bn.momentum, bn.eps)
 
     @staticmethod
     def _shifted_sums(x, k, pl):
@@ -177,19 +168,11 @@ class EEGcnn(nn.Module):
         g = ops.bn_elu_pool(g, self.block2_bn, self.block2_pool.kernel_size[1])
         return self.block2_drop(g)
 
-    def _forward_reference_ops(self, x):
-        x = x.unsqueeze(1)                                           # (B,1,C,T)
-        x = self.block1_bn1(self.block1_conv1(x))
-        x = self.block1_bn2(self.block1_depthwise(x))
-        x = self.block1_drop(self.block1_pool(self.block1_elu(x)))
-        x = self.block2_conv2(self.block2_conv1(x))
-        x = self.block2_drop(self.block2_pool(self.block2_elu(self.block2_bn(x))))
-        return x.squeeze(2)                                          # (B,F2,T')
 
-
-# BatchNorm-1 batch variance: "gram" = quadratic form over the input's window Gram matrix (ops.autocorr); "conv" = brute-force
-# pass over the un-stored convolution (ign_conv1_sumsq_*: 3.1e10 FMA forward, 6.2e10 backward at the benchmark shape)
-_BN1_VARIANCE = os.environ.get("IGN_EEG_BN1", "gram")
+# BatchNorm-1 batch variance: "gram" = quadratic form over the input's window Gram matrix (ops.autocorr); "conv" (kernel lengths
+# beyond 128 or rows shorter than the kernel; tests) = brute-force pass over the un-stored convolution (ign_conv1_sumsq_*:
+# 3.1e10 FMA forward, 6.2e10 backward at the benchmark shape)
+_BN1_VARIANCE = "gram"
 
 
 def _encoder_layer_forward(layer, x, n_heads):

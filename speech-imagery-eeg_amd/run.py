@@ -36,6 +36,10 @@ def build_parser():
     p.add_argument("--data", type=str, default="UEA", choices=['EEG', 'EEG3', 'UEA', 'SYNTH'])
     p.add_argument("--data_root", type=str, default="./data/UEA_multivariate")
     p.add_argument("--json_path", type=str, default="./json/textmaps.json")
+    p.add_argument("--hipgraph", action="store_true",
+                   help="replay the training step (forward, fused loss, backward, Adam) as one captured hipGraph -- for the "
+                        "launch-bound regime of small batches (run_uea.sh: --batch_size 32): one host call per step instead of "
+                        "~45 launches.  Ignored (eager) with gradient accumulation / clipping, bf16 autocast or several ranks")
     p.add_argument("--synthetic", type=str, default=None, help="SYNTH provider: n,C,T,classes (default 8192,122,1000,3)")
     p.add_argument("--target_channels", type=int, default=122)
     p.add_argument("--target_timepoints", type=int, default=1651)

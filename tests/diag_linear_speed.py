@@ -32,7 +32,7 @@ for (Ci, Co) in [(512, 512), (512, 2048), (2048, 512), (64, 512)]:
     print(f"wgrad Ci={Ci} Co={Co}: f32 {t32:.3f} ms ({flops/t32/1e9:.0f} TFLOP/s, err {e32:.1e})  bf16x6 {t6:.3f} ms "
           f"({flops/t6/1e9:.0f} TFLOP/s-equiv, err {e6:.1e})", flush=True)
 
-# forward GEMM (ign_clconv_fwd_x6, k = 1): 128x128 tiles (IGN_X6_WIDE=0) vs the 128x256 eight-wave kernel
+# forward GEMM (ign_clconv_fwd_x6, k = 1) on the 128x256 eight-wave kernel (the 128x128 A/B of round 1 is in DESIGN 4.6)
 for (Ci, Co) in [(512, 512), (512, 2048), (2048, 512), (512, 1536)]:
     x = torch.randn(M, Ci, device=dev); w = torch.randn(Co, Ci, device=dev) / Ci ** 0.5; b = torch.randn(Co, device=dev)
     wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, 1)), device=dev, dtype=torch.bfloat16)
@@ -41,4 +41,4 @@ for (Ci, Co) in [(512, 512), (512, 2048), (2048, 512), (512, 1536)]:
     t = timeit(lambda: _lib.check(L.ign_clconv_fwd_x6(p(x), p(wt3), p(b), None, None, p(y), None, 1, M, Ci, Co, 1, s()), "f"))
     ref = x[:4096].double() @ w.double().t() + b.double()
     err = float((y[:4096] - ref).abs().max() / ref.abs().max())
-    print(f"fwd Ci={Ci} Co={Co} (IGN_X6_WIDE={os.environ.get('IGN_X6_WIDE', '1')}): {t:.3f} ms ({2.0*M*Ci*Co/t/1e9:.0f} TFLOP/s-equiv, err {err:.1e})", flush=True)
+    print(f"fwd Ci={Ci} Co={Co}: {t:.3f} ms ({2.0*M*Ci*Co/t/1e9:.0f} TFLOP/s-equiv, err {err:.1e})", flush=True)

@@ -212,6 +212,18 @@ def test_dwconv1d_vs_torch(B, C, T, k):
     assert _rel(y, yr) < 1e-5 and _rel(x.grad, xd.grad) < 1e-5 and _rel(w.grad, wd.grad) < 2e-5
 
 
+def _eegcnn_reference_ops(m, x):
+    """IGN/model/eegcnn.py:85-108 layer by layer on the module's own nn layers (torch / library kernels): the op-by-op evaluation
+    the HIP restructuring of models/eegcnn.py is checked against."""
+    x = x.unsqueeze(1)                                           # (B,1,C,T)
+    x = m.block1_bn1(m.block1_conv1(x))
+    x = m.block1_bn2(m.block1_depthwise(x))
+    x = m.block1_drop(m.block1_pool(m.block1_elu(x)))
+    x = m.block2_conv2(m.block2_conv1(x))
+    x = m.block2_drop(m.block2_pool(m.block2_elu(m.block2_bn(x))))
+    return x.squeeze(2)                                          # (B,F2,T')
+
+
 def test_eegcnn_block_matches_reference_ops_in_eval_and_train():
     """The algebraic restructuring of block 1/2 against the layer-by-layer evaluation of the same module (torch ops),
     including BatchNorm running statistics."""
@@ -229,7 +241,7 @@ def test_eegcnn_block_matches_reference_ops_in_eval_and_train():
     for mode in (True, False):
         m.train(mode); ref.train(mode)
         a = m(x)
-        b = ref._forward_reference_ops(x)
+        b = _eegcnn_reference_ops(ref, x)
         parity(f"out train={mode}", a, b, kind="scale", ref_is="same module, layer-by-layer torch ops (fp32, GPU)")
         if mode:
             ga = torch.autograd.grad(a.square().sum(), [p for p in m.parameters()], allow_unused=True)
@@ -258,7 +270,7 @@ def test_eegcnn_train_step_at_short_rows_with_many_samples(T, k1):
     ref = copy.deepcopy(m).double().cpu()          # float64 on the host: the fp32 library convolutions are themselves 3e-4 off here
     x = torch.randn(48, 9, T, device=dev) * 1.5 + 0.2
     m.train(); ref.train()
-    a, b = m(x), ref._forward_reference_ops(x.double().cpu())
+    a, b = m(x), _eegcnn_reference_ops(ref, x.double().cpu())
     assert torch.isfinite(a).all()
     parity(f"short rows T={T} k={k1}: out", a, b, kind="scale", ref_is="same module, layer-by-layer torch ops (float64, CPU)")
     ga = torch.autograd.grad(a.square().sum(), list(m.parameters()), allow_unused=True)

@@ -201,3 +201,40 @@ def test_harness_default_bf16_autocast_mode_trains(tmp_path, monkeypatch):
     ckpt = torch.load(os.path.join(e.checkpoint_dir, "checkpoint.pth"), map_location="cpu", weights_only=True)
     e.model.load_state_dict(ckpt)
     assert e.test() is not None
+
+
+def test_hipgraph_harness_run_equals_the_eager_run(tmp_path, monkeypatch):
+    """`run.py --hipgraph`: Experiment.train replays the step as one captured hipGraph (first batch of every (beta, lr) eager, then
+    capture, then replays; ragged last batch eager).  Same data, same seeds: the per-epoch validation numbers and the final weights
+    must equal the eager run's (1e-5: the captured step is the same launch sequence)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import speech_imagery_eeg_amd  # noqa
+    import run
+    from exp.experiment_classification import Experiment
+    monkeypatch.chdir(tmp_path)
+    outs = {}
+    for mode in ("eager", "graph"):
+        argv = ["--model", "InterpGN", "--dnn_type", "FCN", "--data", "SYNTH", "--synthetic", "104,6,100,4", "--dataset", "g" + mode,
+                "--batch_size", "32", "--amp", "--train_epochs", "3", "--num_workers", "0", "--seed", "0", "--beta_schedule", "cosine",
+                "--lr_decay", "--patience", "10"] + (["--hipgraph"] if mode == "graph" else [])
+        a = run.get_args(argv)
+        run.set_seed(0)
+        e = Experiment(a)
+        vals, orig = [], e.validation
+
+        def rec(orig=orig, vals=vals):
+            r = orig()
+            vals.append(r)
+            return r
+        e.validation = rec
+        torch.manual_seed(123)
+        e.train()
+        outs[mode] = (vals, {k: v.detach().float().cpu().clone() for k, v in e.model.state_dict().items()})
+        if mode == "graph":
+            assert getattr(e, "_graphed", None) is not None and e.optimizer.capturable      # the graph path really ran
+    for (la, aa), (lb, ab) in zip(*[o[0] for o in outs.values()]):
+        assert abs(la - lb) <= 1e-5 * max(1.0, abs(la)) and aa == ab
+    for k, v in outs["eager"][1].items():
+        w = outs["graph"][1][k]
+        assert float((v - w).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), k
