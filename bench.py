@@ -385,14 +385,18 @@ def attention_roofline(lib_timing, steps, Bh, Lq, E, layers, attn_math):
     ms_b = (lib_timing["attn_bwd_dkdv"][0] + lib_timing["attn_bwd_dq"][0]) / steps
     tf_f = f_fwd / (ms_f * 1e-3) / 1e12 if ms_f > 0 else 0.0
     tf_b = 2.5 * f_fwd / (ms_b * 1e-3) / 1e12 if ms_b > 0 else 0.0
-    if attn_math == "bf16x6" and E <= 64:
+    if attn_math in ("bf16x6", "f16x3") and E <= 64:
         tiles = Bh * ((Lq + 31) // 32) ** 2 * layers
-        ex_f, ex_b = 48.0 * MFMA_32x32x16_FLOP * tiles * (E / 64.0), 192.0 * MFMA_32x32x16_FLOP * tiles * (E / 64.0)
+        half = 0.5 if attn_math == "f16x3" else 1.0      # three products per element pair instead of six
+        ex_f, ex_b = 48.0 * half * MFMA_32x32x16_FLOP * tiles * (E / 64.0), 192.0 * half * MFMA_32x32x16_FLOP * tiles * (E / 64.0)
         ex_tf_f = ex_f / (ms_f * 1e-3) / 1e12 if ms_f > 0 else 0.0
         ex_tf_b = ex_b / (ms_b * 1e-3) / 1e12 if ms_b > 0 else 0.0
         return {"bound": "mfma", "kernel": "attn_bwd_x6 (dq + dk + dv kernels)", "achieved": ex_tf_b, "peak": PEAK_BF16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": ex_tf_b / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "ms_per_step": ms_b,
-                "pricing": "executed bf16 MFMA flops (split-bf16: fp32 operands as 3 bf16 terms, 6 products) / dense bf16 peak",
+                "arithmetic": attn_math,
+                "pricing": "executed 16-bit MFMA flops / dense bf16 (= fp16) peak; " +
+                           ("f16x3: fp32 operands scaled by a power of two and split into 2 fp16 terms, 3 products"
+                            if attn_math == "f16x3" else "bf16x6: fp32 operands as 3 bf16 terms, 6 products"),
                 "algorithmic_fp32_tflops": tf_b,
                 "fwd_kernel": {"kernel": "attn_fwd_x6", "achieved": ex_tf_f, "frac": ex_tf_f / PEAK_BF16_MFMA_TFLOPS,
                                "algorithmic_fp32_tflops": tf_f, "ms_per_step": ms_f}}
@@ -402,8 +406,9 @@ def attention_roofline(lib_timing, steps, Bh, Lq, E, layers, attn_math):
             "fwd_kernel": {"kernel": "attn_fwd_kernel", "achieved": tf_f, "frac": tf_f / PEAK_FP32_MFMA_TFLOPS, "ms_per_step": ms_f}}
 
 
-def gemm_groups(lib, steps, flops_by_label, x6):
-    """ms/step and pricing of the GEMM-shaped kernel groups (timer label -> algorithmic flops per step)."""
+def gemm_groups(lib, steps, flops_by_label, nprod):
+    """ms/step and pricing of the GEMM-shaped kernel groups (timer label -> algorithmic flops per step).  nprod = 16-bit MFMA
+    products executed per algorithmic fp32 product (6: three bf16 planes; 3: two fp16 planes; 1: bf16 autocast; None: fp32 MFMA)."""
     out = {}
     for lab, fl in flops_by_label.items():
         ms, n = lib.timing_read(lab)
@@ -411,9 +416,10 @@ def gemm_groups(lib, steps, flops_by_label, x6):
         if ms <= 0:
             continue
         tf = fl / (ms * 1e-3) / 1e12
-        if x6:
+        if nprod:
             out[lab] = {"ms_per_step": ms, "launches_per_step": n // steps, "algorithmic_fp32_tflops": tf,
-                        "executed_bf16_tflops": 6.0 * tf, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": 6.0 * tf / PEAK_BF16_MFMA_TFLOPS}
+                        "products_per_fp32_product": nprod, "executed_16bit_tflops": nprod * tf, "peak": PEAK_BF16_MFMA_TFLOPS,
+                        "frac": nprod * tf / PEAK_BF16_MFMA_TFLOPS}
         else:
             out[lab] = {"ms_per_step": ms, "launches_per_step": n // steps, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
                         "frac": tf / PEAK_FP32_MFMA_TFLOPS}
@@ -434,12 +440,14 @@ def baseline_result(b, lib, steps, dt, last, cpu_sample):
     north_star names for config 4), the GEMM / convolution kernel groups, and the CPU oracle of the same model."""
     from ign_hip import ops as ign_ops
     cfg, B, T, config = b.cfg, b.B, b.T, b.config
-    x6 = ign_ops.LINEAR_WGRAD == "bf16x6" and not b.amp
+    h3 = ign_ops.GEMM_MATH == "f16x3" and not b.amp
+    x6 = (1.0 if b.amp else 3.0 if h3 else 6.0) if ign_ops.LINEAR_WGRAD == "bf16x6" else None
+    amath = "f16x3" if (h3 and ign_ops.ATTN_MATH == "bf16x6") else ign_ops.ATTN_MATH
     timing = {k: lib.timing_read(k) for k in ("attn_fwd", "attn_bwd_dkdv", "attn_bwd_dq")}
     M = float(B * T)
     if config == "transformer":
         desc = "Transformer-encoder baseline (d_model 512, 8 heads, d_ff 2048, 2 layers)"
-        roof = attention_roofline(timing, steps, B * cfg.n_heads, T, cfg.d_model // cfg.n_heads, cfg.e_layers, ign_ops.ATTN_MATH)
+        roof = attention_roofline(timing, steps, B * cfg.n_heads, T, cfg.d_model // cfg.n_heads, cfg.e_layers, amath)
         lin = 2.0 * M * (4 * 512 * 512 + 2 * 512 * 2048) * cfg.e_layers        # Q,K,V,O + the two 1x1-conv FFN layers
         emb = 2.0 * M * 512 * 122 * 3                                            # k=3 circular token embedding
         # timer label "clconv_fwd" = every launch of ign_clconv_fwd_x6: the Linear / embedding FORWARD GEMMs and the Linear
@@ -447,11 +455,11 @@ def baseline_result(b, lib, steps, dt, last, cpu_sample):
         groups = gemm_groups(lib, steps, {"clconv_fwd": lin + emb + lin, "clconv_wgrad": lin + emb}, x6)
         if "clconv_fwd" in groups:
             groups["clconv_fwd"]["what"] = "Linear + token-embedding forward GEMMs and the Linear input-gradient GEMMs (one kernel)"
-        others = other_kernels(lib, steps, ("layernorm_fwd", "layernorm_bwd", "head_fwd", "head_bwd_xw", "head_bwd_x", "head_bwd_w", "adam"))
+        others = other_kernels(lib, steps, ("layernorm_fwd", "layernorm_bwd", "head_fwd", "head_bwd_xw", "head_bwd_x", "head_bwd_w", "absmax", "adam"))
     else:
         desc = "EEG-CNN baseline (CNN 8x8 filters k=125/25 + 2-layer encoder d_model 512, 8 heads, d_ff 256)"
         S = T // 10
-        roof = attention_roofline(timing, steps, B * 8, S, cfg.d_model // 8, 2, ign_ops.ATTN_MATH)
+        roof = attention_roofline(timing, steps, B * 8, S, cfg.d_model // 8, 2, amath)
         Me = float(B * S)
         lin = 2.0 * Me * (64 * 512 + 2 * (4 * 512 * 512 + 2 * 512 * 256))       # projection + 2 x (in_proj, out_proj, FFN)
         groups = gemm_groups(lib, steps, {"clconv_fwd": lin + lin, "clconv_wgrad": lin}, x6)      # forward + input gradient (see above)
@@ -459,7 +467,7 @@ def baseline_result(b, lib, steps, dt, last, cpu_sample):
             groups["clconv_fwd"]["what"] = "Linear forward GEMMs and the Linear input-gradient GEMMs (one kernel)"
         others = other_kernels(lib, steps, ("chan_contract", "chan_contract_bwd_w", "dwconv1d", "dwconv1d_bwd_w", "chan_stats",
                                             "affine_elu_pool", "bn_elu_pool_bwd_sums", "bn_elu_pool_bwd_apply", "autocorr",
-                                            "conv1_sumsq_fwd", "conv1_sumsq_bwd", "layernorm_fwd", "layernorm_bwd", "adam"))
+                                            "conv1_sumsq_fwd", "conv1_sumsq_bwd", "layernorm_fwd", "layernorm_bwd", "absmax", "adam"))
         # config 3's evidence is HBM GB/s of the conv-kernel path: algorithmic bytes of the CNN block per step =
         # forward x 125 MB + u / v 4 x 65.5 MB + h 32.8 + q / g 3 x 32.8 + out 6.6; backward about twice that
         cnn_labels = ("chan_contract", "chan_contract_bwd_w", "dwconv1d", "dwconv1d_bwd_w", "chan_stats", "affine_elu_pool",
@@ -474,7 +482,8 @@ def baseline_result(b, lib, steps, dt, last, cpu_sample):
     res = {"metric": f"epochs/sec (B=256, C=122, T=1000) {config} baseline 3-class",
            "value": (steps * B * b.world / N_TRAIN) / dt, "unit": "epochs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
            "workload": f"Synthetic CHISCO-shape EEG (122ch x 1000, 3-class) {desc}, Adam lr 5e-3, fp32", "final_loss": float(last),
-           "roofline": roof, "gemm_kernels": groups, "other_kernels": others}
+           "gemm_math": ("bf16 autocast (one product)" if b.amp else ign_ops.GEMM_MATH), "roofline": roof, "gemm_kernels": groups,
+           "other_kernels": others}
     if b.world == 1 and cpu_sample > 0 and b.rank == 0:
         log(f"cpu baseline ({config}) ...")
         res["cpu_baseline"] = cpu_baseline_baseline(config, cfg, b.state0, 16 if config == "transformer" else 64, host_cores())

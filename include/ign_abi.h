@@ -409,6 +409,11 @@ int ign_clconv_pack_weights_h2_multi(int n, const float* const* w_oik, void* con
 int ign_clconv_fwd_h3(const float* x, const void* wt_h2, const float* bias, const float* pro_a, const float* pro_b, float* y,
                       float* stat_part, const float* bound_in, const float* bound_w, int B, int Tin, int Ci, int Co, int k,
                       void* stream);
+/* the same, additionally max'ing max |y| into the device float amax_out (nullable; the caller zeroes it): the magnitude bound of
+ * the output for the next GEMM that consumes it -- taken in the epilogue instead of by a pass over the tensor (ign_absmax)     */
+int ign_clconv_fwd_h3_amax(const float* x, const void* wt_h2, const float* bias, const float* pro_a, const float* pro_b, float* y,
+                           float* stat_part, const float* bound_in, const float* bound_w, float* amax_out, int B, int Tin, int Ci,
+                           int Co, int k, void* stream);
 int ign_clconv_dgrad_h3(const float* dyp, const void* wt_h2_dgrad, const float* y_in, const float* a_in, const float* b_in,
                         const float* mean_in, const float* invstd_in, float* g_in, float* stat_part, const float* bound_dy,
                         const float* bound_w, int B, int Tin, int Ci, int Co, int k, void* stream);

@@ -4,11 +4,7 @@
 #include "ign_clconv.h"
 
 // maxima of non-negative floats as unsigned integers on their bit patterns (see 'operand bounds' below)
-__device__ __forceinline__ void atomic_absmax(float* slot, float v) {                 // v >= 0
-    unsigned int* u = reinterpret_cast<unsigned int*>(slot);
-    const unsigned int b = __float_as_uint(v);
-    if (b > __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(u, b);
-}
+__device__ __forceinline__ void atomic_absmax(float* slot, float v) { ign_atomic_absmax(slot, v); }      // v >= 0
 __device__ __forceinline__ float block_max_1024(float v, float* sh) {                // result valid in thread 0
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -57,7 +57,15 @@ struct GemmNTArgs {
     const float* ey; const float* ea; const float* eb; const float* emean; const float* einv;
     int mtiles, ntiles;
     const unsigned short* B3; int Kp;          // split-bf16 kernels: Bt as 3 bf16 planes (3, N, Kp), Kp = K rounded up to 8
+    float* amax_out;                           // nullable: max |C| is max'ed into this device float (integer atomicMax on the bits)
 };
+
+// max of non-negative floats as unsigned integers on their bit patterns: exact, order-independent (bitwise reproducible)
+__device__ __forceinline__ void ign_atomic_absmax(float* slot, float v) {
+    unsigned int* u = reinterpret_cast<unsigned int*>(slot);
+    const unsigned int b = __float_as_uint(v);
+    if (b > __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(u, b);
+}
 
 // ---- epilogue shared by the fp32 and the split-bf16 kernels.  Lane (l31, h) of accumulator (i, j) holds column
 // n = n0 + wn*64 + j*32 + l31 and the 16 rows m0 + wm*64 + i*32 + acc_row16(r, h).  `red` is >= 512 floats of LDS that no
@@ -71,6 +79,7 @@ __device__ __forceinline__ void nt_epilogue_body(const GemmNTArgs& a, const f32x
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave & 1, wn = wave >> 1;
+    float amax = 0.f;                          // SC kernels only: magnitude of the output, for the GEMM that consumes it
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + l31;
@@ -104,8 +113,14 @@ __device__ __forceinline__ void nt_epilogue_body(const GemmNTArgs& a, const f32x
                     if (ok) { s1[j] += v; s2[j] = fmaf(v, (yv[r] - em) * ei, s2[j]); }
                 }
                 if (ok) a.C[(long long)m * a.N + n] = v;
+                if (SC && ok) amax = fmaxf(amax, fabsf(v));
             }
         }
+    }
+    if (SC && a.amax_out) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if (lane == 0) ign_atomic_absmax(a.amax_out, amax);
     }
 }
 

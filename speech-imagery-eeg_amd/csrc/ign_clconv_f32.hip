@@ -381,7 +381,7 @@ extern "C" int ign_clconv_pack_weights(const float* w_oik, float* wt_fwd, float*
 // x6: 0 = fp32 MFMA, 6 = split bf16 (six products), 1 = operands rounded to bf16 (one product)
 static int clconv_fwd_impl(const char* who, int x6, const float* x, const void* wt, const float* bias, const float* pro_a,
                            const float* pro_b, float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream,
-                           const float* bound_a = nullptr, const float* bound_w = nullptr) {
+                           const float* bound_a = nullptr, const float* bound_w = nullptr, float* amax_out = nullptr) {
     const int Tout = Tin - k + 1;
     if (!x || !wt || !y || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || ((pro_a == nullptr) != (pro_b == nullptr))) {
         ign_set_error("%s: bad argument (B=%d Tin=%d Ci=%d Co=%d k=%d)", who, B, Tin, Ci, Co, k);
@@ -393,7 +393,7 @@ static int clconv_fwd_impl(const char* who, int x6, const float* x, const void* 
     a.A = x; a.am = RowMap{Tout, 0, Ci, (long long)Tin * Ci}; a.K = k * Ci;
     a.Bt = x6 ? nullptr : (const float*)wt; a.ldb = k * Ci; a.C = y; a.M = (int)M; a.N = Co; a.bias = bias;
     a.B3 = x6 ? (const unsigned short*)wt : nullptr; a.Kp = 0;
-    a.pro_a = pro_a; a.pro_b = pro_b; a.pro_c = Ci; a.part = stat_part;
+    a.pro_a = pro_a; a.pro_b = pro_b; a.pro_c = Ci; a.part = stat_part; a.amax_out = amax_out;
     a.mtiles = (int)((M + TM - 1) / TM); a.ntiles = (Co + TN - 1) / TN;
     IgnScopedTimer tm("clconv_fwd", (hipStream_t)stream);
     if (x6) {
@@ -426,9 +426,15 @@ extern "C" int ign_clconv_fwd_bf16(const float* x, const void* wt3, const float*
 extern "C" int ign_clconv_fwd_h3(const float* x, const void* wt_h2, const float* bias, const float* pro_a, const float* pro_b,
                                  float* y, float* stat_part, const float* bound_in, const float* bound_w, int B, int Tin, int Ci,
                                  int Co, int k, void* stream) {
+    return ign_clconv_fwd_h3_amax(x, wt_h2, bias, pro_a, pro_b, y, stat_part, bound_in, bound_w, nullptr, B, Tin, Ci, Co, k, stream);
+}
+
+extern "C" int ign_clconv_fwd_h3_amax(const float* x, const void* wt_h2, const float* bias, const float* pro_a, const float* pro_b,
+                                      float* y, float* stat_part, const float* bound_in, const float* bound_w, float* amax_out, int B,
+                                      int Tin, int Ci, int Co, int k, void* stream) {
     if (!bound_in || !bound_w) { ign_set_error("ign_clconv_fwd_h3: null operand bound"); return IGN_E_ARG; }
     return clconv_fwd_impl("ign_clconv_fwd_h3", 3, x, wt_h2, bias, pro_a, pro_b, y, stat_part, B, Tin, Ci, Co, k, stream, bound_in,
-                           bound_w);
+                           bound_w, amax_out);
 }
 
 static int clconv_dgrad_impl(const char* who, int x6, const float* dyp, const void* wt_dgrad, const float* y_in, const float* a_in,

@@ -354,7 +354,10 @@ class AttentionFn(torch.autograd.Function):
 
 
 def attention(q, k, v, scale):
-    return AttentionFn.apply(q, k, v, scale)
+    out = AttentionFn.apply(q, k, v, scale)
+    if GEMM_MATH == "f16x3" and ATTN_MATH == "bf16x6" and not torch.is_autocast_enabled() and q.shape[-1] <= 64:
+        set_bound(out, tensor_bound(v))        # a row of the output is a convex combination of rows of v (cached: no extra pass)
+    return out
 
 
 class PackedAttentionFn(torch.autograd.Function):
@@ -416,7 +419,10 @@ def attention_packed(qkv, scale):
     E = qkv.shape[-1]
     if ATTN_MATH != "bf16x6" or E > 64:
         return attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], scale)
-    return PackedAttentionFn.apply(qkv, scale)
+    out = PackedAttentionFn.apply(qkv, scale)
+    if GEMM_MATH == "f16x3" and not torch.is_autocast_enabled():
+        set_bound(out, tensor_bound(qkv))      # convex combinations of rows of v: bounded by the packed tensor's bound (cached)
+    return out
 
 
 class HeadLinearFn(torch.autograd.Function):
@@ -492,6 +498,11 @@ def tensor_bound(t):
     cached = getattr(t, "_ign_bound", None)
     if cached is not None and cached[1] == t._version and cached[2] == t.data_ptr():
         return cached[0]
+    base = getattr(t, "_base", None)
+    if base is not None and base.numel() == t.numel():       # a reshaped view of a tensor whose producer attached a bound
+        cb = getattr(base, "_ign_bound", None)
+        if cb is not None and cb[1] == base._version and cb[2] == base.data_ptr():
+            return cb[0]
     if not t.is_contiguous():
         base = getattr(t, "_base", None)
         if base is not None and base.is_contiguous() and base.dtype == t.dtype and base.numel() <= 4 * t.numel():
@@ -510,6 +521,15 @@ def set_bound(t, slot):
     """Attach a known magnitude bound (one-element device tensor) to `t`; see tensor_bound."""
     t._ign_bound = (slot, t._version, t.data_ptr())
     return t
+
+
+def keep_bound(out, src, factor=1.0):
+    """`out` = f(src) element-wise with |f(u)| <= factor |u| (ReLU, GELU: factor 1): `out` inherits src's magnitude bound, if
+    src carries one, instead of being scanned when a dense layer consumes it."""
+    cb = getattr(src, "_ign_bound", None)
+    if cb is not None and cb[1] == src._version and cb[2] == src.data_ptr() and factor == 1.0:
+        set_bound(out, cb[0])
+    return out
 
 
 def _gemm(L, bf16):
@@ -539,7 +559,7 @@ class LinearFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, 1)), device=dev, dtype=torch.bfloat16)
         wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, 1)), device=dev, dtype=torch.bfloat16) if need_dx else None
-        y = torch.empty(M, Co, device=dev, dtype=torch.float32)
+        y = torch.empty(*x.shape[:-1], Co, device=dev, dtype=torch.float32)    # final shape (not a view: its reshaped views find its bound)
         ctx.bf16 = torch.is_autocast_enabled()          # autocast region: operands rounded to bf16, one product (see _gemm)
         ctx.h3 = (not ctx.bf16) and GEMM_MATH == "f16x3"
         ctx.bx = ctx.bw = None
@@ -551,18 +571,22 @@ class LinearFn(torch.autograd.Function):
             _lib.check(L.ign_clconv_pack_weights_h2_multi(1, v1(w.data_ptr()), v1(wt3.data_ptr()), v1(wd3.data_ptr()) if need_dx else None,
                                                           i1(Co), i1(Ci), i1(1), None, v1(ctx.bw.data_ptr()), _stream()),
                        "ign_clconv_pack_weights_h2_multi")
-            _lib.check(L.ign_clconv_fwd_h3(_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, _ptr(ctx.bx), _ptr(ctx.bw), 1, M, Ci,
-                                           Co, 1, _stream()), "ign_clconv_fwd_h3")
+            # the epilogue also takes max |y|: the operand bound of whatever dense layer / attention core consumes y
+            yb = _new_slot(dev)
+            _lib.check(L.ign_clconv_fwd_h3_amax(_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, _ptr(ctx.bx), _ptr(ctx.bw),
+                                                _ptr(yb), 1, M, Ci, Co, 1, _stream()), "ign_clconv_fwd_h3")
         else:
+            yb = None
             _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt3), _ptr(wd3), Co, Ci, 1, _stream()), "ign_clconv_pack_weights_x3")
             _lib.check(_gemm(L, ctx.bf16)[0](_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, 1, M, Ci, Co, 1, _stream()),
                        "ign_clconv_fwd_x6")
         ctx.save_for_backward(x2)
         ctx.wd3, ctx.dims, ctx.has_bias, ctx.xshape = wd3, (M, Ci, Co), bias is not None, x.shape
-        return y.view(*x.shape[:-1], Co)
+        ctx.mark_non_differentiable(*([yb] if yb is not None else []))
+        return y, yb
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gyb=None):
         L = _lib.lib()
         (x2,) = ctx.saved_tensors
         M, Ci, Co = ctx.dims
@@ -613,7 +637,10 @@ def linear(x, w, bias=None):
             or w.shape[0] % 4 or x.numel() == 0 or x.shape[-1] != w.shape[1]
             or x.numel() // x.shape[-1] >= (1 << 30)):
         return torch.nn.functional.linear(x, w, bias)
-    return LinearFn.apply(x, w, bias)
+    y, yb = LinearFn.apply(x, w, bias)
+    if yb is not None:
+        set_bound(y, yb)
+    return y
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -23,8 +23,10 @@ class EncoderLayer(nn.Module):
         new_x, attn = self.attention(x, x, x, attn_mask=attn_mask, tau=tau, delta=delta)
         x = ops.layer_norm(x + self.dropout(new_x), self.norm1)
         # the k=1 convolutions are plain GEMMs over (B*T, d): apply them without the two transposes
-        y = ops.linear(x, self.conv1.weight.squeeze(-1), self.conv1.bias)
-        y = self.dropout(self.activation(y))
+        u = ops.linear(x, self.conv1.weight.squeeze(-1), self.conv1.bias)
+        y = ops.keep_bound(self.activation(u), u)            # |relu(u)|, |gelu(u)| <= |u|: the magnitude bound of u carries over
+        if self.training and self.dropout.p > 0:
+            y = self.dropout(y)
         y = self.dropout(ops.linear(y, self.conv2.weight.squeeze(-1), self.conv2.bias))
         return ops.layer_norm(x + y, self.norm2), attn
 

@@ -183,8 +183,11 @@ def _encoder_layer_forward(layer, x, n_heads):
     o = ops.attention_packed(qkv, 1.0 / math.sqrt(d // n_heads))      # gradients land in one packed buffer
     a = ops.linear(o.reshape(B, S, d), sa.out_proj.weight, sa.out_proj.bias)
     x = ops.layer_norm(x + layer.dropout1(a), layer.norm1)
-    ff = ops.linear(layer.dropout(F.relu(ops.linear(x, layer.linear1.weight, layer.linear1.bias))), layer.linear2.weight,
-                    layer.linear2.bias)
+    u = ops.linear(x, layer.linear1.weight, layer.linear1.bias)
+    hdn = ops.keep_bound(F.relu(u), u)                              # |relu(u)| <= |u|: the magnitude bound carries over
+    if layer.training and layer.dropout.p > 0:
+        hdn = layer.dropout(hdn)
+    ff = ops.linear(hdn, layer.linear2.weight, layer.linear2.bias)
     return ops.layer_norm(x + layer.dropout2(ff), layer.norm2)
 
 

@@ -76,24 +76,33 @@ def test_one_rank_rccl_rendezvous_emits_the_collective_fields():
 
 
 def test_committed_bench_line_carries_the_contract_fields():
-    """The driver-facing JSON line (profiles/r2k_bench_line.json = the default `python bench.py` run of the round-end
-    measurement pass): metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline /
-    dtype / data / config.workload, the roofline object of the dominant kernel, the CPU baseline, and configs 3 / 4."""
-    line = json.load(open(os.path.join(ROOT, "profiles", "r2k_bench_line.json")))
+    """The driver-facing JSON line (profiles/r3_bench_line.json = the default `python bench.py` run of the round-end measurement
+    pass, profiles/collect_round.sh): metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling /
+    vs_baseline / dtype / data / config.workload, the roofline object of the dominant kernel, the CPU baseline, configs 3 / 4 --
+    and the round-3 additions: config.data says the inputs are resident, the `harness` leg (Experiment.train_one_epoch with
+    per-step H2D copies), the launch count, and GEMM groups priced by the products their arithmetic executes."""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_line.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "baselines"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "baselines", "harness"):
         assert k in line, k
     assert line["unit"] == "epochs/s" and line["n_gpus"] == 1 and line["scaling"] == "weak" and line["vs_baseline"] is None
     assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
+    assert "resident in HBM" in line["config"]["data"]
     assert abs(line["value"] - line["steps"] * 256 / 8192 / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1e-9 * line["value"] + 1e-12
     roof = line["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"} <= set(roof)
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0 < roof["frac"] < 1
     assert roof["traffic"] and "NOT measured in this run" in roof["traffic_source"]
+    for k, v in roof["isolated"].items():
+        if k.startswith("clconv_"):
+            assert v["products_per_fp32_product"] == 3.0 and abs(v["frac"] - 3.0 * v["achieved"] / 2500.0) < 1e-9
     cpu = line["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample", "cpu"} <= set(cpu) and cpu["kind"] == "port" and "3 timed" in cpu["sample"]
+    har = line["harness"]
+    assert har["unit"] == "epochs/s" and 0 < har["value"] <= line["value"] * 1.05 and "H2D" in har["what"] and har["steps_per_epoch"] == 32
+    assert line["config"]["launches_per_step"]["per_step"] <= 48
     for name in ("eegcnn", "transformer"):
         b = line["baselines"][name]
-        assert b["roofline"]["peak"] == 2500.0 and 0 < b["roofline"]["frac"] < 1          # executed bf16 flops / dense bf16 peak
-        assert all(0 < g["frac"] < 1 for g in b["gemm_kernels"].values())
+        assert b["roofline"]["peak"] == 2500.0 and 0 < b["roofline"]["frac"] < 1          # executed 16-bit flops / dense bf16 peak
+        assert all(0 < g["frac"] < 0.6 and g["products_per_fp32_product"] == 3.0 for g in b["gemm_kernels"].values())
         assert b["cpu_baseline"]["kind"] == "port" and b["cpu_baseline"]["value"] > 0
