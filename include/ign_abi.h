@@ -279,6 +279,11 @@ int ign_layernorm_bwd(const float* x, const float* gy, const float* gamma, const
  * pass over the data.  part: (ign_autocorr_parts(rows), K) partial sums, added up by the caller in double.                   */
 long long ign_autocorr_parts(int rows);
 int ign_autocorr_fwd(const float* x_rows, float* part, int rows, int T, int K, void* stream);
+/* The edge terms of that Gram matrix: per row only the first / last k-1 samples of the zero-padded row xp (left pad pad_left)
+ * enter.  part: (ign_edge_lagprod_parts(rows), 2, 124, 128) floats, [b][0][s][d] = sum over the block's rows of xp[s] xp[s+d]
+ * (head, s + d < k-1), [b][1][s][d] = the same at xp[T+s] (tail); summed over b by the caller in double.  k <= 125.          */
+long long ign_edge_lagprod_parts(int rows);
+int ign_edge_lagprod_fwd(const float* x_rows, float* part, int rows, int T, int k, int pad_left, void* stream);
 /* Depthwise (per-channel) 1-D convolution over time, zero 'same' padding: y[b,c,t] = sum_j w[c,j] xpad[b,c,t+j].
  * Replaces the temporal convolutions of IGN/model/eegcnn.py:67 (after the channel contraction) and :78 (block2_conv1).
  * flip=1 correlates with the reversed filter (gradient w.r.t. x: call with dy and pad_left = k-1-pad_left).

@@ -454,6 +454,50 @@ __global__ void __launch_bounds__(256) xcorr_kernel(const float* __restrict__ a,
         part[((size_t)bsl * Cc + ch) * K + tid] = ((red[tid] + red[NT * 32 + tid]) + red[2 * NT * 32 + tid]) + red[3 * NT * 32 + tid];
 }
 
+// Edge terms of the window Gram matrix (models/eegcnn.py::_window_gram): per row only the first / last k-1 samples of the
+// zero-padded row xp (left pad pl) are involved,
+//     out[0][s][d] = sum_rows xp[s] xp[s+d]          (s, s+d < m = k-1: the head),
+//     out[1][s][d] = sum_rows xp[T+s] xp[T+s+d]      (the tail),
+// which round 1 took from two batched GEMMs over zero-padded copies.  Thread <-> (lag d, half of the s range): 2 x 62
+// accumulators, the two segments of a row in LDS; partials per block, the caller adds them in double.  4.8e8 FMA at the benchmark
+// shape: launch-bound.
+constexpr int EG_MAXM = 124, EG_HALF = 62;
+__global__ void __launch_bounds__(256) edge_lagprod_kernel(const float* __restrict__ x, float* __restrict__ part, int rows, int T, int k,
+                                                           int pl, int rows_per_block) {
+    __shared__ float hs[2 * EG_MAXM + 8], ts[2 * EG_MAXM + 8];
+    const int m = k - 1;
+    const int d = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float ah[EG_HALF], at[EG_HALF];
+#pragma unroll
+    for (int i = 0; i < EG_HALF; ++i) { ah[i] = 0.f; at[i] = 0.f; }
+    for (int r = r0; r < r1; ++r) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * EG_MAXM + 8; i += 256) {
+            // head: xp[i] = x[i - pl], i < m;   tail: xp[T + i] = x[T + i - pl], i < pl   (zero elsewhere, and beyond m)
+            const int sh = i - pl, st = T + i - pl;
+            hs[i] = (i < m && sh >= 0 && sh < T) ? x[(size_t)r * T + sh] : 0.f;
+            ts[i] = (i < m && st >= 0 && st < T) ? x[(size_t)r * T + st] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < EG_HALF; ++i) {
+            const int s = half * EG_HALF + i;
+            ah[i] = fmaf(hs[s], hs[s + d], ah[i]);
+            at[i] = fmaf(ts[s], ts[s + d], at[i]);
+        }
+    }
+    if (d < k) {
+        float* pb = part + (size_t)blockIdx.x * 2 * EG_MAXM * 128;
+#pragma unroll
+        for (int i = 0; i < EG_HALF; ++i) {
+            const int s = half * EG_HALF + i;
+            pb[(size_t)s * 128 + d] = ah[i];
+            pb[(size_t)(EG_MAXM + s) * 128 + d] = at[i];
+        }
+    }
+}
+
 // launch geometry of xcorr_kernel for rows of T samples and K lags; returns 0 when the shape is outside its tile
 static int xcorr_geometry(int T, int K, int* lpr, int* T4, int* BL, int* NT, size_t* lds) {
     if (T > 1024 || K > 128 || T < 1 || K < 1) return 0;
@@ -707,4 +751,22 @@ extern "C" int ign_autocorr_fwd(const float* x, float* part, int rows, int T, in
     IgnScopedTimer tm("autocorr", (hipStream_t)stream);
     hipLaunchKernelGGL(autocorr_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, x, part, rows, T, K, xs_len);
     return ign_check_launch("autocorr_kernel");
+}
+
+// part: (ign_edge_lagprod_parts(rows), 2, 124, 128) floats; [.,0,s,d] head products, [.,1,s,d] tail products (s >= k-1 rows and
+// d >= k columns are zero / unwritten garbage-free: the kernel writes every (s < 124, d < k) slot).  k <= 125.
+extern "C" long long ign_edge_lagprod_parts(int rows) { return rows > 0 ? std::min(256, rows) : 0; }
+
+extern "C" int ign_edge_lagprod_fwd(const float* x, float* part, int rows, int T, int k, int pad_left, void* stream) {
+    static const char* who = "ign_edge_lagprod_fwd";
+    if (!x || !part || rows <= 0 || T <= 0 || k <= 1 || pad_left < 0 || pad_left >= k) {
+        ign_set_error("%s: bad argument (rows=%d T=%d k=%d pl=%d)", who, rows, T, k, pad_left);
+        return IGN_E_ARG;
+    }
+    if (k - 1 > EG_MAXM) { ign_set_error("%s: k=%d exceeds %d taps", who, k, EG_MAXM + 1); return IGN_E_UNSUP; }
+    const int nb = (int)ign_edge_lagprod_parts(rows);
+    const int rpb = (rows + nb - 1) / nb;
+    IgnScopedTimer tm("edge_lagprod", (hipStream_t)stream);
+    hipLaunchKernelGGL(edge_lagprod_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, part, rows, T, k, pad_left, rpb);
+    return ign_check_launch("edge_lagprod_kernel");
 }

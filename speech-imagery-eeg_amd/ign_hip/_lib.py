@@ -29,6 +29,8 @@ SIGNATURES = {
     "ign_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp]),
     "ign_autocorr_parts": (ll, [ci]),
     "ign_autocorr_fwd": (ci, [vp, vp, ci, ci, ci, vp]),
+    "ign_edge_lagprod_parts": (ll, [ci]),
+    "ign_edge_lagprod_fwd": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "ign_attn_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
     "ign_attn_fwd_x6": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
     "ign_attn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),

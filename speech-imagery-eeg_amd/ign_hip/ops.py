@@ -942,6 +942,19 @@ def autocorr(x_rows, K):
     return part.sum(dim=0, dtype=torch.float64)
 
 
+def edge_lagprod(x_rows, k, pad_left):
+    """(Dh, Dt), float64 (k-1, k): Dh[s, d] = sum_rows xp[s] xp[s+d] over the first k-1 samples of the zero-padded rows (0 where
+    s + d >= k-1), Dt the same over the k-1 samples from position T on (ign_edge_lagprod_fwd; no gradient: input data)."""
+    _need_gpu("edge_lagprod", x_rows)
+    L = _lib.lib()
+    x_rows = x_rows.contiguous()
+    R, T = x_rows.shape
+    part = torch.empty(int(L.ign_edge_lagprod_parts(R)), 2, 124, 128, device=x_rows.device, dtype=torch.float32)
+    _lib.check(L.ign_edge_lagprod_fwd(_ptr(x_rows), _ptr(part), R, T, int(k), int(pad_left), _stream()), "ign_edge_lagprod_fwd")
+    tot = part[:, :, :k - 1, :k].sum(dim=0, dtype=torch.float64)
+    return tot[0], tot[1]
+
+
 def conv1_sumsq(x_rows, w1, mu, pad_left):
     return Conv1SumSqFn.apply(x_rows, w1, mu, pad_left)
 

@@ -87,22 +87,25 @@ class EEGcnn(nn.Module):
             col = torch.arange(m, device=dev).view(m, 1) + torch.arange(k, device=dev).view(1, k)       # s + d
             cls._GRAM_INDEX[key] = ((jp - j).abs(), torch.minimum(j.expand(k, k), jp.expand(k, k)), col.clamp(max=m - 1), col < m)
         d, lo, colc, valid = cls._GRAM_INDEX[key]
-        head = F.pad(x2d[:, :k - 1 - pl], (pl, 0))                 # xp[:, 0 : k-1]
-        tail = F.pad(x2d[:, T - pl:], (0, k - 1 - pl))             # xp[:, T : T+k-1]
+        if m <= 124:
+            # D[s, d] = sum_rows xp[s] xp[s+d] at the two ends of the rows, straight from ign_edge_lagprod_fwd
+            Dh, Dt = ops.edge_lagprod(x2d, k, pl)
+        else:
+            head = F.pad(x2d[:, :k - 1 - pl], (pl, 0))                 # xp[:, 0 : k-1]
+            tail = F.pad(x2d[:, T - pl:], (0, k - 1 - pl))             # xp[:, T : T+k-1]
 
-        def gram64(a):
-            # (m, R) @ (R, m) over ~1000-row chunks in fp32 (batched GEMM), chunks added in float64 (a float64 GEMM of this
-            # skinny shape takes 3.3 ms in hipBLAS; this takes 0.15)
-            nch = max(1, (R + 1023) // 1024)
-            rows = (R + nch - 1) // nch
-            a = F.pad(a, (0, 0, 0, nch * rows - R)).view(nch, rows, m)
-            return torch.bmm(a.transpose(1, 2), a).sum(dim=0, dtype=torch.float64)
+            def gram64(a):
+                # (m, R) @ (R, m) over ~1000-row chunks in fp32 (batched GEMM), chunks added in float64
+                nch = max(1, (R + 1023) // 1024)
+                rows = (R + nch - 1) // nch
+                a = F.pad(a, (0, 0, 0, nch * rows - R)).view(nch, rows, m)
+                return torch.bmm(a.transpose(1, 2), a).sum(dim=0, dtype=torch.float64)
 
-        Hh, Ht = gram64(head), gram64(tail)
-        zero = Hh.new_zeros(())
-        Dh = torch.where(valid, Hh.gather(1, colc), zero)          # D[s, d] = H[s, s+d]
-        Dt = torch.where(valid, Ht.gather(1, colc), zero)
-        z = Hh.new_zeros(1, k)
+            Hh, Ht = gram64(head), gram64(tail)
+            zero = Hh.new_zeros(())
+            Dh = torch.where(valid, Hh.gather(1, colc), zero)          # D[s, d] = H[s, s+d]
+            Dt = torch.where(valid, Ht.gather(1, colc), zero)
+        z = Dh.new_zeros(1, k)
         cumh = torch.cat([z, Dh.cumsum(0)], 0)                     # [j, d] = sum_{s<j}
         cumt = torch.cat([Dt.flip(0).cumsum(0).flip(0), z], 0)     # [j, d] = sum_{s>=j}
         return C[d] - cumh[lo, d] - cumt[lo, d]
