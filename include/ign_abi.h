@@ -404,6 +404,10 @@ int ign_clconv_pack_weights_x3_multi(int n, const float* const* w_oik, void* con
  *                  exceed sqrt(R - 1) (training mode only; eval mode keeps the bf16 kernels)
  *   dL/dy          max |dL/dy|, taken by ign_bn_bwd_apply_amax as it writes the tensor (integer atomicMax on the bit patterns of
  *                  non-negative floats: exact and order-independent, so results stay bitwise reproducible)
+ * Supported magnitudes: the scale exponent is clamped to +-60, i.e. bounds from 2^-46 (1.4e-14; below it the operand loses
+ * precision gradually and finally reads as zero -- gradients of that size no longer move an fp32 weight) to 2^74 (1.9e22; a
+ * tensor beyond it overflows fp16 and the result is NaN, as loudly as the diverged run that produced it).  A bound of 0 or a
+ * non-finite bound selects scale 1.  A bound must BE an upper bound: a value above it may overflow.
  * Replaces the same reference lines as ign_clconv_fwd / _dgrad / _wgrad (IGN/model/FullyConvNet.py:31-59 and its autograd).   */
 int ign_absmax(const float* x, long long n, float* slot /* max'ed into, caller zeroes */, void* stream);
 int ign_fcn_scan(int nl, const float* const* w, const long long* nw, const float* const* gamma_prev, const float* const* beta_prev,

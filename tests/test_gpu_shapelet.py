@@ -422,3 +422,87 @@ def test_abi_argument_errors():
     assert L.ign_shapelet_fwd(pp, pp, None, pp, pp, 4, 0, pp, pp, None, None, 1, 2, 8, 2, 3, 1, 1.0, 0x10, None) == -1001  # LTS, no thr
     assert L.ign_shapelet_bwd_workspace_bytes(1, 2, 8, 2, 3, 2, 0) == 1 * 2 * 2 * 3 * 4      # strided plans exist since round 2
     assert L.ign_shapelet_bwd_workspace_bytes(1, 2, 8, 2, 3, 0, 0) == 0
+
+
+def test_abi_argument_errors_of_the_round3_entry_points():
+    """Raw ctypes calls: every round-3 entry point refuses bad arguments with IGN_E_ARG / IGN_E_UNSUP before launching anything."""
+    dev = _dev()
+    import ctypes
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import _lib
+    L = _lib.lib()
+    x = torch.zeros(4096, device=dev)
+    pp = ctypes.c_void_p(x.data_ptr())
+    v1, i1, l1 = ctypes.c_void_p * 1, ctypes.c_int * 1, ctypes.c_longlong * 1
+    ARG, UNSUP = -1001, -1002
+    # operand bounds
+    assert L.ign_absmax(None, 16, pp, None) == ARG and L.ign_absmax(pp, 0, pp, None) == ARG
+    assert L.ign_absmax(ctypes.c_void_p(x.data_ptr() + 4), 16, pp, None) == ARG                      # not 16-byte aligned
+    assert L.ign_fcn_scan(0, v1(x.data_ptr()), l1(16), None, None, None, None, pp, None) == ARG
+    assert L.ign_fcn_scan(9, v1(x.data_ptr()), l1(16), None, None, None, None, pp, None) == ARG
+    assert L.ign_fcn_scan(1, v1(x.data_ptr()), l1(16), v1(x.data_ptr()), None, None, None, pp, None) == ARG      # gamma without beta
+    assert L.ign_fcn_scan(1, v1(x.data_ptr()), l1(16), v1(x.data_ptr()), v1(x.data_ptr()), i1(4), l1(1), pp, None) == ARG   # R <= 1
+    # fp16 GEMMs need both bounds
+    assert L.ign_clconv_fwd_h3(pp, pp, None, None, None, pp, None, None, pp, 1, 16, 4, 4, 3, None) == ARG
+    assert L.ign_clconv_dgrad_h3(pp, pp, pp, pp, pp, pp, pp, pp, pp, pp, None, 1, 16, 4, 4, 3, None) == ARG
+    assert L.ign_clconv_wgrad_h3(pp, 2, pp, None, None, pp, pp, None, pp, 1, 16, 4, 4, 3, None) == ARG
+    assert L.ign_linear_wgrad_h3(pp, pp, pp, None, pp, pp, pp, 0, 4, 4, None) == ARG
+    assert L.ign_clconv_pack_weights_h2_multi(1, v1(x.data_ptr()), v1(x.data_ptr()), None, i1(4), i1(4), i1(3), None, None, None) == ARG
+    assert L.ign_clconv_pack_weights_x3_multi(9, v1(x.data_ptr()), v1(x.data_ptr()), None, i1(4), i1(4), i1(3), None, None) == ARG
+    assert L.ign_clconv_wgrad_reduce_multi(0, v1(x.data_ptr()), v1(x.data_ptr()), i1(1), i1(4), i1(4), i1(3), None) == ARG
+    assert L.ign_clconv_wgrad_x6_nsplit(1, 16, 4, 4, 7) == 0                                       # k = 7 has no multi-tap kernel
+    # attention on fp16 planes: E <= 64, all bounds present
+    z = (pp,) * 5
+    assert L.ign_attn_fwd_h3(*z, 1, 8, 8, 1, 128, 128, 128, 128, 128, 128, 128, 1.0, None, pp, pp, pp) == UNSUP
+    assert L.ign_attn_fwd_h3(*z, 1, 8, 8, 1, 64, 64, 64, 64, 64, 64, 64, 1.0, None, pp, None, pp) == ARG
+    assert L.ign_attn_bwd_h3(*((pp,) * 10), 1, 8, 8, 1, 64, 64, 64, 64, 64, 64, 64, 1.0, None, 0, 0, pp, pp, pp, None) == ARG
+    # fused regulariser, bank backward, head backward with an addend
+    assert L.ign_sbm_reg_fwd_bwd(pp, pp, 16, 0.1, 9, v1(x.data_ptr()), v1(x.data_ptr()), i1(2), i1(3), 2, 0.1, 1e-6, pp, pp, None) == ARG
+    assert L.ign_sbm_reg_fwd_bwd(pp, pp, 16, 0.1, 1, v1(x.data_ptr()), v1(x.data_ptr()), i1(17), i1(3), 2, 0.1, 1e-6, pp, pp, None) == UNSUP
+    assert L.ign_sbm_reg_fwd_bwd(pp, pp, 16, 0.1, 0, None, None, None, None, 2, 0.1, 1e-6, None, pp, None) == ARG          # no output
+    assert L.ign_sbm_reg_workspace_bytes(9, 2, 16) == 0
+    assert L.ign_shapelet_bwd_bank_workspace_bytes(0, 1, 2, 8, i1(2), i1(3), i1(1), 0) == 0
+    assert L.ign_shapelet_bwd_bank(pp, 0, None, pp, pp, pp, 4, None, None, None, None, None, None, None, None, None, pp, 1, 2, 8, None,
+                                   None, None, 1.0, 0, None) == ARG
+    assert L.ign_head_bwd_acc(None, pp, pp, pp, pp, None, pp, pp, 1, 4, 2, 4, None) == ARG
+    assert L.ign_loss_fwd_bwd_reg(pp, pp, pp, pp, pp, pp, pp, pp, pp, 4, 1, 1.0, None) == ARG                                # N < 2
+    assert L.ign_edge_lagprod_fwd(pp, pp, 4, 16, 1, 0, None) == ARG and L.ign_edge_lagprod_fwd(pp, pp, 4, 16, 130, 0, None) == UNSUP
+
+
+@pytest.mark.parametrize("bound", [0.0, float("inf"), float("nan"), 1e-30, 1e20])
+def test_fp16_gemm_with_degenerate_magnitude_bounds(bound):
+    """ign_pow2_scale: a bound of zero (an all-zero operand), a non-finite one, or one at the ends of the supported range
+    (the scale exponent is clamped to +-60: magnitudes from ~1e-14, below which precision degrades gracefully towards "the operand
+    is zero", up to 1.9e22 -- include/ign_abi.h) must not produce NaN / inf; the all-zero case returns the bias."""
+    dev = _dev()
+    import ctypes
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import _lib
+    L = _lib.lib()
+    B, T, Ci, Co, k = 2, 40, 8, 128, 3
+    g = torch.Generator().manual_seed(4)
+    zero_in = bound == 0.0
+    # (a bound must BE a bound: the finite non-zero cases use data a factor ~10 below it; the scale exponent is clamped to +-60,
+    # so operands of 1e-31 underflow to zero -- the output is the bias -- instead of overflowing)
+    import math
+    fallback = bound == 0.0 or not math.isfinite(bound)          # scale 1
+    mag = 1.0 if fallback else bound / 30.0
+    x = torch.zeros(B, T, Ci) if zero_in else torch.randn(B, T, Ci, generator=g).clamp(-3, 3) * mag
+    w = torch.randn(Co, Ci, k, generator=g) * 0.1
+    bias = torch.randn(Co, generator=g)
+    xd, wd, bd = x.to(dev), w.to(dev), bias.to(dev)
+    wt = torch.zeros(int(L.ign_clconv_x3_elems(Co, Ci, k)), device=dev, dtype=torch.bfloat16)
+    slots = torch.tensor([float(w.abs().max()), bound, 0.0, 0.0], device=dev)
+    v1, i1 = ctypes.c_void_p * 1, ctypes.c_int * 1
+    _lib.check(L.ign_clconv_pack_weights_h2_multi(1, v1(wd.data_ptr()), v1(wt.data_ptr()), None, i1(Co), i1(Ci), i1(k), None,
+                                                  v1(slots.data_ptr()), None), "pack")
+    y = torch.full((B, T - k + 1, Co), float("nan"), device=dev)
+    _lib.check(L.ign_clconv_fwd_h3(ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(wt.data_ptr()), ctypes.c_void_p(bd.data_ptr()), None,
+                                   None, ctypes.c_void_p(y.data_ptr()), None, ctypes.c_void_p(slots.data_ptr() + 4),
+                                   ctypes.c_void_p(slots.data_ptr()), B, T, Ci, Co, k, None), "fwd_h3")
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    ref = torch.nn.functional.conv1d(x.double().permute(0, 2, 1), w.double(), bias.double()).permute(0, 2, 1)
+    # unscaled (scale 1) operands of O(1) are inside fp16's range: full accuracy; the clamped / tiny cases keep the bias exact
+    tol = 3e-6 if (fallback or bound == 1e20) else 1e-3
+    assert float((y.double().cpu() - ref).abs().max() / ref.abs().max()) < tol
