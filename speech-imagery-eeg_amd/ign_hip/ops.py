@@ -495,10 +495,15 @@ def tensor_bound(t):
     """A one-element device tensor holding an upper bound of max |t| -- what the fp16 GEMMs scale their operands by.  A producer
     that knows a bound attaches it (`set_bound`: LayerNorm's hard bound from its parameters); otherwise ONE pass over the tensor
     takes the exact maximum (ign_absmax), cached on the tensor object for as long as it is not modified in place."""
-    cached = getattr(t, "_ign_bound", None)
+    # Parameters are never cached: the flat Adam kernel (ign_adam_step) rewrites them through raw pointers, which does not move
+    # the version counter a cache entry is validated by -- a stale bound would let a weight that has grown overflow fp16.
+    param = t.is_leaf and t.requires_grad
+    cached = None if param else getattr(t, "_ign_bound", None)
     if cached is not None and cached[1] == t._version and cached[2] == t.data_ptr():
         return cached[0]
-    base = getattr(t, "_base", None)
+    base = None if param else getattr(t, "_base", None)
+    if base is not None and (base.is_leaf and base.requires_grad):
+        base = None
     if base is not None and base.numel() == t.numel():       # a reshaped view of a tensor whose producer attached a bound
         cb = getattr(base, "_ign_bound", None)
         if cb is not None and cb[1] == base._version and cb[2] == base.data_ptr():
@@ -510,10 +515,11 @@ def tensor_bound(t):
     tc = t if t.is_contiguous() else t.contiguous()
     slot = _new_slot(t.device)
     _lib.check(_lib.lib().ign_absmax(_ptr(tc), tc.numel(), _ptr(slot), _stream()), "ign_absmax")
-    try:
-        t._ign_bound = (slot, t._version, t.data_ptr())
-    except Exception:
-        pass
+    if not param:
+        try:
+            t._ign_bound = (slot, t._version, t.data_ptr())
+        except Exception:
+            pass
     return slot
 
 

@@ -723,3 +723,30 @@ def test_resnet_and_layernorm_full_size_sample_independence():
         y = ops.layer_norm(h, ln)
         assert torch.equal(y[1000003:1000003 + 70000], ops.layer_norm(h[1000003:1000003 + 70000].contiguous(), ln))
         assert _rel(y[:4096], torch.nn.functional.layer_norm(h[:4096].double(), (64,), ln.weight.double(), ln.bias.double())) < 2e-6
+
+
+def test_weight_bounds_follow_the_optimizer():
+    """The magnitude bound of a WEIGHT must be taken afresh at every call: the flat Adam kernel rewrites parameters through raw
+    pointers (no version bump), so a cached bound would go stale -- here one Adam step with a huge learning rate grows the weight
+    ~1000x, far beyond the 4x headroom between the scaled maximum (2^14) and fp16's overflow."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    from ign_hip.ddp import FlatAdam, FlatParamBucket
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 256).to(dev)
+    bucket = FlatParamBucket(lin, 1)
+    opt = FlatAdam(bucket, lr=50.0)
+    x = torch.randn(40, 64, device=dev)
+    for it in range(2):
+        y = ops.linear(x, lin.weight, lin.bias)
+        ref = torch.nn.functional.linear(x.double(), lin.weight.detach().double(), lin.bias.detach().double())
+        assert torch.isfinite(y).all(), f"call {it}"
+        assert _rel(y, ref) < 3e-6, f"call {it}"
+        y.square().mean().backward()
+        opt.step()
+        bucket.zero_grad()
+    assert float(lin.weight.detach().abs().max()) > 40.0          # the weight did grow far beyond its first bound
+    y = ops.linear(x, lin.weight, lin.bias)
+    ref = torch.nn.functional.linear(x.double(), lin.weight.detach().double(), lin.bias.detach().double())
+    assert torch.isfinite(y).all() and _rel(y, ref) < 3e-6
