@@ -131,17 +131,32 @@ __device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const
 // GEMM form above loads and splits every activation k times.  Weights: bf16 planes (3, N, k*Cp), Cp = channels rounded up to
 // 16, so every (tap, chunk) block is 16-byte aligned.  One barrier per (chunk, tap) step of 24 MFMAs per wave; the weights
 // of the next step and (on the last tap) the next span are prefetched into registers during the MFMAs.
+#ifndef IGN_H3_WAVES
+#define IGN_H3_WAVES 3                             // minimum waves per SIMD asked of the fp16-plane convolution kernel (A/B: -DIGN_H3_WAVES=2)
+#endif
 constexpr int X6T_SPAN = TM + 15;                  // k <= 16
 constexpr int X6T_APLANE = X6T_SPAN * X6_PITCH;
 constexpr int X6T_ABUF = 3 * X6T_APLANE;
 constexpr int X6T_BBUF = 3 * X6_PLANE;
 constexpr size_t X6T_LDS_BYTES = (size_t)2 * (X6T_ABUF + X6T_BBUF) * sizeof(unsigned short);
 
+// LDS of one workgroup: two stages of NPL operand planes each (NPL = 2 for the fp16 arithmetic: 52 KB, three workgroups per CU
+// -- the register budget below is set to match; 3 otherwise: 78 KB, two workgroups per CU)
+template <int NP> struct X6tLds {
+    static constexpr int NPL = (NP == 2) ? 2 : 3;
+    static constexpr int ABUF = NPL * X6T_APLANE, BBUF = NPL * X6_PLANE;
+    static constexpr size_t BYTES = (size_t)2 * (ABUF + BBUF) * sizeof(unsigned short);
+};
+// Three workgroups per CU for the fp16 forward kernel (168 VGPRs, 3 spilled: 0.733 -> 0.678 ms for the FCN's forward convolutions on
+// one box); the data-gradient variant keeps two -- its epilogue holds 16 y values per accumulator and spills 99 registers at the
+// 168 budget (0.505 -> 0.667 ms).
+template <int NP, int EPI> struct X6tWaves { static constexpr int N = (NP == 2 && EPI == EPI_BIAS_STATS) ? IGN_H3_WAVES : 2; };
 template <int V, bool PRO, int EPI, int NP>
-__global__ void __launch_bounds__(256, 2) clconv_x6t_kernel(const ConvX6Args ca) {
+__global__ void __launch_bounds__(256, (X6tWaves<NP, EPI>::N)) clconv_x6t_kernel(const ConvX6Args ca) {
     const GemmNTArgs& a = ca.g;
     constexpr int VPR = KC / V;                               // vectors per span row
     constexpr int APASS = (X6T_SPAN * VPR + 255) / 256;       // staging passes of the span (V=4: 3, V=2: 5, V=1: 9)
+    constexpr int X6T_ABUF = X6tLds<NP>::ABUF, X6T_BBUF = X6tLds<NP>::BBUF;      // (shadow the three-plane constants)
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     __bf16* Abuf = reinterpret_cast<__bf16*>(smem16);
     __bf16* Bbuf = Abuf + 2 * X6T_ABUF;
@@ -547,11 +562,14 @@ __device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
 }
 
 template <int KT, int NR, int VX, bool PRO, int NP>
-__global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Args a) {
+// (fp16 arithmetic: two planes leave room for a third workgroup per CU; the 8-tap variant keeps two -- eight accumulators do not
+//  fit the 168-register budget of three waves per SIMD without ~100 spilled registers)
+__global__ void __launch_bounds__(256, ((NP == 2 && KT <= 5) ? IGN_H3_WAVES : 2)) clconv_wgrad_x6_kernel(const WgradX6Args a) {
     constexpr int RU = 16 * NR;                     // output rows per unit
     constexpr int SPAN = RU + KT - 1;               // input rows per unit
     constexpr int PPLANE = RU * WG_PITCH, QPLANE = SPAN * WG_PITCH;
-    constexpr int STAGE = 3 * (PPLANE + QPLANE);
+    constexpr int NPL = (NP == 2) ? 2 : 3;          // planes held per operand (two for the fp16 arithmetic: 2/3 of the LDS)
+    constexpr int STAGE = NPL * (PPLANE + QPLANE);
     constexpr int XVPR = 64 / VX;                   // input vectors per row
     constexpr int XPASS = (SPAN * XVPR + 255) / 256;
     constexpr int DPASS = NR;                       // dy: RU rows x 16 float4 = 256 * NR vectors
@@ -614,7 +632,7 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Ar
     };
     auto lstore = [&](int buf) {
         __bf16* P = smem + buf * STAGE;
-        __bf16* Q = P + 3 * PPLANE;
+        __bf16* Q = P + NPL * PPLANE;
 #pragma unroll
         for (int p = 0; p < DPASS; ++p) {
             if constexpr (NP == 2) {
@@ -656,7 +674,7 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_kernel(const WgradX6Ar
     for (int u = u_begin; u < u_end; ++u, buf ^= 1) {
         if (u + 1 < u_end) gload(u + 1);
         const __bf16* P = smem + buf * STAGE;
-        const __bf16* Q = P + 3 * PPLANE;
+        const __bf16* Q = P + NPL * PPLANE;
 #pragma unroll
         for (int s = 0; s < NR; ++s) {
             bf16x8 af[NP];
@@ -730,9 +748,11 @@ struct Wgrad1Args {
 };
 
 template <int NP>
-__global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1Args a) {
+__global__ void __launch_bounds__(256, (NP == 2 ? IGN_H3_WAVES : 2)) clconv_wgrad_x6_k1_kernel(const Wgrad1Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     __bf16* smem = reinterpret_cast<__bf16*>(smem16);
+    constexpr int NPL = (NP == 2) ? 2 : 3;                        // planes per operand held in LDS
+    constexpr int W1_STAGE = 2 * NPL * W1_PLANE;                  // (shadows the three-plane constant)
     // Workgroups go round-robin over the 8 XCDs: XCD x takes the row ranges (splits) = x mod 8 and runs all tiles of a split
     // back to back, so the dy / x rows a split shares between its tiles are fetched into ONE L2, once.
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
@@ -780,7 +800,7 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1
     };
     auto lstore = [&](int buf) {
         __bf16* P = smem + buf * W1_STAGE;
-        __bf16* Q = P + 3 * W1_PLANE;
+        __bf16* Q = P + NPL * W1_PLANE;
         if (want_b) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) bsum[v] += rd[0][v] + rd[1][v];
@@ -809,7 +829,7 @@ __global__ void __launch_bounds__(256, 2) clconv_wgrad_x6_k1_kernel(const Wgrad1
     for (int u = u_begin; u < u_end; ++u, buf ^= 1) {
         if (u + 1 < u_end) gload(u + 1);
         const __bf16* P = smem + buf * W1_STAGE + roff + wco * 64;
-        const __bf16* Q = smem + buf * W1_STAGE + 3 * W1_PLANE + roff + wci * 64;
+        const __bf16* Q = smem + buf * W1_STAGE + NPL * W1_PLANE + roff + wci * 64;
         bf16x8 bf[2][NP], af[2][NP];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -871,10 +891,10 @@ static int launch_x6t(const ConvX6Args& a, int V, bool pro, hipStream_t s) {
         static bool once = false;                                                                                            \
         if (!once) {                                                                                                         \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_x6t_kernel<VV, PP, EPI, NP>),                     \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6T_LDS_BYTES);                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6tLds<NP>::BYTES);                   \
             once = true;                                                                                                     \
         }                                                                                                                    \
-        hipLaunchKernelGGL((clconv_x6t_kernel<VV, PP, EPI, NP>), grid, block, X6T_LDS_BYTES, s, a);                           \
+        hipLaunchKernelGGL((clconv_x6t_kernel<VV, PP, EPI, NP>), grid, block, X6tLds<NP>::BYTES, s, a);                       \
     } while (0)
     if (V == 4) { if (pro) IGN_X6T(4, true); else IGN_X6T(4, false); }
     else if (V == 2) { if (pro) IGN_X6T(2, true); else IGN_X6T(2, false); }
@@ -971,7 +991,7 @@ static int pack_multi_impl(int n, const float* const* w_oik, void* const* wt3_fw
 
 template <int KT, int NR, int NP>
 static int launch_wgrad_x6(const WgradX6Args& a, int V, bool pro, dim3 grid, hipStream_t s) {
-    constexpr size_t lds = (size_t)2 * 3 * ((16 * NR) + (16 * NR + KT - 1)) * WG_PITCH * sizeof(unsigned short);
+    constexpr size_t lds = (size_t)2 * (NP == 2 ? 2 : 3) * ((16 * NR) + (16 * NR + KT - 1)) * WG_PITCH * sizeof(unsigned short);
 #define IGN_WG(VV, PP)                                                                                                       \
     do {                                                                                                                     \
         static bool once = false;                                                                                            \
@@ -1043,15 +1063,16 @@ static int wgrad_x6_impl(const char* who, const float* dyp, int dy_pad, const fl
         w.citiles = (Ci + 127) / 128; w.ntiles = tiles;
         w.part_b = db ? (float*)workspace + (size_t)w.nsplit * Co * Ci : nullptr;
         w.bound_dy = bound_dy; w.bound_x = bound_x;
+        constexpr size_t w1_lds = (size_t)2 * 2 * (NP == 2 ? 2 : 3) * W1_PLANE * sizeof(unsigned short);     // two stages x two operands
         static bool once = false;
         if (!once) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_wgrad_x6_k1_kernel<NP>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)W1_LDS_BYTES);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)w1_lds);
             once = true;
         }
         {
             IgnScopedTimer tm("clconv_wgrad", s);
-            hipLaunchKernelGGL(clconv_wgrad_x6_k1_kernel<NP>, dim3((unsigned)(tiles * ((w.nsplit + 7) / 8 * 8))), dim3(256), W1_LDS_BYTES,
+            hipLaunchKernelGGL(clconv_wgrad_x6_k1_kernel<NP>, dim3((unsigned)(tiles * ((w.nsplit + 7) / 8 * 8))), dim3(256), w1_lds,
                                s, w);
         }
         int rc1 = ign_check_launch("clconv_wgrad_x6_k1_kernel");
