@@ -5,6 +5,7 @@
 # it into the committed files.
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; T=r3
+python -c "import __graft_entry__ as g; g.smoke()" > $O/${T}_smoke.log 2>&1; tail -1 $O/${T}_smoke.log
 python -m pytest tests -q -m gpu > $O/${T}_tests.log 2>&1; tail -3 $O/${T}_tests.log; cp $O/parity.json $O/${T}_parity.json
 cd $R && python bench.py --count-launches > $O/${T}_bench.json 2> $O/${T}_bench.err; tail -c 300 $O/${T}_bench.json
 python bench.py --shape bm --batch 32 --steps 300 --warmup 30 --alt-steps 0 --baseline-steps 0 --cpu-sample 0 --harness-epochs 0 --count-launches > $O/${T}_bm32_eager.json 2> $O/${T}_bm32_eager.err
@@ -13,6 +14,8 @@ python bench.py --precision bf16 --alt-steps 0 --baseline-steps 0 --cpu-sample 0
 python bench.py --groups 6x10 --alt-steps 0 --baseline-steps 0 --cpu-sample 0 --harness-epochs 0 > $O/${T}_bench_6x10.json 2> $O/${T}_bench_6x10.err
 IGN_CONV_MATH=bf16x6 python bench.py --alt-steps 0 --baseline-steps 0 --cpu-sample 0 --harness-epochs 0 > $O/${T}_bench_convx6.json 2> $O/${T}_bench_convx6.err
 IGN_GEMM_MATH=bf16x6 python bench.py --config transformer --steps 6 --warmup 2 --cpu-sample 0 > $O/${T}_tr_x6.json 2> $O/${T}_tr_x6.err
+for d in ResNet PatchTST TimesNet; do python bench.py --dnn $d --steps 8 --warmup 3 --alt-steps 0 --iso-steps 1 --baseline-steps 0 --cpu-sample 0 --harness-epochs 0 > $O/${T}_ign_$d.json 2> $O/${T}_ign_$d.err; done
+python bench.py --config transformer --precision bf16 --steps 6 --warmup 2 --cpu-sample 0 > $O/${T}_tr_bf16.json 2> $O/${T}_tr_bf16.err
 cd /tmp && export TMPDIR=/tmp
 P="--alt-steps 0 --baseline-steps 0 --cpu-sample 0 --harness-epochs 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof_ign -o ign -- python $R/bench.py $P > $O/${T}_prof_ign.json 2> $O/${T}_prof_ign.err

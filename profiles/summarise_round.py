@@ -53,7 +53,10 @@ def copy(src, dst):
 for src, dst in ((f"{T}_bench.json", f"{T}_bench_line.json"), (f"{T}_bm32_eager.json", f"{T}_bm32_eager_bench_line.json"),
                  (f"{T}_bm32_graph.json", f"{T}_bm32_graph_bench_line.json"), (f"{T}_bench_bf16.json", f"{T}_bench_line_bf16_autocast.json"),
                  (f"{T}_bench_6x10.json", f"{T}_bench_line_6x10.json"), (f"{T}_bench_convx6.json", f"{T}_bench_line_conv_bf16x6.json"),
-                 (f"{T}_tr_x6.json", f"{T}_transformer_bench_line_bf16x6.json")):
+                 (f"{T}_tr_x6.json", f"{T}_transformer_bench_line_bf16x6.json"),
+                 (f"{T}_tr_bf16.json", f"{T}_transformer_bench_line_bf16_autocast.json"),
+                 (f"{T}_ign_ResNet.json", f"{T}_bench_line_ign_ResNet.json"), (f"{T}_ign_PatchTST.json", f"{T}_bench_line_ign_PatchTST.json"),
+                 (f"{T}_ign_TimesNet.json", f"{T}_bench_line_ign_TimesNet.json")):
     p = os.path.join(O, src)
     if os.path.exists(p):
         json.dump(one_json_line(p), open(os.path.join(P, dst), "w"), indent=1)
