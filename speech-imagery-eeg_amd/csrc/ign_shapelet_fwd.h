@@ -14,6 +14,12 @@
 #pragma once
 #include "ign_common.h"
 
+// Up to this many windows per lane the shapelet values of a step are all requested before anything else is scheduled (one exposed
+// scalar-cache latency per step); beyond it the pinned order costs registers -> scratch (same box: L = 100 0.638 -> 0.676 ms at 16,
+// L = 300 1.136 -> 1.11 ms at 12 against 8).
+#ifndef IGN_FWD_BARRIER_TT
+#define IGN_FWD_BARRIER_TT 12
+#endif
 template <int TT> struct FwdJ { static constexpr int J = (TT <= 8) ? 8 : 4; };
 
 // Wave reductions on the DPP path (pure VALU): two quad permutes, row_half_mirror, row_mirror, row_bcast:15, row_bcast:31.
@@ -56,12 +62,15 @@ __device__ __forceinline__ float wave_bcast_l63(float v) {
 }
 
 // The body of one block; (bx, by) play the role of blockIdx.x / .y (kept as parameters: round 2's one-grid bank kernel called the
-// same body with a remapped block index, measured slower and was removed -- DESIGN 4.1b).
+// same body with a remapped block index, measured slower and was removed -- DESIGN 4.1b).  The calling kernel's ONLY argument must be
+// the ShpFwdArgs block `a`: the epilogue re-reads it from offset 0 of the kernarg segment.
 template <int TT, int KT, int DIST>
 __device__ __forceinline__ void shp_fwd_body(const ShpFwdArgs& a, const int bx, const int by, float* smem) {
     constexpr int J = FwdJ<TT>::J;
     const int wpb = blockDim.x >> 6;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index is uniform but the compiler cannot know: without readfirstlane every row / output address below is per-lane
+    // 64-bit VALU arithmetic (31 address pairs, formed before the distance loop and spilled: 248 B/lane of scratch at TT = 15)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int nbg = (a.B + wpb - 1) / wpb;
     const int c = bx / nbg;                         // block-uniform: every wave of the block shares w[:,c,:]
     const int bg = bx - c * nbg;
@@ -128,11 +137,19 @@ __device__ __forceinline__ void shp_fwd_body(const ShpFwdArgs& a, const int bx, 
         for (; j0 + J <= L; j0 += J) {
 #pragma unroll
             for (int jj = 0; jj < J; ++jj) xw[TT - 1 + jj] = xl[j0 + TT - 1 + jj];
+            // all KT*J shapelet values of this step are requested up front (s_load, wave-uniform); with the barrier nothing is
+            // scheduled across: one exposed scalar-cache latency per step instead of one per shapelet
+            float wvs[J][KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int jj = 0; jj < J; ++jj) wvs[jj][k] = wk[k * wks + j0 + jj];
+            if constexpr (TT <= IGN_FWD_BARRIER_TT) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int jj = 0; jj < J; ++jj) {
 #pragma unroll
                 for (int k = 0; k < KT; ++k) {
-                    const float wv = wk[k * wks + j0 + jj];          // wave-uniform -> s_load / SGPR operand
+                    const float wv = wvs[jj][k];                     // SGPR operand
                     if (DIST >= DIST_COS) wn2[k] = fmaf(wv, wv, wn2[k]);
 #pragma unroll
                     for (int t = 0; t < TT; ++t) {
@@ -184,15 +201,24 @@ __device__ __forceinline__ void shp_fwd_body(const ShpFwdArgs& a, const int bx, 
             for (int i = 0; i < TT - 1; ++i) xw[i] = xw[i + 1];
         }
 
-        // ---- per-pass epilogue, one shapelet at a time so only ONE set of row statistics is live (the 128-VGPR budget
-        // of 4 waves/SIMD is otherwise exceeded and the spills showed up as 1 GB/step of scratch writes in WRITE_SIZE):
+        // ---- per-pass epilogue, one shapelet at a time so only ONE set of row statistics is live:
         // d = mean -> gate statistics -> coalesced store of d -> (last pass) merge of the 64 lanes and outputs.
         // Branch-free statistics: window positions past the end of the row (only in the last lanes) get d = +BIG, so
         // p = exp(-(eps BIG)^2) = 0 and exp(-(BIG - m)) = 0 never win the arg-max / arg-min and add nothing to M; the
         // RBF soft-max weight exp(p) of such a slot is exactly 1, which is subtracted from Z afterwards.
-        const int nvalid = min(TT, max(0, a.Tw - tl));
-        const bool lds_store = (a.npass == 1) && a.d;          // x row no longer needed: reuse its LDS as a transpose buffer
-        const bool last_pass = pass + 1 == a.npass;
+        // Everything the epilogue addresses is wave-uniform.  Two opaque scalar copies keep that arithmetic HERE: the row index
+        // (so that the 5 x 6 output addresses are not formed before the distance loop and carried across it) and the argument
+        // block, re-read from the kernarg segment at the point of use (`a` is the kernel's only argument, at offset 0) instead
+        // of holding ~30 SGPRs across the loop.  Together with the scalar wave index above this removed all scratch: the
+        // hoisted per-lane 64-bit addresses used to be spilled, 31 pairs per block = 1 GB/step of scratch writes in WRITE_SIZE.
+        int be = b;
+        asm volatile("" : "+s"(be));
+        typedef const __attribute__((address_space(4))) ShpFwdArgs* kargs_p;
+        kargs_p ae = (kargs_p)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ae));
+        const int nvalid = min(TT, max(0, ae->Tw - tl));
+        const bool lds_store = (ae->npass == 1) && ae->d;          // x row no longer needed: reuse its LDS as a transpose buffer
+        const bool last_pass = pass + 1 == ae->npass;
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
             float rb, rd, rZ, rM;
@@ -204,7 +230,7 @@ __device__ __forceinline__ void shp_fwd_body(const ShpFwdArgs& a, const int bx, 
                 rZ = park[(5 * k + 2) * blockDim.x]; rM = park[(5 * k + 3) * blockDim.x];
                 ri = __float_as_int(park[(5 * k + 4) * blockDim.x]);
             }
-            float* drow = a.d ? a.d + (((size_t)b * a.C + c) * a.K + (k0 + k)) * a.Tw : nullptr;
+            float* drow = ae->d ? ae->d + (((size_t)be * ae->C + c) * ae->K + (k0 + k)) * ae->Tw : nullptr;
             float dv[TT];
             if (DIST >= DIST_COS) {
                 // cosine:  d = 1 - dot / (max(|x|,1e-8) max(|w|,1e-8))              (F.cosine_similarity)
@@ -214,19 +240,19 @@ __device__ __forceinline__ void shp_fwd_body(const ShpFwdArgs& a, const int bx, 
                 for (int t = 0; t < TT; ++t) {
                     float xn;
                     if (DIST == DIST_COS) xn = sqrtf(xsq[t]);
-                    else                  xn = sqrtf(fmaxf(xsq[t] - xsm[t] * xsm[t] * a.invL, 0.f));
+                    else                  xn = sqrtf(fmaxf(xsq[t] - xsm[t] * xsm[t] * ae->invL, 0.f));
                     const float den = (DIST == DIST_COS) ? fmaxf(xn, 1e-8f) * fmaxf(wn, 1e-8f) : xn * wn + 1e-8f;
                     dv[t] = (t < nvalid) ? 1.f - acc[k][t] / den : 1e18f;
-                    if (k == 0 && a.xstat && row_ok && t < nvalid) a.xstat[((size_t)b * a.C + c) * a.Tw + tl + t] = xn;
+                    if (k == 0 && ae->xstat && row_ok && t < nvalid) ae->xstat[((size_t)be * ae->C + c) * ae->Tw + tl + t] = xn;
                 }
             } else {
 #pragma unroll
-                for (int t = 0; t < TT; ++t) dv[t] = (t < nvalid) ? acc[k][t] * a.invL : 1e18f;
+                for (int t = 0; t < TT; ++t) dv[t] = (t < nvalid) ? acc[k][t] * ae->invL : 1e18f;
             }
-            if (a.gate == GATE_RBF) {
+            if (ae->gate == GATE_RBF) {
 #pragma unroll
                 for (int t = 0; t < TT; ++t) {
-                    const float u = a.eps * dv[t];
+                    const float u = ae->eps * dv[t];
                     const float p = __expf(-(u * u));
                     const float e = __expf(p);
                     rZ += e;
@@ -268,12 +294,12 @@ __device__ __forceinline__ void shp_fwd_body(const ShpFwdArgs& a, const int bx, 
 #pragma unroll
                         for (int i = 0; i < TT; ++i) {
                             const int idx = lane + 64 * i;
-                            if (idx < a.Tw) drow[idx] = xs[idx];
+                            if (idx < ae->Tw) drow[(unsigned)idx] = xs[idx];
                         }
                 } else if (row_ok) {
 #pragma unroll
                     for (int t = 0; t < TT; ++t)
-                        if (t < nvalid) drow[tl + t] = dv[t];
+                        if (t < nvalid) drow[(unsigned)(tl + t)] = dv[t];      // unsigned: scalar base + 32-bit lane offset
                 }
             }
             if (!last_pass) {
@@ -292,7 +318,7 @@ __device__ __forceinline__ void shp_fwd_body(const ShpFwdArgs& a, const int bx, 
                 IGN_ARGMAX_STEP(DPP_BCAST31, 0xc);
                 float dmin = wave_min_l63(rd);
                 float Z = rZ, M = rM;
-                if (a.gate == GATE_LTS) {
+                if (ae->gate == GATE_LTS) {
                     dmin = wave_bcast_l63(dmin);                  // every lane rescales its partial sums to the row minimum
                     const float sc = (rd < INFINITY) ? __expf(dmin - rd) : 0.f;
                     Z *= sc; M *= sc;
@@ -301,20 +327,20 @@ __device__ __forceinline__ void shp_fwd_body(const ShpFwdArgs& a, const int bx, 
                 M = wave_sum_l63(M);
                 if (lane == 63 && row_ok) {
                     const int kk = k0 + k;
-                    const size_t col = (size_t)b * a.ld + a.col0 + (size_t)kk * a.C + c;
-                    const size_t sidx = ((size_t)b * a.K + kk) * a.C + c;
+                    const size_t col = (size_t)be * ae->ld + ae->col0 + (size_t)kk * ae->C + c;
+                    const size_t sidx = ((size_t)be * ae->K + kk) * ae->C + c;
                     float pout;
-                    if (a.gate == GATE_RBF) {
+                    if (ae->gate == GATE_RBF) {
                         pout = best;                       // = p[t*] * (1 + s - s): Shapelet.py:81-82
                     } else {
-                        const float th = a.thr[(size_t)kk * a.C + c];
+                        const float th = ae->thr[(size_t)kk * ae->C + c];
                         pout = 1.f / (1.f + __expf(-(th - dmin)));
                     }
-                    a.p_out[col] = pout;
-                    a.dmin_out[col] = dmin;
-                    a.tstar[sidx] = idx;
-                    a.zmu[2 * sidx] = Z;
-                    a.zmu[2 * sidx + 1] = M / Z;
+                    ae->p_out[col] = pout;
+                    ae->dmin_out[col] = dmin;
+                    ae->tstar[sidx] = idx;
+                    ae->zmu[2 * sidx] = Z;
+                    ae->zmu[2 * sidx + 1] = M / Z;
                 }
             }
         }
