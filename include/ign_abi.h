@@ -46,6 +46,11 @@ const char* ign_last_error(void);
  * IGN/model/FullyConvNet.py:53).                                                                        */
 int ign_instnorm_fwd(const float* x_btc, float* xn_bct, float* xt_bct, int B, int T, int C, float eps,
                      void* stream);
+/* Same pass, additionally max |x| of the raw input as an atomic maximum into *amax_slot (caller zeroes it): the magnitude bound
+ * of the FCN expert's first fp16 GEMM operand (ign_clconv_fwd_h3), taken where the batch is staged anyway instead of by a
+ * separate ign_absmax pass when both experts run on one stream.                                                              */
+int ign_instnorm_fwd_amax(const float* x_btc, float* xn_bct, float* xt_bct, int B, int T, int C, float eps, float* amax_slot,
+                          void* stream);
 
 /* On-GPU input pipeline of the CHISCO loader: raw (B,C,T) recordings -> standardised (B,T,C) batches.
  * Replaces, per batch, Normalizer('per_sample_std') of IGN/data_factory/eeg.py:332-367 (per sample and channel over time:
@@ -410,8 +415,11 @@ int ign_clconv_pack_weights_x3_multi(int n, const float* const* w_oik, void* con
  * non-finite bound selects scale 1.  A bound must BE an upper bound: a value above it may overflow.
  * Replaces the same reference lines as ign_clconv_fwd / _dgrad / _wgrad (IGN/model/FullyConvNet.py:31-59 and its autograd).   */
 int ign_absmax(const float* x, long long n, float* slot /* max'ed into, caller zeroes */, void* stream);
+/* ign_fcn_scan also clears `zero[0..nzero)` (nullable / 0): the identically-zero gradients of the convolution biases in front of
+ * a batch-statistics BatchNorm are views of that buffer, so the backward needs no fill launch.                               */
 int ign_fcn_scan(int nl, const float* const* w, const long long* nw, const float* const* gamma_prev, const float* const* beta_prev,
-                 const int* C_prev, const long long* R_prev, float* slots /* (nl, 4): written */, void* stream);
+                 const int* C_prev, const long long* R_prev, float* slots /* (nl, 4): written */, float* zero, long long nzero,
+                 void* stream);
 int ign_clconv_pack_weights_h2_multi(int n, const float* const* w_oik, void* const* wt_fwd, void* const* wt_dgrad, const int* Co,
                                      const int* Ci, const int* k, long long* const* counters, const float* const* w_bounds,
                                      void* stream);
@@ -473,6 +481,11 @@ int ign_bn_finalize_fwd(const float* part, int nparts, long long R, int C, const
 int ign_bn_affine_eval(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
                        float eps, int C, float* a, float* b, float* mean, float* invstd, void* stream);
 int ign_bn_relu_pool_fwd(const float* y, const float* a, const float* b, float* pooled, int B, int T, int C, void* stream);
+/* The same with the FCN expert's class head in the same launch: logits[b][n] = bias[n] + sum_c pooled[b][c] W[n][c]  (W (N,C),
+ * bias nullable; replaces nn.Linear at IGN/model/FullyConvNet.py:50,58 on top of the pooling): a sample's pooled row is complete
+ * inside its block.  `pooled` is still written (the head's weight gradient needs it: ign_head_bwd).                          */
+int ign_bn_relu_pool_head_fwd(const float* y, const float* a, const float* b, float* pooled, const float* W, const float* bias,
+                              float* logits, int B, int T, int C, int N, void* stream);
 long long ign_bn_relu_pool_bwd_parts(int B, int T);
 int ign_bn_relu_pool_bwd(const float* y, const float* gpool, const float* a, const float* b, const float* mean,
                          const float* invstd, float* g, float* part, int B, int T, int C, void* stream);

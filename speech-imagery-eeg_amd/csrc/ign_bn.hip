@@ -101,9 +101,12 @@ __global__ void __launch_bounds__(1024) bn_finalize_bwd_kernel(const float* __re
 
 // Global average pool of relu(a*y + b) over time:  pooled[b][c] = (1/T) sum_t max(a_c*y[b,t,c] + b_c, 0).
 // One block per sample; thread <-> (row lane, 4 channels); the row lanes are combined through LDS in fixed order.
+// With a head (W != null): logits[b][n] = bias[n] + sum_c pooled[b][c] W[n][c] from the same block -- the sample's pooled row is
+// complete here (one block per sample), so the class head of the FCN expert (IGN/model/FullyConvNet.py:58) needs no launch.
 __global__ void __launch_bounds__(256) bn_relu_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ a,
                                                                const float* __restrict__ b, float* __restrict__ pooled, int T,
-                                                               int C) {
+                                                               int C, const float* __restrict__ W,
+                                                               const float* __restrict__ bias, float* __restrict__ logits, int N) {
     extern __shared__ float sm[];                         // [rif][C]
     const int c4 = C / 4, rif = 256 / c4;
     const int col = (threadIdx.x % c4) * 4, rofs = threadIdx.x / c4;
@@ -125,7 +128,19 @@ __global__ void __launch_bounds__(256) bn_relu_pool_fwd_kernel(const float* __re
     for (int c = threadIdx.x; c < C; c += 256) {
         float u = 0.f;
         for (int q = 0; q < rif; ++q) u += sm[q * C + c];
-        pooled[(size_t)blockIdx.x * C + c] = u / (float)T;
+        u /= (float)T;
+        pooled[(size_t)blockIdx.x * C + c] = u;
+        if (W) sm[c] = u;                                 // column c is this thread's alone: read above, rewritten here
+    }
+    if (!W) return;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int n = wave; n < N; n += 4) {                   // one wave per class: fixed-order lane partials, butterfly sum
+        float u = 0.f;
+        for (int c = lane; c < C; c += 64) u = fmaf(sm[c], W[(size_t)n * C + c], u);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) u += __shfl_xor(u, o, 64);
+        if (lane == 0) logits[(size_t)blockIdx.x * N + n] = u + (bias ? bias[n] : 0.f);
     }
 }
 
@@ -253,9 +268,11 @@ struct FcnScanTable {
     const float* w[SCAN_LMAX]; long long nw[SCAN_LMAX];
     const float* gamma[SCAN_LMAX]; const float* beta[SCAN_LMAX]; int C[SCAN_LMAX]; float sqrtR[SCAN_LMAX];
 };
-__global__ void __launch_bounds__(1024) fcn_scan_kernel(const FcnScanTable t, float* __restrict__ slots) {
+__global__ void __launch_bounds__(1024) fcn_scan_kernel(const FcnScanTable t, float* __restrict__ slots, float* __restrict__ zero,
+                                                        long long nzero) {
     __shared__ float sh[16];
     const int l = blockIdx.x;
+    for (long long i = (long long)l * 1024 + threadIdx.x; i < nzero; i += (long long)gridDim.x * 1024) zero[i] = 0.f;
     float m = 0.f;
     for (long long i = threadIdx.x; i < t.nw[l]; i += 1024) m = fmaxf(m, fabsf(t.w[l][i]));
     m = block_max_1024(m, sh);
@@ -278,7 +295,9 @@ extern "C" int ign_absmax(const float* x, long long n, float* slot, void* stream
 }
 
 extern "C" int ign_fcn_scan(int nl, const float* const* w, const long long* nw, const float* const* gamma_prev,
-                            const float* const* beta_prev, const int* C_prev, const long long* R_prev, float* slots, void* stream) {
+                            const float* const* beta_prev, const int* C_prev, const long long* R_prev, float* slots, float* zero,
+                            long long nzero, void* stream) {
+    if (nzero < 0 || (nzero > 0 && !zero)) { ign_set_error("ign_fcn_scan: nzero=%lld with zero=%p", nzero, (void*)zero); return IGN_E_ARG; }
     if (nl <= 0 || nl > SCAN_LMAX || !w || !nw || !slots) { ign_set_error("ign_fcn_scan: nl=%d outside 1..%d or null table", nl, SCAN_LMAX); return IGN_E_ARG; }
     FcnScanTable t;
     for (int l = 0; l < nl; ++l) {
@@ -292,7 +311,7 @@ extern "C" int ign_fcn_scan(int nl, const float* const* w, const long long* nw, 
         t.gamma[l] = has ? gamma_prev[l] : nullptr; t.beta[l] = has ? beta_prev[l] : nullptr;
         t.C[l] = has ? C_prev[l] : 0; t.sqrtR[l] = has ? sqrtf((float)(R_prev[l] - 1)) : 0.f;
     }
-    hipLaunchKernelGGL(fcn_scan_kernel, dim3(nl), dim3(1024), 0, (hipStream_t)stream, t, slots);
+    hipLaunchKernelGGL(fcn_scan_kernel, dim3(nl), dim3(1024), 0, (hipStream_t)stream, t, slots, zero, nzero);
     return ign_check_launch("fcn_scan_kernel");
 }
 
@@ -344,7 +363,23 @@ extern "C" int ign_bn_relu_pool_fwd(const float* y, const float* a, const float*
     if (!y || !a || !b || !pooled) { ign_set_error("ign_bn_relu_pool_fwd: null pointer"); return IGN_E_ARG; }
     const int rif = 256 / (C / 4);
     IgnScopedTimer tm("bn_relu_pool_fwd", (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(B), dim3(256), (size_t)rif * C * 4, (hipStream_t)stream, y, a, b, pooled, T, C);
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(B), dim3(256), (size_t)rif * C * 4, (hipStream_t)stream, y, a, b, pooled, T, C,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 0);
+    return ign_check_launch("bn_relu_pool_fwd_kernel");
+}
+
+extern "C" int ign_bn_relu_pool_head_fwd(const float* y, const float* a, const float* b, float* pooled, const float* W,
+                                         const float* bias, float* logits, int B, int T, int C, int N, void* stream) {
+    int rc;
+    if ((rc = bn_check("ign_bn_relu_pool_head_fwd", (long long)B * T, C))) return rc;
+    if (!y || !a || !b || !pooled || !W || !logits || N <= 0) {
+        ign_set_error("ign_bn_relu_pool_head_fwd: null pointer or N=%d", N);
+        return IGN_E_ARG;
+    }
+    const int rif = 256 / (C / 4);
+    IgnScopedTimer tm("bn_relu_pool_fwd", (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(B), dim3(256), (size_t)rif * C * 4, (hipStream_t)stream, y, a, b, pooled, T, C,
+                       W, bias, logits, N);
     return ign_check_launch("bn_relu_pool_fwd_kernel");
 }
 

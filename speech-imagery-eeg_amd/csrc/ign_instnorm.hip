@@ -7,10 +7,11 @@
 // CT = 8 (36 KB tiles) PMC showed 2.4x the algorithmic fetch traffic -- 32-byte pieces of 128-byte lines -- and 115 us for the
 // 250 MB; the large tile uses 1024-thread blocks so that one block per CU still keeps 32 KB of loads in flight.
 #include "ign_common.h"
+#include "ign_clconv.h"       // ign_atomic_absmax
 
 __global__ void __launch_bounds__(1024) instnorm_kernel(const float* __restrict__ x, float* __restrict__ xn,
                                                        float* __restrict__ xt, int B, int T, int C, int CT,
-                                                       float eps) {
+                                                       float eps, float* __restrict__ amax_slot) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const int pitch = CT + 1;
     const int nct = (C + CT - 1) / CT;
@@ -38,6 +39,7 @@ __global__ void __launch_bounds__(1024) instnorm_kernel(const float* __restrict_
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
+    float am = 0.f;                                               // max |x| of this wave's share of the tile (amax_slot only)
     for (int cc = wave; cc < CT; cc += (nthr >> 6)) {
         const int c = c0 + cc;
         if (c >= C) break;
@@ -60,14 +62,20 @@ __global__ void __launch_bounds__(1024) instnorm_kernel(const float* __restrict_
             const float xv = tile[t * pitch + cc];
             on[t] = (xv - mean) / denom;
             if (ot) ot[t] = xv;
+            am = fmaxf(am, fabsf(xv));
         }
+    }
+    if (amax_slot) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+        if (lane == 0) ign_atomic_absmax(amax_slot, am);
     }
 }
 
-extern "C" int ign_instnorm_fwd(const float* x_btc, float* xn_bct, float* xt_bct, int B, int T, int C, float eps,
-                                void* stream) {
+static int instnorm_impl(const char* who, const float* x_btc, float* xn_bct, float* xt_bct, int B, int T, int C, float eps,
+                         float* amax_slot, void* stream) {
     if (!x_btc || !xn_bct || B <= 0 || T <= 0 || C <= 0) {
-        ign_set_error("ign_instnorm_fwd: null pointer or non-positive dimension (B=%d T=%d C=%d)", B, T, C);
+        ign_set_error("%s: null pointer or non-positive dimension (B=%d T=%d C=%d)", who, B, T, C);
         return IGN_E_ARG;
     }
     int CT = 32;
@@ -75,7 +83,7 @@ extern "C" int ign_instnorm_fwd(const float* x_btc, float* xn_bct, float* xt_bct
     const size_t lds = (size_t)T * (CT + 1) * 4;
     const int threads = lds > 64 * 1024 ? 1024 : 256;
     if (lds > 160 * 1024) {
-        ign_set_error("ign_instnorm_fwd: T=%d does not fit the LDS tile", T);
+        ign_set_error("%s: T=%d does not fit the LDS tile", who, T);
         return IGN_E_TOOBIG;
     }
     const int nct = (C + CT - 1) / CT;
@@ -83,8 +91,21 @@ extern "C" int ign_instnorm_fwd(const float* x_btc, float* xn_bct, float* xt_bct
         (void)hipFuncSetAttribute((const void*)instnorm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     IgnScopedTimer tm("instnorm", (hipStream_t)stream);
     hipLaunchKernelGGL(instnorm_kernel, dim3((unsigned)B * nct), dim3(threads), lds, (hipStream_t)stream, x_btc, xn_bct,
-                       xt_bct, B, T, C, CT, eps);
+                       xt_bct, B, T, C, CT, eps, amax_slot);
     return ign_check_launch("instnorm_kernel");
+}
+
+extern "C" int ign_instnorm_fwd(const float* x_btc, float* xn_bct, float* xt_bct, int B, int T, int C, float eps,
+                                void* stream) {
+    return instnorm_impl("ign_instnorm_fwd", x_btc, xn_bct, xt_bct, B, T, C, eps, nullptr, stream);
+}
+
+// The same pass also takes max |x| of the raw input (atomic maximum into *amax_slot, which the caller zeroed): the FCN expert's
+// fp16 GEMMs scale their first operand by it (ign_clconv_fwd_h3), and the batch is in LDS here anyway.
+extern "C" int ign_instnorm_fwd_amax(const float* x_btc, float* xn_bct, float* xt_bct, int B, int T, int C, float eps,
+                                     float* amax_slot, void* stream) {
+    if (!amax_slot) { ign_set_error("ign_instnorm_fwd_amax: null amax_slot"); return IGN_E_ARG; }
+    return instnorm_impl("ign_instnorm_fwd_amax", x_btc, xn_bct, xt_bct, B, T, C, eps, amax_slot, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -20,6 +20,7 @@ SIGNATURES = {
     "ign_abi_version": (ci, []),
     "ign_last_error": (ctypes.c_char_p, []),
     "ign_instnorm_fwd": (ci, [vp, vp, vp, ci, ci, ci, cf, vp]),
+    "ign_instnorm_fwd_amax": (ci, [vp, vp, vp, ci, ci, ci, cf, vp, vp]),
     "ign_standardise_nct_to_btc": (ci, [vp, vp, vp, ci, ci, ci, cf, vp]),
     "ign_shapelet_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),
     "ign_shapelet_fwd_bank": (ci, [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, cf, ci, vp]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "ign_bn_finalize_fwd": (ci, [vp, ci, ll, ci, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp, vp]),
     "ign_bn_affine_eval": (ci, [vp, vp, vp, vp, cf, ci, vp, vp, vp, vp, vp]),
     "ign_bn_relu_pool_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, vp]),
+    "ign_bn_relu_pool_head_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "ign_bn_relu_pool_bwd_parts": (ll, [ci, ci]),
     "ign_bn_relu_pool_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     "ign_bn_finalize_bwd": (ci, [vp, ci, ci, vp, vp, vp]),
@@ -99,7 +101,7 @@ SIGNATURES = {
     "ign_clconv_wgrad_reduce_multi": (ci, [ci, vp, vp, vp, vp, vp, vp, vp]),
     "ign_clconv_pack_weights_x3_multi": (ci, [ci, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ign_absmax": (ci, [vp, ll, vp, vp]),
-    "ign_fcn_scan": (ci, [ci, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ign_fcn_scan": (ci, [ci, vp, vp, vp, vp, vp, vp, vp, vp, ll, vp]),
     "ign_clconv_pack_weights_h2_multi": (ci, [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ign_clconv_fwd_h3": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ign_clconv_fwd_h3_amax": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
@@ -120,6 +122,22 @@ SIGNATURES = {
 
 class IgnError(RuntimeError):
     pass
+
+
+_RAW_STREAM = None
+
+
+def stream():
+    """hipStream_t of torch's current stream on the current device, as the `stream` argument of the entry points.
+    `torch.cuda.current_stream()` builds a Python Stream object each time (~9 us: 19 calls = 0.18 ms of a 0.9 ms step at
+    run_uea.sh's batch 32); the raw getter behind it returns the handle in well under a microsecond."""
+    global _RAW_STREAM
+    import torch
+    if _RAW_STREAM is None:
+        _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _RAW_STREAM:
+        return ctypes.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def lib_path():

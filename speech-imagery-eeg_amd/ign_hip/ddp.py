@@ -38,6 +38,9 @@ class FlatParamBucket:
                 raise ValueError("all parameters must share one device and dtype")
             self.views.append(self.flat_grad[off:off + p.numel()].view_as(p))
             p.grad = None if self.flat_grad.is_cuda else self.views[-1]
+        # slots that may hold something other than zeros (`gather`): the buffer starts zero-filled, and a parameter that gets no
+        # gradient step after step (three of the IGN model's) needs no fill kernel per step to keep its slot at zero
+        self._dirty = [False] * len(self.params)
         self.module = module
 
     @property
@@ -57,16 +60,22 @@ class FlatParamBucket:
         On the GPU ``zero_grad`` leaves ``p.grad = None``, so autograd hands every parameter a fresh gradient tensor (no
         accumulate kernel); one ``ign_gather_flat`` launch copies them all into their slots and ``p.grad`` is pointed back
         at the slot, so clipping, the all-reduce and the optimizer see one buffer.  Parameters whose ``.grad`` already is
-        the slot view (CPU path, or a second call) are left alone; parameters without a gradient get zeros."""
+        the slot view (CPU path, or a second call) are left alone; parameters without a gradient get zeros -- by a fill only when
+        their slot was written since it was last zero (the buffer starts zero-filled; scaling by clipping or averaging keeps
+        zeros zero)."""
         todo = []
-        for p, off, view in zip(self.params, self.offsets, self.views):
+        for i, (p, off, view) in enumerate(zip(self.params, self.offsets, self.views)):
             g = p.grad
             if g is view:
+                self._dirty[i] = True                    # written in place by autograd (CPU path) or by the caller
                 continue
             if g is None:
-                view.zero_()
+                if self._dirty[i]:
+                    view.zero_()
+                    self._dirty[i] = False
             else:
                 todo.append((g.contiguous(), off, view))
+                self._dirty[i] = True
             p.grad = view
         if not todo:
             return
@@ -81,7 +90,7 @@ class FlatParamBucket:
         off = (ctypes.c_longlong * n)(*[o for _, o, _ in todo])
         cnt = (ctypes.c_longlong * n)(*[g.numel() for g, _, _ in todo])
         _lib.check(_lib.lib().ign_gather_flat(src, off, cnt, n, ctypes.c_void_p(self.flat_grad.data_ptr()),
-                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ign_gather_flat")
+                                              _lib.stream()), "ign_gather_flat")
 
     def allreduce(self):
         """Average the gradients over ranks: one collective on the flat bucket."""
@@ -168,12 +177,12 @@ class FlatAdam(torch.optim.Optimizer):
             self._lib.check(self._lib.lib().ign_adam_step_dev(
                 ptr(self.flat_param), ptr(self.bucket.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
                 self.flat_param.numel(), g["lr"], g["betas"][0], g["betas"][1], g["eps"], ptr(self.step_dev), ptr(self.bc_dev),
-                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ign_adam_step_dev")
+                self._lib.stream()), "ign_adam_step_dev")
             return loss
         self._lib.check(self._lib.lib().ign_adam_step(
             ptr(self.flat_param), ptr(self.bucket.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
             self.flat_param.numel(), g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count,
-            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ign_adam_step")
+            self._lib.stream()), "ign_adam_step")
         return loss
 
     def zero_grad(self, set_to_none=False):

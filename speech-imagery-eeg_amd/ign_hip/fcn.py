@@ -36,8 +36,17 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = _lib.stream
+
+
+def _attached_bound(t):
+    """ops.cached_bound without importing ops (which imports this module)."""
+    cb = getattr(t, "_ign_bound", None)
+    if cb is None or cb[1] != t._version or cb[2] != t.data_ptr():
+        return None
+    if torch.cuda.is_current_stream_capturing() and not (len(cb) > 3 and cb[3]):
+        return None
+    return cb[0]
 
 
 class BnState:
@@ -70,7 +79,10 @@ class FcnBodyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, states_math, *params):
         L = _lib.lib()
-        states, math = states_math
+        states, math, has_head = states_math
+        head_w, head_b = (params[-2], params[-1]) if has_head else (None, None)
+        if has_head:
+            params = params[:-2]
         if not x.is_cuda or x.dtype != torch.float32:
             raise _lib.IgnError(f"fcn_body: needs a float32 GPU tensor, got {x.dtype} on {x.device} (no CPU fallback)")
         x = x.contiguous()
@@ -78,13 +90,13 @@ class FcnBodyFn(torch.autograd.Function):
         nl = len(params) // 4
         dev = x.device
         f32 = dict(device=dev, dtype=torch.float32)
-        need_grad = any(ctx.needs_input_grad[2:])
+        need_grad = any(ctx.needs_input_grad[2:2 + len(params)])
         if math == "f16x3" and not (all(st.use_batch_stats for st in states) and nl <= 8):
             math = "bf16x6"           # running statistics: no hard bound on the normalised activations
         h3 = math == "f16x3"
         x6 = math in ("bf16x6", "bf16", "f16x3")
         conv_fwd = L.ign_clconv_fwd_bf16 if math == "bf16" else L.ign_clconv_fwd_x6
-        slots = None
+        slots = zbuf = xbound = None
         fp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off)        # address of float `off` of a float32 tensor
         inputs, affine, wds, shapes = [x], [], [], []
         pa = pb = None
@@ -112,10 +124,19 @@ class FcnBodyFn(torch.autograd.Function):
                 for w in ws_:
                     T_ = T_ - w.shape[2] + 1
                     Touts.append(T_)
+                # (the same launch clears the buffer the backward returns as the convolution biases' gradients: a bias in front of
+                # a batch-statistics BatchNorm has an identically zero gradient -- the batch mean removes it)
+                zbuf = torch.empty(sum(w.shape[0] for w in ws_), **f32) if need_grad else None
                 _lib.check(L.ign_fcn_scan(nl, pv(ws_), lla(*[w.numel() for w in ws_]), pv(gam), pv(bet),
                                           ia(*([0] + [ws_[l - 1].shape[0] for l in range(1, nl)])),
-                                          lla(*([0] + [B * Touts[l - 1] for l in range(1, nl)])), _ptr(slots), _stream()), "ign_fcn_scan")
-                _lib.check(L.ign_absmax(_ptr(x), x.numel(), fp(slots, 1), _stream()), "ign_absmax")
+                                          lla(*([0] + [B * Touts[l - 1] for l in range(1, nl)])), _ptr(slots), _ptr(zbuf),
+                                          zbuf.numel() if zbuf is not None else 0, _stream()), "ign_fcn_scan")
+                # max |x|: attached to the tensor by a producer that had the batch in its hands (ops.instance_norm when both
+                # experts share a stream), else one pass over x
+                xbound = _attached_bound(x)
+                if xbound is None:
+                    _lib.check(L.ign_absmax(_ptr(x), x.numel(), fp(slots, 1), _stream()), "ign_absmax")
+                    xbound = slots[1:2]
                 _lib.check(L.ign_clconv_pack_weights_h2_multi(nl, pv(ws_), pv(wts), pv(wds_), *dims, bump_tab,
                                                               vpa(*[slots.data_ptr() + 16 * l for l in range(nl)]), _stream()),
                            "ign_clconv_pack_weights_h2_multi")
@@ -149,8 +170,9 @@ class FcnBodyFn(torch.autograd.Function):
                     _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt), _ptr(wd), Co, Ci, k, _stream()),
                                "ign_clconv_pack_weights_x3")
                 if h3:
-                    _lib.check(L.ign_clconv_fwd_h3(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part), fp(slots, 4 * l + 1),
-                                                   fp(slots, 4 * l), B, Tin, Ci, Co, k, _stream()), "ign_clconv_fwd_h3")
+                    _lib.check(L.ign_clconv_fwd_h3(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part),
+                                                   fp(slots, 4 * l + 1) if l else _ptr(xbound), fp(slots, 4 * l), B, Tin, Ci, Co, k,
+                                                   _stream()), "ign_clconv_fwd_h3")
                 else:
                     _lib.check(conv_fwd(_ptr(h), _ptr(wt), _ptr(b), _ptr(pa), _ptr(pb), _ptr(y), _ptr(part), B, Tin, Ci, Co, k,
                                         _stream()), "ign_clconv_fwd_x6")
@@ -177,10 +199,27 @@ class FcnBodyFn(torch.autograd.Function):
         y_last = inputs[-1]
         Cl, Tl = y_last.shape[2], y_last.shape[1]
         pooled = torch.empty(B, Cl, **f32)
-        _lib.check(L.ign_bn_relu_pool_fwd(_ptr(y_last), _ptr(pa), _ptr(pb), _ptr(pooled), B, Tl, Cl, _stream()),
-                   "ign_bn_relu_pool_fwd")
-        ctx.saved = (inputs, affine, wds, shapes, [st.use_batch_stats for st in states], math, slots) if need_grad else None
-        return pooled
+        head = None
+        if has_head:
+            # the class head in the pooling launch (a sample's pooled row is complete inside its block)
+            head_w = head_w.contiguous()
+            N = head_w.shape[0]
+            if head_w.shape[1] != Cl or head_w.dtype != torch.float32:
+                raise _lib.IgnError(f"fcn_body: head weight {tuple(head_w.shape)} {head_w.dtype} does not fit {Cl} pooled channels")
+            out = torch.empty(B, N, **f32)
+            _lib.check(L.ign_bn_relu_pool_head_fwd(_ptr(y_last), _ptr(pa), _ptr(pb), _ptr(pooled), _ptr(head_w), _ptr(head_b), _ptr(out),
+                                                   B, Tl, Cl, N, _stream()), "ign_bn_relu_pool_head_fwd")
+            head = (pooled, head_w, head_b is not None)
+        else:
+            out = pooled
+            _lib.check(L.ign_bn_relu_pool_fwd(_ptr(y_last), _ptr(pa), _ptr(pb), _ptr(pooled), B, Tl, Cl, _stream()),
+                       "ign_bn_relu_pool_fwd")
+        ctx.head = head
+        ctx.head_needs = tuple(ctx.needs_input_grad[-2:]) if has_head else None
+        ctx.saved = (inputs, affine, wds, shapes, [st.use_batch_stats for st in states], math, slots, zbuf, xbound) \
+            if (need_grad or (has_head and any(ctx.head_needs))) else None
+        ctx.body_grad = need_grad
+        return out
 
     @staticmethod
     def backward(ctx, gpool):
@@ -189,7 +228,7 @@ class FcnBodyFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise _lib.IgnError("fcn_body: gradient w.r.t. the input series is not implemented (inputs are data)")
         L = _lib.lib()
-        inputs, affine, wds, shapes, batch_stats, math, slots = ctx.saved
+        inputs, affine, wds, shapes, batch_stats, math, slots, zbuf, xbound = ctx.saved
         h3 = math == "f16x3"
         x6 = math in ("bf16x6", "bf16", "f16x3")
         fp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off)
@@ -198,6 +237,21 @@ class FcnBodyFn(torch.autograd.Function):
         dev = gpool.device
         f32 = dict(device=dev, dtype=torch.float32)
         gpool = gpool.contiguous()
+        head_grads = ()
+        if ctx.head is not None:
+            # gpool is the gradient of the LOGITS here: head backward first (pooled-row gradient, weight and bias gradients, one launch)
+            pooled, head_w, has_b = ctx.head
+            N, Cl = head_w.shape
+            glog = gpool
+            gpool = torch.empty(B, Cl, **f32)
+            ghw = torch.empty_like(head_w)
+            ghb = torch.empty(N, **f32) if has_b else None
+            _lib.check(L.ign_head_bwd(_ptr(glog), _ptr(pooled), _ptr(head_w), _ptr(gpool), _ptr(ghw), _ptr(ghb), B, Cl, N, Cl, _stream()),
+                       "ign_head_bwd")
+            head_grads = (ghw if ctx.head_needs[0] else None, ghb if ctx.head_needs[1] else None)
+            if not ctx.body_grad:
+                ctx.saved = None
+                return (None, None, *([None] * (4 * nl)), *head_grads)
         grads = [None] * (4 * nl)
         # The bias in front of a batch-statistics BatchNorm has an identically zero gradient (the batch mean removes it): the
         # zeros of all blocks are views of ONE buffer (one fill launch)
@@ -205,7 +259,8 @@ class FcnBodyFn(torch.autograd.Function):
         for (Co_, _, _, _, _), bs_ in zip(shapes, batch_stats):
             zoff.append(ztot)
             ztot += Co_ if bs_ else 0
-        zbuf = torch.zeros(ztot, **f32) if ztot else None
+        if zbuf is None or zbuf.numel() != ztot:      # (the fp16 path's forward prologue has cleared one of the right size)
+            zbuf = torch.zeros(ztot, **f32) if ztot else None
 
         # last block: pool -> ReLU mask -> BatchNorm-backward sums
         Co, Ci, k, Tin, Tout = shapes[-1]
@@ -244,7 +299,7 @@ class FcnBodyFn(torch.autograd.Function):
             wgrad = (L.ign_clconv_wgrad_bf16 if math == "bf16" else L.ign_clconv_wgrad_x6) if wx6 else L.ign_clconv_wgrad
             if h3 and wx6:
                 _lib.check(L.ign_clconv_wgrad_h3(_ptr(dyp), pad, _ptr(inputs[l]), _ptr(pa), _ptr(pb), None if defer else _ptr(dw), _ptr(ws),
-                                                 fp(slots, 4 * l + 2), fp(slots, 4 * l + 1), B, Tin, Ci, Co, k, _stream()),
+                                                 fp(slots, 4 * l + 2), fp(slots, 4 * l + 1) if l else _ptr(xbound), B, Tin, Ci, Co, k, _stream()),
                            "ign_clconv_wgrad_h3")
             else:
                 _lib.check(wgrad(_ptr(dyp), pad, _ptr(inputs[l]), _ptr(pa), _ptr(pb), None if defer else _ptr(dw), _ptr(ws), B, Tin,
@@ -279,12 +334,14 @@ class FcnBodyFn(torch.autograd.Function):
                                                        ia(*[d[4] for d in deferred]), ia(*[d[5] for d in deferred]), _stream()),
                        "ign_clconv_wgrad_reduce_multi")
         ctx.saved = None
-        return (None, None, *grads)
+        return (None, None, *grads, *head_grads)
 
 
-def fcn_body(x, blocks, math=None):
+def fcn_body(x, blocks, math=None, head=None):
     """x (B,T,C) float32 on the GPU; blocks = [(conv1d, batchnorm1d), ...] -> pooled (B, C_last).
-    `math`: arithmetic of the GEMMs (see CONV_MATH); default = "bf16" inside an autocast region, else CONV_MATH."""
+    `math`: arithmetic of the GEMMs (see CONV_MATH); default = "bf16" inside an autocast region, else CONV_MATH.
+    `head`: an nn.Linear over the pooled channels (<= 16 outputs) -> its logits (B, N) are returned instead, computed by the
+    pooling launch."""
     if math is None:
         math = "bf16" if torch.is_autocast_enabled() else CONV_MATH
     states = [BnState(bn) for _, bn in blocks]            # (the step counters are bumped by the node's prologue launch)
@@ -295,4 +352,9 @@ def fcn_body(x, blocks, math=None):
         if conv.stride != (1,) or conv.padding != (0,) or conv.dilation != (1,) or conv.groups != 1:
             raise _lib.IgnError("fcn_body: only stride-1, unpadded, undilated, ungrouped Conv1d is implemented")
         params += [conv.weight, conv.bias, bn.weight, bn.bias]
-    return FcnBodyFn.apply(x, (states, math), *params)
+    if head is not None:
+        if head.weight.shape[0] > 16:
+            raise _lib.IgnError("fcn_body: the fused head covers up to 16 outputs")
+        # (a head without bias passes a None placeholder: autograd.Function accepts non-tensor inputs)
+        return FcnBodyFn.apply(x, (states, math, True), *params, head.weight, head.bias)
+    return FcnBodyFn.apply(x, (states, math, False), *params)

@@ -19,8 +19,7 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = _lib.stream
 
 
 def _need_gpu(name, *ts):
@@ -34,15 +33,23 @@ def _need_gpu(name, *ts):
             raise _lib.IgnError(f"{name}: expected float32, got {t.dtype}")
 
 
-def instance_norm(x_btc, want_raw=False, eps=1e-8):
-    """(B,T,C) -> normalised (B,C,T) [+ raw transpose].  Replaces IGN/model/Shapelet.py:186-187."""
+def instance_norm(x_btc, want_raw=False, eps=1e-8, input_bound=False):
+    """(B,T,C) -> normalised (B,C,T) [+ raw transpose].  Replaces IGN/model/Shapelet.py:186-187.
+    `input_bound`: also attach max |x| to `x_btc` (see cached_bound) for a consumer of the raw batch."""
     _need_gpu("instance_norm", x_btc)
     x = x_btc.contiguous()
     B, T, C = x.shape
     xn = torch.empty(B, C, T, device=x.device, dtype=torch.float32)
     xt = torch.empty_like(xn) if want_raw else None
     L = _lib.lib()
-    _lib.check(L.ign_instnorm_fwd(_ptr(x), _ptr(xn), _ptr(xt), B, T, C, eps, _stream()), "ign_instnorm_fwd")
+    if input_bound and cached_bound(x_btc) is None:
+        # the raw batch is staged in LDS by this pass anyway: take max |x| here, for the FCN expert's first fp16 GEMM
+        # (ign_hip/fcn.py looks the bound up on the tensor) instead of a separate pass over x
+        slot = _new_slot(x.device)
+        _lib.check(L.ign_instnorm_fwd_amax(_ptr(x), _ptr(xn), _ptr(xt), B, T, C, eps, _ptr(slot), _stream()), "ign_instnorm_fwd_amax")
+        set_bound(x_btc, slot)
+    else:
+        _lib.check(L.ign_instnorm_fwd(_ptr(x), _ptr(xn), _ptr(xt), B, T, C, eps, _stream()), "ign_instnorm_fwd")
     return xn, xt
 
 
@@ -177,6 +184,7 @@ class ShapeletBankFn(torch.autograd.Function):
         P, D, saved = _bank_forward(xn, ws, thrs, eps, mode, strides, need_grad)
         Tstar = _cat_tstar(saved, xn.shape[0])
         ctx.mark_non_differentiable(D, Tstar)
+        ctx.set_materialize_grads(False)              # (else autograd fills a zero tensor per unused output, one launch each)
         ctx.meta = (float(eps), int(mode), n_groups, saved, need_grad)
         ctx.save_for_backward(xn, P, D, *ws, *[t for t in thrs if t is not None])
         return P, D, Tstar
@@ -188,6 +196,8 @@ class ShapeletBankFn(torch.autograd.Function):
             raise _lib.IgnError("shapelet backward called but the forward ran without saving distances")
         xn, P, D = ctx.saved_tensors[:3]
         ws = ctx.saved_tensors[3:3 + G]
+        if gP is None:
+            return (None,) * (5 + G + (G if mode & GATE_LTS else 0))
         gP = gP.contiguous()
         grads_w = _bank_backward(xn, ws, gP, P, D, saved, eps, mode)
         grads_t = _threshold_grads(gP, P, ws, saved, xn.shape[1]) if mode & GATE_LTS else []
@@ -491,6 +501,20 @@ def _new_slot(device):
     return pool[0][i:i + 1]
 
 
+def cached_bound(t):
+    """The bound attached to `t` (one-element device tensor) if it still describes the tensor's contents, else None.  A bound
+    that was MEASURED from the data in an earlier call (ign_absmax, ign_instnorm_fwd_amax) is not trusted while a hipGraph is
+    being captured: the capture would bake in 'already known' and replay the example batch's bound for every later batch
+    (GraphedTrainStep refills the same input tensors).  Bounds attached by a producer inside the captured region carry the
+    flag `in_graph` and stay valid -- their kernels are part of the graph."""
+    cb = getattr(t, "_ign_bound", None)
+    if cb is None or cb[1] != t._version or cb[2] != t.data_ptr():
+        return None
+    if torch.cuda.is_current_stream_capturing() and not (len(cb) > 3 and cb[3]):
+        return None
+    return cb[0]
+
+
 def tensor_bound(t):
     """A one-element device tensor holding an upper bound of max |t| -- what the fp16 GEMMs scale their operands by.  A producer
     that knows a bound attaches it (`set_bound`: LayerNorm's hard bound from its parameters); otherwise ONE pass over the tensor
@@ -498,16 +522,16 @@ def tensor_bound(t):
     # Parameters are never cached: the flat Adam kernel (ign_adam_step) rewrites them through raw pointers, which does not move
     # the version counter a cache entry is validated by -- a stale bound would let a weight that has grown overflow fp16.
     param = t.is_leaf and t.requires_grad
-    cached = None if param else getattr(t, "_ign_bound", None)
-    if cached is not None and cached[1] == t._version and cached[2] == t.data_ptr():
-        return cached[0]
+    cached = None if param else cached_bound(t)
+    if cached is not None:
+        return cached
     base = None if param else getattr(t, "_base", None)
     if base is not None and (base.is_leaf and base.requires_grad):
         base = None
     if base is not None and base.numel() == t.numel():       # a reshaped view of a tensor whose producer attached a bound
-        cb = getattr(base, "_ign_bound", None)
-        if cb is not None and cb[1] == base._version and cb[2] == base.data_ptr():
-            return cb[0]
+        cb = cached_bound(base)
+        if cb is not None:
+            return cb
     if not t.is_contiguous():
         base = getattr(t, "_base", None)
         if base is not None and base.is_contiguous() and base.dtype == t.dtype and base.numel() <= 4 * t.numel():
@@ -516,25 +540,25 @@ def tensor_bound(t):
     slot = _new_slot(t.device)
     _lib.check(_lib.lib().ign_absmax(_ptr(tc), tc.numel(), _ptr(slot), _stream()), "ign_absmax")
     if not param:
-        try:
-            t._ign_bound = (slot, t._version, t.data_ptr())
-        except Exception:
-            pass
+        set_bound(t, slot)
     return slot
 
 
 def set_bound(t, slot):
-    """Attach a known magnitude bound (one-element device tensor) to `t`; see tensor_bound."""
-    t._ign_bound = (slot, t._version, t.data_ptr())
+    """Attach a known magnitude bound (one-element device tensor) to `t`; see tensor_bound / cached_bound."""
+    try:
+        t._ign_bound = (slot, t._version, t.data_ptr(), torch.cuda.is_current_stream_capturing())
+    except Exception:
+        pass
     return t
 
 
 def keep_bound(out, src, factor=1.0):
     """`out` = f(src) element-wise with |f(u)| <= factor |u| (ReLU, GELU: factor 1): `out` inherits src's magnitude bound, if
     src carries one, instead of being scanned when a dense layer consumes it."""
-    cb = getattr(src, "_ign_bound", None)
-    if cb is not None and cb[1] == src._version and cb[2] == src.data_ptr() and factor == 1.0:
-        set_bound(out, cb[0])
+    cb = cached_bound(src) if factor == 1.0 else None
+    if cb is not None:
+        set_bound(out, cb)
     return out
 
 
@@ -589,10 +613,13 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2)
         ctx.wd3, ctx.dims, ctx.has_bias, ctx.xshape = wd3, (M, Ci, Co), bias is not None, x.shape
         ctx.mark_non_differentiable(*([yb] if yb is not None else []))
+        ctx.set_materialize_grads(False)              # no zero-filled "gradient" of the bound output per backward call
         return y, yb
 
     @staticmethod
     def backward(ctx, gy, _gyb=None):
+        if gy is None:
+            return None, None, None
         L = _lib.lib()
         (x2,) = ctx.saved_tensors
         M, Ci, Co = ctx.dims
@@ -705,7 +732,7 @@ def layer_norm(x, norm):
         slots = torch.empty(4, device=x.device, dtype=torch.float32)
         v1, i1, l1 = ctypes.c_void_p * 1, ctypes.c_int * 1, ctypes.c_longlong * 1
         wp, bp = norm.weight.data_ptr(), norm.bias.data_ptr()
-        _lib.check(_lib.lib().ign_fcn_scan(1, v1(wp), l1(D), v1(wp), v1(bp), i1(D), l1(max(D, 2)), _ptr(slots), _stream()), "ign_fcn_scan")
+        _lib.check(_lib.lib().ign_fcn_scan(1, v1(wp), l1(D), v1(wp), v1(bp), i1(D), l1(max(D, 2)), _ptr(slots), None, 0, _stream()), "ign_fcn_scan")
         set_bound(out, slots[1:2])
     return out
 
@@ -826,6 +853,7 @@ class GiniGateFn(torch.autograd.Function):
         _lib.check(_lib.lib().ign_gate_fwd(_ptr(sbm), _ptr(dnn), _ptr(out), _ptr(eta), B, N, gv, use, _stream()), "ign_gate_fwd")
         ctx.save_for_backward(sbm, dnn)
         ctx.gv = (use, gv)
+        ctx.set_materialize_grads(False)              # eta usually carries no gradient: no zero fill for it
         return out, eta
 
     @staticmethod
@@ -834,6 +862,9 @@ class GiniGateFn(torch.autograd.Function):
         B, N = sbm.shape
         use, gv = ctx.gv
         gs, gd = torch.empty_like(sbm), torch.empty_like(dnn)
+        if gout is None and geta is None:
+            return None, None, None
+        gout = torch.zeros_like(sbm) if gout is None else gout
         geta = geta.contiguous() if geta is not None else None
         _lib.check(_lib.lib().ign_gate_bwd(_ptr(sbm), _ptr(dnn), _ptr(gout.contiguous()), _ptr(geta), _ptr(gs), _ptr(gd), B, N,
                                            gv, use, _stream()), "ign_gate_bwd")
@@ -886,10 +917,13 @@ class IgnLossFn(torch.autograd.Function):
         ctx.save_for_backward(gsd)
         ctx.reg_shape = None if reg is None else tuple(reg.shape)
         ctx.mark_non_differentiable(out, eta)
+        ctx.set_materialize_grads(False)              # no zero-filled "gradients" of the two reporting outputs per step
         return loss2[2], out, eta
 
     @staticmethod
     def backward(ctx, gl, gout, geta):
+        if gl is None:
+            return None, None, None, None, None
         (gsd,) = ctx.saved_tensors
         unit = _UNIT.get(gl.device)
         # the root gradient of ops.backward(): exactly 1 -- no scaling launch; otherwise one launch for both logit gradients

@@ -30,6 +30,8 @@ class FullyConvNetwork(nn.Module):
         # x (B,T,C) is already the channels-last operand of the implicit GEMM: no transpose, no im2col.  The kernels take fp32
         # activations (inside an autocast region they round the GEMM operands to bf16 themselves): other dtypes are cast, never
         # handed to a library convolution
-        pooled = fcn.fcn_body(x if x.dtype == torch.float32 else x.float(),
-                              [(b[0], b[1]) for b in (self.block1, self.block2, self.block3)])
-        return ops.head_linear(pooled, self.fc.weight, self.fc.bias)
+        x = x if x.dtype == torch.float32 else x.float()
+        blocks = [(b[0], b[1]) for b in (self.block1, self.block2, self.block3)]
+        if self.fc.weight.shape[0] <= 16 and not torch.is_autocast_enabled():
+            return fcn.fcn_body(x, blocks, head=self.fc)            # class head inside the pooling launch
+        return ops.head_linear(fcn.fcn_body(x, blocks), self.fc.weight, self.fc.bias)

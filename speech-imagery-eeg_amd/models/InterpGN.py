@@ -63,8 +63,12 @@ class InterpGN(nn.Module):
 
     def _experts(self, x, x_mark_enc, x_dec, x_mark_dec, mask):
         if not (self.expert_streams and x.is_cuda and x.numel() >= self.two_stream_min_elems):
+            # one stream, SBM first: its instance-norm pass hands the FCN expert the magnitude bound of the raw batch
+            self.sbm.input_bound = isinstance(self.deep_model, FullyConvNetwork) and x.is_cuda and x.dtype == torch.float32 \
+                and not torch.is_autocast_enabled()
             sbm_out, info = self.sbm(x)
             return sbm_out, info, self.deep_model(x, x_mark_enc, x_dec, x_mark_dec, mask)
+        self.sbm.input_bound = False                # two streams: the FCN expert is enqueued first and scans x itself
         main = torch.cuda.current_stream(x.device)
         side = _SIDE_STREAMS.get(x.device)
         if side is None:

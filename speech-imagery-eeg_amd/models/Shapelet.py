@@ -125,13 +125,17 @@ class ShapeBottleneckModel(nn.Module):
         self.lambda_reg = configs.lambda_reg
         self.lambda_div = configs.lambda_div
 
+    # set by InterpGN when a deep expert on the same stream consumes the raw batch through the fp16 GEMMs: the instance-norm
+    # pass then also takes max |x| (ops.instance_norm), which spares that expert a pass of its own
+    input_bound = False
+
     # -- hot path ---------------------------------------------------------------------------------
     def shapelet_features(self, x, xn=None):
         """x (B,T,C) on the GPU -> (p, d_min) of every group, concatenated in the reference's order.
         `xn`: the instance-normalised (B,C,T) tensor if the caller already ran ign_instnorm_fwd (InterpGN does, to
         share the transpose with the FCN expert)."""
         if xn is None:
-            xn, _ = ops.instance_norm(x)
+            xn, _ = ops.instance_norm(x, input_bound=self.input_bound)
         first = self.shapelets[0]
         thr = [s.threshold for s in self.shapelets] if first.gate == ops.GATE_LTS else None
         return ops.shapelet_bank(xn, [s.weights for s in self.shapelets], first.eps, first.mode(),
@@ -156,7 +160,7 @@ class ShapeBottleneckModel(nn.Module):
                 or x.dtype != torch.float32:
             return None
         if xn is None:
-            xn, _ = ops.instance_norm(x)
+            xn, _ = ops.instance_norm(x, input_bound=self.input_bound)
         lts = first.gate == ops.GATE_LTS
         fuse_head = self.configs.sbm_cls == 'linear' and (self.dropout.p == 0.0 or not self.training) \
             and self.total_shapelets % 4 == 0          # the streaming head kernel reads float4 rows (else: ops.head_linear's route)

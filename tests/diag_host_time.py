@@ -1,32 +1,60 @@
-"""Diagnostic: host issue time of one IGN step (time until step() returns with an empty GPU queue in front of it)."""
-import os, sys, time
+"""Diagnostic: host issue time of one IGN step (time until step() returns with an empty GPU queue in front of it) and a cProfile
+of the host side.   python tests/diag_host_time.py [bm|ch] [batch]"""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import speech_imagery_eeg_amd  # noqa
 from conftest import make_cfg
 from ign_hip import ops as ign_ops
 from ign_hip.ddp import FlatAdam, FlatParamBucket
 from models.InterpGN import InterpGN
+
+shape = sys.argv[1] if len(sys.argv) > 1 else "bm"
+C, T, NC = (6, 100, 4) if shape == "bm" else (122, 1000, 3)
+B = int(sys.argv[2]) if len(sys.argv) > 2 else (32 if shape == "bm" else 256)
 dev = torch.device("cuda:0")
-cfg = make_cfg(enc_in=122, seq_len=1000, num_class=3)
+cfg = make_cfg(enc_in=C, seq_len=T, num_class=NC)
 torch.manual_seed(0)
 m = InterpGN(cfg).to(dev).train()
-bucket = FlatParamBucket(m, 1); opt = FlatAdam(bucket, lr=5e-3)
-x = torch.randn(256, 1000, 122, device=dev); y = torch.randint(0, 3, (256,), device=dev); mask = torch.ones(256, 1000, device=dev)
+bucket = FlatParamBucket(m, 1)
+opt = FlatAdam(bucket, lr=5e-3)
+x = torch.randn(B, T, C, device=dev)
+y = torch.randint(0, NC, (B,), device=dev)
+mask = torch.ones(B, T, device=dev)
+
+
 def step():
     out, info = m(x, mask, None, None)
-    loss = ign_ops.ign_loss(info.shapelet_preds, info.dnn_preds, y, 1.0)[0] + info.loss.mean()
-    loss.backward(); opt.step(); bucket.zero_grad()
-for _ in range(5): step()
+    loss = ign_ops.ign_loss(info.shapelet_preds, info.dnn_preds, y, 1.0, reg=info.loss)[0]
+    ign_ops.backward(loss)
+    opt.step()
+    bucket.zero_grad()
+
+
+for _ in range(20):
+    step()
 torch.cuda.synchronize()
 hs, ts = [], []
-for _ in range(10):
+for _ in range(50):
     torch.cuda.synchronize(); t0 = time.perf_counter(); step(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     hs.append((t1 - t0) * 1e3); ts.append((t2 - t0) * 1e3)
-print("host issue time per step: %.2f ms (min %.2f); step wall with sync %.2f ms" % (sum(hs) / len(hs), min(hs), sum(ts) / len(ts)))
-import cProfile, pstats
+print("host issue time per step: %.3f ms (min %.3f); step wall with sync %.3f ms" % (sum(hs) / len(hs), min(hs), sum(ts) / len(ts)))
+t0 = time.perf_counter()
+for _ in range(200):
+    step()
+torch.cuda.synchronize()
+print("200 back-to-back steps: %.3f ms/step" % ((time.perf_counter() - t0) * 1e3 / 200))
 pr = cProfile.Profile(); torch.cuda.synchronize(); pr.enable()
-for _ in range(5): step()
+for _ in range(50):
+    step()
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(28)
+st.sort_stats("cumtime").print_stats(40)

@@ -144,3 +144,35 @@ def test_one_rank_rccl_allreduce_between_backward_and_adam_is_bitwise_neutral(tm
     mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
     res = torch.load(out, weights_only=True)
     assert res["backend"] == "nccl" and res["same"] and res["n"] > 10
+
+
+def test_flat_bucket_keeps_slots_of_gradient_free_parameters_at_zero_without_a_fill_per_step():
+    """`FlatParamBucket.gather` zero-fills the slot of a parameter without a gradient only when the slot was written since it was
+    last zero: a parameter used in step 1 and unused in step 2 must read zeros in step 2, one that never gets a gradient costs
+    no fill kernel at all."""
+    if not has_gpu():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, os.path.join(ROOT, "speech-imagery-eeg_amd"))
+    from ign_hip.ddp import FlatParamBucket
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.ones(7))
+            self.b = torch.nn.Parameter(torch.ones(5))
+            self.never = torch.nn.Parameter(torch.ones(3))
+
+        def forward(self, use_b):
+            return (self.a * 2).sum() + ((self.b * 3).sum() if use_b else 0.0)
+
+    m = M().cuda()
+    bucket = FlatParamBucket(m, 1)
+    for use_b, want_b in ((True, 3.0), (False, 0.0), (False, 0.0), (True, 3.0)):
+        m(use_b).backward()
+        bucket.gather()
+        assert torch.equal(m.a.grad, torch.full((7,), 2.0, device="cuda"))
+        assert torch.equal(m.b.grad, torch.full((5,), want_b, device="cuda")), (use_b, m.b.grad)
+        assert torch.equal(m.never.grad, torch.zeros(3, device="cuda"))
+        assert m.b.grad.data_ptr() == bucket.views[1].data_ptr()
+        bucket.zero_grad()
+    assert bucket._dirty == [True, True, False]

@@ -426,8 +426,8 @@ def test_backward_with_the_cached_unit_gradient_equals_loss_backward():
 
 
 def test_ign_step_launch_count():
-    """Round-3 budget: one IGN(FCN) training step (forward, fused loss, backward, flat Adam) issues at most 48 GPU kernels
-    (round 2: ~130); counted with torch.profiler, per-kernel breakdown in the assertion message."""
+    """Round-3 budget: one IGN(FCN) training step (forward, fused loss, backward, flat Adam) at run_uea.sh's batch 32 issues at
+    most 40 GPU kernels (round 2: ~130); counted with torch.profiler, per-kernel breakdown in the assertion message."""
     dev = _dev()
     import speech_imagery_eeg_amd  # noqa
     from ign_hip import ops
@@ -470,12 +470,15 @@ def test_ign_step_launch_count():
     os.makedirs(os.path.join(os.path.dirname(__file__), "..", "gpurun_out"), exist_ok=True)
     json.dump({"per_step": per_step, "by_kernel": {k: v / n for k, v in sorted(names.items(), key=lambda kv: -kv[1])}},
               open(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "ign_step_launches.json"), "w"), indent=1)
-    assert per_step <= 48, f"{per_step} launches per step: " + ", ".join(f"{k[:40]} x{v / n:g}" for k, v in names.items())
+    assert per_step <= 40, f"{per_step} launches per step: " + ", ".join(f"{k[:40]} x{v / n:g}" for k, v in names.items())
 
 
-def test_graphed_train_step_equals_eager():
-    """One IGN step (two expert streams, fused loss tail, backward, capturable flat Adam) captured as a hipGraph and replayed
-    must walk the same parameter trajectory as the eager step."""
+@pytest.mark.parametrize("scales", [(1.0, 1.0, 1.0, 1.0), (1.0, 40.0, 3e3, 2e5)], ids=["same magnitude", "growing magnitude"])
+def test_graphed_train_step_equals_eager(scales):
+    """One IGN step (fused loss tail, backward, capturable flat Adam) captured as a hipGraph and replayed must walk the same
+    parameter trajectory as the eager step.  'growing magnitude': the replayed batches are up to 2e5 times larger than the
+    example batch the graph was captured on -- the magnitude bound of the raw input (fp16 GEMM scaling) has to be taken INSIDE
+    the graph for every batch; a bound remembered from the warm-up steps would overflow fp16 here."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     dev = torch.device("cuda:0")
@@ -489,7 +492,7 @@ def test_graphed_train_step_equals_eager():
     torch.manual_seed(0)
     base = InterpGN(cfg)
     g = torch.Generator().manual_seed(5)
-    xs = [torch.randn(8, 100, 6, generator=g).to(dev) for _ in range(4)]
+    xs = [(torch.randn(8, 100, 6, generator=g) * sc).to(dev) for sc in scales]
     ys = [(torch.arange(8) % 4).to(dev) for _ in range(4)]
     mask = torch.ones(8, 100, device=dev)
     finals = {}
@@ -517,7 +520,7 @@ def test_graphed_train_step_equals_eager():
         torch.cuda.synchronize()
         finals[mode] = (losses, {k: v.detach().clone() for k, v in model.state_dict().items()})
     for a, b in zip(finals["eager"][0], finals["graph"][0]):
-        assert abs(a - b) <= 1e-6 * max(1.0, abs(a))
+        assert a == a and abs(a - b) <= 1e-6 * max(1.0, abs(a)), (finals["eager"][0], finals["graph"][0])
     for k, v in finals["eager"][1].items():
         w = finals["graph"][1][k]
         if v.dtype.is_floating_point:

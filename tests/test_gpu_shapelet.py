@@ -438,10 +438,12 @@ def test_abi_argument_errors_of_the_round3_entry_points():
     # operand bounds
     assert L.ign_absmax(None, 16, pp, None) == ARG and L.ign_absmax(pp, 0, pp, None) == ARG
     assert L.ign_absmax(ctypes.c_void_p(x.data_ptr() + 4), 16, pp, None) == ARG                      # not 16-byte aligned
-    assert L.ign_fcn_scan(0, v1(x.data_ptr()), l1(16), None, None, None, None, pp, None) == ARG
-    assert L.ign_fcn_scan(9, v1(x.data_ptr()), l1(16), None, None, None, None, pp, None) == ARG
-    assert L.ign_fcn_scan(1, v1(x.data_ptr()), l1(16), v1(x.data_ptr()), None, None, None, pp, None) == ARG      # gamma without beta
-    assert L.ign_fcn_scan(1, v1(x.data_ptr()), l1(16), v1(x.data_ptr()), v1(x.data_ptr()), i1(4), l1(1), pp, None) == ARG   # R <= 1
+    assert L.ign_fcn_scan(0, v1(x.data_ptr()), l1(16), None, None, None, None, pp, None, 0, None) == ARG
+    assert L.ign_fcn_scan(9, v1(x.data_ptr()), l1(16), None, None, None, None, pp, None, 0, None) == ARG
+    assert L.ign_fcn_scan(1, v1(x.data_ptr()), l1(16), v1(x.data_ptr()), None, None, None, pp, None, 0, None) == ARG      # gamma without beta
+    assert L.ign_fcn_scan(1, v1(x.data_ptr()), l1(16), v1(x.data_ptr()), v1(x.data_ptr()), i1(4), l1(1), pp, None, 0, None) == ARG   # R <= 1
+    assert L.ign_fcn_scan(1, v1(x.data_ptr()), l1(16), None, None, None, None, pp, None, 5, None) == ARG         # nzero without a buffer
+    assert L.ign_instnorm_fwd_amax(pp, pp, None, 1, 4, 4, ctypes.c_float(1e-8), None, None) == ARG             # null slot
     # fp16 GEMMs need both bounds
     assert L.ign_clconv_fwd_h3(pp, pp, None, None, None, pp, None, None, pp, 1, 16, 4, 4, 3, None) == ARG
     assert L.ign_clconv_dgrad_h3(pp, pp, pp, pp, pp, pp, pp, pp, pp, pp, None, 1, 16, 4, 4, 3, None) == ARG
@@ -506,3 +508,22 @@ def test_fp16_gemm_with_degenerate_magnitude_bounds(bound):
     # unscaled (scale 1) operands of O(1) are inside fp16's range: full accuracy; the clamped / tiny cases keep the bias exact
     tol = 3e-6 if (fallback or bound == 1e20) else 1e-3
     assert float((y.double().cpu() - ref).abs().max() / ref.abs().max()) < tol
+
+
+def test_instance_norm_takes_the_input_bound_in_the_same_pass():
+    """ops.instance_norm(..., input_bound=True): outputs bitwise those of the plain pass, and the bound attached to the raw batch
+    is exactly max |x| (what ign_absmax returns); a second call finds the bound attached and takes the plain route."""
+    dev = _dev()
+    from ign_hip import ops
+    g = torch.Generator().manual_seed(3)
+    for (B, T, C, sc) in [(5, 100, 6, 1.0), (3, 1000, 122, 37.5), (2, 64, 33, 1e-4)]:
+        x = (torch.randn(B, T, C, generator=g) * sc).to(dev)
+        xn0, _ = ops.instance_norm(x.clone())
+        xn1, xt1 = ops.instance_norm(x, want_raw=True, input_bound=True)
+        b = ops.cached_bound(x)
+        assert b is not None and float(b) == float(x.abs().max())
+        assert torch.equal(xn0, xn1) and torch.equal(xt1, x.permute(0, 2, 1))
+        xn2, _ = ops.instance_norm(x, input_bound=True)
+        assert ops.cached_bound(x) is b and torch.equal(xn2, xn0)
+        x.mul_(2.0)                                         # modified in place: the attached bound no longer describes it
+        assert ops.cached_bound(x) is None
