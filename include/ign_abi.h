@@ -191,7 +191,9 @@ int ign_attn_bwd_h3(const float* q, const float* k, const float* v, const float*
                     int B, int L, int S, int H, int E,
                     long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb, long long v_sl,
                     float scale, void* stream, long long g_sb, long long g_sl,
-                    const float* bq, const float* bk, const float* bv, const float* bgo);
+                    const float* bq, const float* bk, const float* bv, const float* bgo,
+                    float* g_amax /* nullable: max over |gq|, |gk|, |gv| as an atomic maximum (caller zeroes) -- the bound of
+                                     the packed gradient for the projection's backward GEMMs */);
 
 /* Skinny expert-head GEMM  out[b,n] = sum_f X[b,f] W[n,f] (+ bias[n]),  N <= 16 classes, F % 4 == 0, row pitch ldx.
  * Replaces nn.Linear at IGN/model/Shapelet.py:171,200 (SBM head), IGN/model/Transformer.py:72,109,
@@ -278,6 +280,10 @@ int ign_layernorm_fwd(const float* x, const float* gamma, const float* beta, flo
                       float eps, void* stream);
 int ign_layernorm_bwd(const float* x, const float* gy, const float* gamma, const float* mean, const float* rstd, float* gx,
                       float* dgamma, float* dbeta, float* part, long long R, int D, void* stream);
+/* ign_layernorm_bwd that also takes max |gx| as an atomic maximum into *amax_slot (caller zeroes): the magnitude bound of dL/dx
+ * for the fp16 GEMMs of the dense layer behind (ign_clconv_fwd_h3 / ign_linear_wgrad_h3), where gx is produced anyway.           */
+int ign_layernorm_bwd_amax(const float* x, const float* gy, const float* gamma, const float* mean, const float* rstd, float* gx,
+                           float* dgamma, float* dbeta, float* part, float* amax_slot, long long R, int D, void* stream);
 /* Lag sums C[d] = sum_rows sum_u x[row][u] x[row][u+d], d < K <= 128 -- with edge terms from the first / last k-1 samples of
  * each row they give the window Gram matrix G[j,j'] = sum x_pad[t+j] x_pad[t+j'] and BatchNorm-1's batch variance of
  * IGN/model/eegcnn.py:90-91 as the quadratic form w1^T G w1 (gradient 2 G w1): K*T FMA per row for all filters, no backward
@@ -412,7 +418,9 @@ int ign_clconv_pack_weights_x3_multi(int n, const float* const* w_oik, void* con
  * Supported magnitudes: the scale exponent is clamped to +-60, i.e. bounds from 2^-46 (1.4e-14; below it the operand loses
  * precision gradually and finally reads as zero -- gradients of that size no longer move an fp32 weight) to 2^74 (1.9e22; a
  * tensor beyond it overflows fp16 and the result is NaN, as loudly as the diverged run that produced it).  A bound of 0 or a
- * non-finite bound selects scale 1.  A bound must BE an upper bound: a value above it may overflow.
+ * non-finite bound selects scale 1.  A bound should BE an upper bound; the scaled bound lies in [2^13, 2^14) and fp16 reaches
+ * 65504, so an element up to 3.9 times the bound is still split exactly like any other (the host side relies on a factor 1.13 of
+ * this headroom where dL/du of a GELU inherits the bound of dL/dy), an element beyond 4 times the bound overflows to infinity.
  * Replaces the same reference lines as ign_clconv_fwd / _dgrad / _wgrad (IGN/model/FullyConvNet.py:31-59 and its autograd).   */
 int ign_absmax(const float* x, long long n, float* slot /* max'ed into, caller zeroes */, void* stream);
 /* ign_fcn_scan also clears `zero[0..nzero)` (nullable / 0): the identically-zero gradients of the convolution biases in front of

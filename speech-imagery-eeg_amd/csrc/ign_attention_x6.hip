@@ -343,6 +343,7 @@ struct AttnX6BwdArgs {
     int B, L, S, H, E;
     float scale;
     const float *bq, *bk, *bv, *bg;                // NP = 2: device-side bounds of |q|, |k|, |v|, |dO|
+    float* gmax;                                   // nullable: max |dq|, |dk|, |dv| as an atomic maximum (bound of the packed gradient)
 };
 
 constexpr int AB_T = 32;                                          // rows per staged tile
@@ -465,16 +466,25 @@ __device__ __forceinline__ void x6_tileT_times_acc(f32x16 (&G)[(E + 31) / 32], c
     }
 
 template <int E>
-__device__ __forceinline__ void store_grad_rows(float* dst, const f32x16 (&G)[(E + 31) / 32], float sc, int h) {
+__device__ __forceinline__ float store_grad_rows(float* dst, const f32x16 (&G)[(E + 31) / 32], float sc, int h) {
+    float am = 0.f;                                                  // max |value stored| by this lane
 #pragma unroll
     for (int d = 0; d < (E + 31) / 32; ++d)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int d0 = d * 32 + 8 * g + 4 * h;
-            if (d0 < E)
-                *reinterpret_cast<float4*>(dst + d0) =
-                    make_float4(G[d][4 * g] * sc, G[d][4 * g + 1] * sc, G[d][4 * g + 2] * sc, G[d][4 * g + 3] * sc);
+            if (d0 < E) {
+                const float4 o = make_float4(G[d][4 * g] * sc, G[d][4 * g + 1] * sc, G[d][4 * g + 2] * sc, G[d][4 * g + 3] * sc);
+                *reinterpret_cast<float4*>(dst + d0) = o;
+                am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            }
         }
+    return am;
+}
+__device__ __forceinline__ void wave_amax_to(float* slot, float am, int lane) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    if (lane == 0) ign_atomic_absmax(slot, am);
 }
 
 // ---- dQ: block = 4 waves x 32 queries (lanes); loops over key tiles.  S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta),
@@ -556,8 +566,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_x6_kernel(const AttnX6BwdA
         x6_tileT_times_acc<E, NP>(dQ, Ks, dp, lane);
     }
     // NP = 2: dQ holds sk sds K^T dS
-    if (q_ok) store_grad_rows<E>(a.gq + b * a.gq_sb + (long long)qi * a.g_sl + head * E, dQ,
-                                 (NP == 2) ? a.scale / (sta * sds) : a.scale, h);
+    float am = 0.f;
+    if (q_ok) am = store_grad_rows<E>(a.gq + b * a.gq_sb + (long long)qi * a.g_sl + head * E, dQ,
+                                      (NP == 2) ? a.scale / (sta * sds) : a.scale, h);
+    if (a.gmax) wave_amax_to(a.gmax, am, lane);
 }
 
 // ---- dK / dV: block = 4 waves x 32 keys (lanes); loops over query tiles.  S = Q K^T (rows = queries), P = exp(S - lse);
@@ -678,11 +690,13 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_x6_kernel(const AttnX6Bwd
             x6_tileT_times_acc<E, NP>(G, Qs, dp, lane);
         }
     }
+    float am = 0.f;
     if (k_ok) {
         float* dst = (DV ? a.gv : a.gk) + b * a.gkv_sb + (long long)ki * a.g_sl + head * E;
         // NP = 2: dV holds sg 2^14 dO^T P; dK holds sq sds Q^T dS
-        store_grad_rows<E>(dst, G, DV ? ((NP == 2) ? 6.103515625e-05f / stb : 1.f) : ((NP == 2) ? a.scale / (sta * sds) : a.scale), h);
+        am = store_grad_rows<E>(dst, G, DV ? ((NP == 2) ? 6.103515625e-05f / stb : 1.f) : ((NP == 2) ? a.scale / (sta * sds) : a.scale), h);
     }
+    if (a.gmax) wave_amax_to(a.gmax, am, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -745,7 +759,7 @@ static int attn_bwd_x6_impl(const char* who, const float* q, const float* k, con
                             const float* gout, float* gq, float* gk, float* gv, float* delta_ws, int B, int L, int S, int H,
                             int E, long long q_sb, long long q_sl, long long k_sb, long long k_sl, long long v_sb,
                             long long v_sl, float scale, void* stream, long long g_sb = 0, long long g_sl = 0,
-                            const float* const* bounds = nullptr) {
+                            const float* const* bounds = nullptr, float* g_amax = nullptr) {
     if (NP == 2 && (!bounds || !bounds[0] || !bounds[1] || !bounds[2] || !bounds[3])) {
         ign_set_error("%s: null operand bound", who);
         return IGN_E_ARG;
@@ -781,6 +795,7 @@ static int attn_bwd_x6_impl(const char* who, const float* q, const float* k, con
     a.q_sb = q_sb; a.q_sl = q_sl; a.k_sb = k_sb; a.k_sl = k_sl; a.v_sb = v_sb; a.v_sl = v_sl;
     a.B = B; a.L = L; a.S = S; a.H = H; a.E = E; a.scale = scale;
     if (NP == 2) { a.bq = bounds[0]; a.bk = bounds[1]; a.bv = bounds[2]; a.bg = bounds[3]; }
+    a.gmax = g_amax;
     a.g_sl = g_sl ? g_sl : (long long)H * E;
     a.gq_sb = g_sb ? g_sb : (long long)L * H * E;
     a.gkv_sb = g_sb ? g_sb : (long long)S * H * E;
@@ -845,11 +860,11 @@ extern "C" int ign_attn_fwd_h3(IGN_ATTN_FWD_ARGS, const float* bq, const float* 
     return attn_fwd_x6_impl<2>("ign_attn_fwd_h3", q, k, v, out, lse, B, L, S, H, E, q_sb, q_sl, k_sb, k_sl, v_sb, v_sl, scale, stream, bounds);
 }
 extern "C" int ign_attn_bwd_h3(IGN_ATTN_BWD_ARGS, long long g_sb, long long g_sl, const float* bq, const float* bk, const float* bv,
-                               const float* bgo) {
+                               const float* bgo, float* g_amax) {
     if (E > 64) { ign_set_error("ign_attn_bwd_h3: E=%d > 64", E); return IGN_E_UNSUP; }
     const float* bounds[4] = {bq, bk, bv, bgo};
     return attn_bwd_x6_impl<2>("ign_attn_bwd_h3", q, k, v, out, lse, gout, gq, gk, gv, delta_ws, B, L, S, H, E, q_sb, q_sl, k_sb, k_sl,
-                               v_sb, v_sl, scale, stream, g_sb, g_sl, bounds);
+                               v_sb, v_sl, scale, stream, g_sb, g_sl, bounds, g_amax);
 }
 
 // The same backward writing gq / gk / gv with the caller's batch and sequence strides (elements; head stride E): lets the three

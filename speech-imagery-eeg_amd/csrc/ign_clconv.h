@@ -60,13 +60,6 @@ struct GemmNTArgs {
     float* amax_out;                           // nullable: max |C| is max'ed into this device float (integer atomicMax on the bits)
 };
 
-// max of non-negative floats as unsigned integers on their bit patterns: exact, order-independent (bitwise reproducible)
-__device__ __forceinline__ void ign_atomic_absmax(float* slot, float v) {
-    unsigned int* u = reinterpret_cast<unsigned int*>(slot);
-    const unsigned int b = __float_as_uint(v);
-    if (b > __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(u, b);
-}
-
 // ---- epilogue shared by the fp32 and the split-bf16 kernels.  Lane (l31, h) of accumulator (i, j) holds column
 // n = n0 + wn*64 + j*32 + l31 and the 16 rows m0 + wm*64 + i*32 + acc_row16(r, h).  `red` is >= 512 floats of LDS that no
 // wave still reads.  FULL = the whole 128x128 tile is inside the output: no per-element masks, and the 16 y values an

@@ -5,6 +5,14 @@
 #include <stddef.h>
 #include "../../include/ign_abi.h"
 
+// max of non-negative floats as unsigned integers on their bit patterns: exact, order-independent (bitwise reproducible)
+__device__ __forceinline__ void ign_atomic_absmax(float* slot, float v) {
+    unsigned int* u = reinterpret_cast<unsigned int*>(slot);
+    const unsigned int b = __float_as_uint(v);
+    if (b > __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(u, b);
+}
+
+
 #define IGN_WAVE 64
 
 // thread-local error message (ign_abi.cpp owns the storage)

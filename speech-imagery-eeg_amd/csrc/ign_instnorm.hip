@@ -7,7 +7,6 @@
 // CT = 8 (36 KB tiles) PMC showed 2.4x the algorithmic fetch traffic -- 32-byte pieces of 128-byte lines -- and 115 us for the
 // 250 MB; the large tile uses 1024-thread blocks so that one block per CU still keeps 32 KB of loads in flight.
 #include "ign_common.h"
-#include "ign_clconv.h"       // ign_atomic_absmax
 
 __global__ void __launch_bounds__(1024) instnorm_kernel(const float* __restrict__ x, float* __restrict__ xn,
                                                        float* __restrict__ xt, int B, int T, int C, int CT,

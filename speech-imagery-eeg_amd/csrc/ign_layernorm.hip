@@ -15,6 +15,7 @@ constexpr int LN_ITERS_MAX = 32;              // row groups per wave (fewer when
 struct LnArgs {
     const float *x, *gy, *gamma, *beta, *mean_in, *rstd_in;
     float *y, *gx, *mean, *rstd, *part;       // part: (nblocks, 2, D)
+    float* amax;                              // backward, nullable: max |gx| as an atomic maximum (fp16 GEMM operand bound)
     long long R;
     int D, G, nv;                             // lanes per row, float4 pieces per lane
     int iters;                                // row groups per wave
@@ -93,6 +94,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const LnArgs a) {
         dg[v] = db[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const long long row0 = ((long long)blockIdx.x * 4 + wave) * a.iters * rpw;
+    float am = 0.f;
     for (int it = 0; it < a.iters; ++it) {
         const long long r = row0 + (long long)it * rpw + sub;
         if (row0 + (long long)it * rpw >= a.R) break;               // wave-uniform
@@ -124,11 +126,19 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const LnArgs a) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int c = li + v * G;
-                if (c < D4)
-                    or_[c] = make_float4((gh[v].x - c1 - xh[v].x * c2) * rstd, (gh[v].y - c1 - xh[v].y * c2) * rstd,
-                                         (gh[v].z - c1 - xh[v].z * c2) * rstd, (gh[v].w - c1 - xh[v].w * c2) * rstd);
+                if (c < D4) {
+                    const float4 o = make_float4((gh[v].x - c1 - xh[v].x * c2) * rstd, (gh[v].y - c1 - xh[v].y * c2) * rstd,
+                                                 (gh[v].z - c1 - xh[v].z * c2) * rstd, (gh[v].w - c1 - xh[v].w * c2) * rstd);
+                    or_[c] = o;
+                    am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+                }
             }
         }
+    }
+    if (a.amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+        if (lane == 0) ign_atomic_absmax(a.amax, am);
     }
     // fold the per-lane partials of the 4 * rpw row slots of this block (fixed order), then one partial row per block
     const int slot = wave * rpw + sub, nslots = 4 * rpw;
@@ -232,11 +242,11 @@ extern "C" int ign_layernorm_fwd(const float* x, const float* gamma, const float
 }
 
 // part: ign_layernorm_parts(R, D) * 2 * D floats of workspace; dgamma / dbeta may be NULL
-extern "C" int ign_layernorm_bwd(const float* x, const float* gy, const float* gamma, const float* mean, const float* rstd,
-                                 float* gx, float* dgamma, float* dbeta, float* part, long long R, int D, void* stream) {
-    static const char* who = "ign_layernorm_bwd";
+static int layernorm_bwd_impl(const char* who, const float* x, const float* gy, const float* gamma, const float* mean, const float* rstd,
+                              float* gx, float* dgamma, float* dbeta, float* part, float* amax, long long R, int D, void* stream) {
     if (!x || !gy || !gamma || !mean || !rstd || !gx || !part) { ign_set_error("%s: null pointer", who); return IGN_E_ARG; }
     LnArgs a = {};
+    a.amax = amax;
     long long nblk;
     int rc;
     if ((rc = ln_geometry(who, R, D, &a.G, &a.nv, &nblk, &a.iters))) return rc;
@@ -255,4 +265,17 @@ extern "C" int ign_layernorm_bwd(const float* x, const float* gy, const float* g
         return ign_check_launch("layernorm_reduce_kernel");
     }
     return 0;
+}
+
+extern "C" int ign_layernorm_bwd(const float* x, const float* gy, const float* gamma, const float* mean, const float* rstd,
+                                 float* gx, float* dgamma, float* dbeta, float* part, long long R, int D, void* stream) {
+    return layernorm_bwd_impl("ign_layernorm_bwd", x, gy, gamma, mean, rstd, gx, dgamma, dbeta, part, nullptr, R, D, stream);
+}
+
+// ... and max |gx| as an atomic maximum into *amax_slot (caller zeroes): the bound the fp16 GEMM behind it scales dL/dy by
+extern "C" int ign_layernorm_bwd_amax(const float* x, const float* gy, const float* gamma, const float* mean, const float* rstd,
+                                      float* gx, float* dgamma, float* dbeta, float* part, float* amax_slot, long long R, int D,
+                                      void* stream) {
+    if (!amax_slot) { ign_set_error("ign_layernorm_bwd_amax: null amax_slot"); return IGN_E_ARG; }
+    return layernorm_bwd_impl("ign_layernorm_bwd_amax", x, gy, gamma, mean, rstd, gx, dgamma, dbeta, part, amax_slot, R, D, stream);
 }

@@ -28,6 +28,7 @@ SIGNATURES = {
     "ign_layernorm_parts": (ll, [ll, ci]),
     "ign_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ll, ci, cf, vp]),
     "ign_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp]),
+    "ign_layernorm_bwd_amax": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp]),
     "ign_autocorr_parts": (ll, [ci]),
     "ign_autocorr_fwd": (ci, [vp, vp, ci, ci, ci, vp]),
     "ign_edge_lagprod_parts": (ll, [ci]),
@@ -42,7 +43,7 @@ SIGNATURES = {
     "ign_attn_bwd_bf16": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp]),
     "ign_attn_fwd_h3": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp, vp, vp, vp]),
     "ign_attn_bwd_h3": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ll, ll, ll, ll, ll, ll, cf, vp, ll, ll,
-                             vp, vp, vp, vp]),
+                             vp, vp, vp, vp, vp]),
     "ign_head_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ll, vp]),
     "ign_head_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]),
     "ign_gate_fwd": (ci, [vp, vp, vp, vp, ci, ci, cf, ci, vp]),

@@ -351,10 +351,12 @@ class AttentionFn(torch.autograd.Function):
         delta = torch.empty(B, H, L, device=q.device, dtype=torch.float32)
         (qb, ql), (kb, kl), (vb, vl) = _bl_strides(q, "q"), _bl_strides(k, "k"), _bl_strides(v, "v")
         if ctx.h3:
+            gmax = _new_slot(q.device)            # max over |dq|, |dk|, |dv| (taken as they are stored): one bound for the three
             _lib.check(_lib.lib().ign_attn_bwd_h3(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(gout), _ptr(gq), _ptr(gk), _ptr(gv),
                                                   _ptr(delta), B, L, S, H, E, qb, ql, kb, kl, vb, vl, ctx.scale, _stream(), 0, 0,
-                                                  *[_ptr(t) for t in ctx.bounds], _ptr(tensor_bound(gout))), "ign_attn_bwd_h3")
-            return gq, gk, gv, None
+                                                  *[_ptr(t) for t in ctx.bounds], _ptr(tensor_bound(gout)), _ptr(gmax)),
+                       "ign_attn_bwd_h3")
+            return set_bound(gq, gmax), set_bound(gk, gmax), set_bound(gv, gmax), None
         # split-bf16 kernels up to E = 64 (E = 128 exceeds their register budget: the fp32-MFMA backward is faster there)
         bwd = (_lib.lib().ign_attn_bwd_bf16 if ctx.bf16 else
                _lib.lib().ign_attn_bwd_x6 if (ATTN_MATH == "bf16x6" and E <= 64) else _lib.lib().ign_attn_bwd)
@@ -412,11 +414,12 @@ class PackedAttentionFn(torch.autograd.Function):
         sb, sl = qkv.stride(0), qkv.stride(1)
         if ctx.h3:
             bp = _ptr(ctx.bound)
+            gmax = _new_slot(qkv.device)          # max |dq|, |dk|, |dv|, taken by the kernels as they store: the projection's
             _lib.check(_lib.lib().ign_attn_bwd_h3(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(gout), _ptr(gqkv[:, :, 0]),
                                                   _ptr(gqkv[:, :, 1]), _ptr(gqkv[:, :, 2]), _ptr(delta), B, L, L, H, E, sb, sl, sb, sl,
-                                                  sb, sl, ctx.scale, _stream(), sb, sl, bp, bp, bp, _ptr(tensor_bound(gout))),
-                       "ign_attn_bwd_h3")
-            return gqkv, None
+                                                  sb, sl, ctx.scale, _stream(), sb, sl, bp, bp, bp, _ptr(tensor_bound(gout)),
+                                                  _ptr(gmax)), "ign_attn_bwd_h3")
+            return set_bound(gqkv, gmax), None    # backward GEMMs scale their dL/dy operand by it without a pass over it
         _lib.check(_lib.lib().ign_attn_bwd_x6_strided(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(gout),
                                                       _ptr(gqkv[:, :, 0]), _ptr(gqkv[:, :, 1]), _ptr(gqkv[:, :, 2]), _ptr(delta),
                                                       B, L, L, H, E, sb, sl, sb, sl, sb, sl, ctx.scale, _stream(), sb, sl,
@@ -545,21 +548,56 @@ def tensor_bound(t):
 
 
 def set_bound(t, slot):
-    """Attach a known magnitude bound (one-element device tensor) to `t`; see tensor_bound / cached_bound."""
+    """Attach a known magnitude bound (one-element device tensor) to `t`; see tensor_bound / cached_bound.  A reshaped view is
+    looked up through its ROOT base (`view(...).reshape(...)._base` is the root, not the intermediate view), so a bound attached
+    to a full-size view is attached to that root as well."""
+    cap = torch.cuda.is_current_stream_capturing()
     try:
-        t._ign_bound = (slot, t._version, t.data_ptr(), torch.cuda.is_current_stream_capturing())
+        t._ign_bound = (slot, t._version, t.data_ptr(), cap)
+        base = t._base
+        if base is not None and base.numel() == t.numel() and not (base.is_leaf and base.requires_grad):
+            base._ign_bound = (slot, base._version, base.data_ptr(), cap)
     except Exception:
         pass
     return t
 
 
 def keep_bound(out, src, factor=1.0):
-    """`out` = f(src) element-wise with |f(u)| <= factor |u| (ReLU, GELU: factor 1): `out` inherits src's magnitude bound, if
-    src carries one, instead of being scanned when a dense layer consumes it."""
-    cb = cached_bound(src) if factor == 1.0 else None
+    """`out` = f(src) element-wise with |f(u)| <= factor |u|: `out` inherits src's magnitude bound, if src carries one, instead of
+    being scanned when a dense layer consumes it.  factor 1: ReLU, GELU.  factor <= 2 (GELU's derivative reaches 1.13) is
+    covered by the headroom of the scaling: a bound b is scaled to [2^13, 2^14), fp16 represents values below 2^16, so an
+    element up to 4 b neither overflows nor loses a bit (include/ign_abi.h, "h3")."""
+    cb = cached_bound(src) if factor <= 2.0 else None
     if cb is not None:
         set_bound(out, cb)
     return out
+
+
+class _ActFn(torch.autograd.Function):
+    """ReLU / GELU with torch's own element-wise kernels in both directions; what it adds is the magnitude bound: the output
+    inherits the input's, and dL/du inherits dL/dy's (|relu'| <= 1, |gelu'| <= 1.13) -- a plain F.relu / F.gelu node hands the
+    backward GEMM behind it a tensor without one, i.e. costs a pass over it (ign_absmax)."""
+
+    @staticmethod
+    def forward(ctx, u, gelu):
+        ctx.gelu = gelu
+        y = torch.nn.functional.gelu(u) if gelu else torch.relu(u)
+        ctx.save_for_backward(u if gelu else y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (t,) = ctx.saved_tensors
+        gu = torch.ops.aten.gelu_backward(g, t) if ctx.gelu else torch.ops.aten.threshold_backward(g, t, 0)
+        return keep_bound(gu, g, 1.13 if ctx.gelu else 1.0), None
+
+
+def relu(u):
+    return keep_bound(_ActFn.apply(u, False), u)
+
+
+def gelu(u):
+    return keep_bound(_ActFn.apply(u, True), u)
 
 
 def _gemm(L, bf16):
@@ -629,13 +667,17 @@ class LinearFn(torch.autograd.Function):
         bg = tensor_bound(g2) if ctx.h3 else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, Ci, device=g2.device, dtype=torch.float32)
+            dxb = None
             if ctx.h3:
-                _lib.check(L.ign_clconv_fwd_h3(_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, _ptr(bg), _ptr(ctx.bw), 1, M, Co,
-                                               Ci, 1, _stream()), "ign_clconv_fwd_h3(dx)")
+                dxb = _new_slot(g2.device)           # the epilogue takes max |dx|: the next backward GEMM's operand bound
+                _lib.check(L.ign_clconv_fwd_h3_amax(_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, _ptr(bg), _ptr(ctx.bw),
+                                                    _ptr(dxb), 1, M, Co, Ci, 1, _stream()), "ign_clconv_fwd_h3_amax(dx)")
             else:
                 _lib.check(_gemm(L, ctx.bf16)[0](_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, 1, M, Co, Ci, 1, _stream()),
                            "ign_clconv_fwd_x6(dx)")
             dx = dx.view(ctx.xshape)
+            if dxb is not None:
+                set_bound(dx, dxb)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty(Co, Ci, device=g2.device, dtype=torch.float32)
@@ -709,9 +751,17 @@ class LayerNormFn(torch.autograd.Function):
         dgamma = torch.empty(D, device=x2.device, dtype=torch.float32) if need_w else None
         dbeta = torch.empty(D, device=x2.device, dtype=torch.float32) if need_w and ctx.has_bias else None
         part = torch.empty(int(L.ign_layernorm_parts(R, D)) * 2 * D, device=x2.device, dtype=torch.float32)
-        _lib.check(L.ign_layernorm_bwd(_ptr(x2), _ptr(g2), _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dgamma), _ptr(dbeta),
-                                       _ptr(part), R, D, _stream()), "ign_layernorm_bwd")
-        return gx.view(gy.shape), dgamma, dbeta, None
+        gxv = gx.view(gy.shape)
+        if GEMM_MATH == "f16x3" and not torch.is_autocast_enabled():
+            # dL/dx usually feeds the backward GEMMs of a dense layer: its magnitude bound is taken here, as it is written
+            slot = _new_slot(x2.device)
+            _lib.check(L.ign_layernorm_bwd_amax(_ptr(x2), _ptr(g2), _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dgamma),
+                                                _ptr(dbeta), _ptr(part), _ptr(slot), R, D, _stream()), "ign_layernorm_bwd_amax")
+            set_bound(gxv, slot)
+        else:
+            _lib.check(L.ign_layernorm_bwd(_ptr(x2), _ptr(g2), _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dgamma), _ptr(dbeta),
+                                           _ptr(part), R, D, _stream()), "ign_layernorm_bwd")
+        return gxv, dgamma, dbeta, None
 
 
 def layer_norm(x, norm):

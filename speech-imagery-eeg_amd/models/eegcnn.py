@@ -187,7 +187,7 @@ def _encoder_layer_forward(layer, x, n_heads):
     a = ops.linear(o.reshape(B, S, d), sa.out_proj.weight, sa.out_proj.bias)
     x = ops.layer_norm(x + layer.dropout1(a), layer.norm1)
     u = ops.linear(x, layer.linear1.weight, layer.linear1.bias)
-    hdn = ops.keep_bound(F.relu(u), u)                              # |relu(u)| <= |u|: the magnitude bound carries over
+    hdn = ops.relu(u)                                               # (magnitude bound handed on in both directions)
     if layer.training and layer.dropout.p > 0:
         hdn = layer.dropout(hdn)
     ff = ops.linear(hdn, layer.linear2.weight, layer.linear2.bias)

@@ -750,3 +750,46 @@ def test_weight_bounds_follow_the_optimizer():
     y = ops.linear(x, lin.weight, lin.bias)
     ref = torch.nn.functional.linear(x.double(), lin.weight.detach().double(), lin.bias.detach().double())
     assert torch.isfinite(y).all() and _rel(y, ref) < 3e-6
+
+
+def test_backward_operand_bounds_come_from_the_producers():
+    """fp16 GEMM scaling in the backward of an encoder layer: every dL/dy operand carries a bound attached by the kernel that wrote
+    it (LayerNorm backward, the dense layers' input-gradient epilogue, the attention backward, the activation's backward), so the
+    only passes ign_absmax makes in a forward + backward are over the raw input and the (small) weights.  Each attached bound is
+    checked against the tensor it describes (numerics: the parametrised kernel tests above run all of this on f16x3)."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops, _lib
+    from models.eegcnn import _encoder_layer_forward
+    if ops.GEMM_MATH != "f16x3":
+        pytest.skip("needs the f16x3 arithmetic")
+    torch.manual_seed(0)
+    layer = torch.nn.TransformerEncoderLayer(d_model=64, nhead=4, dim_feedforward=128, dropout=0.0, batch_first=True).to(dev).train()
+    x = torch.randn(4, 50, 64, device=dev)
+    L = _lib.lib()
+    calls, seen = [], []
+    orig_absmax, orig_set = L.ign_absmax, ops.set_bound
+
+    def spy_absmax(*a):
+        calls.append(int(a[1]))
+        return orig_absmax(*a)
+
+    def spy_set(t, slot):
+        seen.append((t, slot))
+        return orig_set(t, slot)
+
+    L.ign_absmax, ops.set_bound = spy_absmax, spy_set
+    try:
+        xin = x.clone().requires_grad_(True)
+        out = _encoder_layer_forward(layer, xin, 4)
+        (out * torch.randn_like(out)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        L.ign_absmax, ops.set_bound = orig_absmax, orig_set
+    weights = [layer.self_attn.in_proj_weight, layer.self_attn.out_proj.weight, layer.linear1.weight, layer.linear2.weight]
+    assert sorted(calls) == sorted([x.numel()] + [w.numel() for w in weights]), \
+        f"ign_absmax passes over {calls} elements; expected the raw input and the four (small) weights only"
+    assert len(seen) >= 10
+    for t, slot in seen:                                     # every attached bound bounds its tensor (4x headroom not needed here)
+        assert float(t.detach().abs().max()) <= float(slot) * 1.14 + 1e-30, (tuple(t.shape), float(t.abs().max()), float(slot))
+    assert all(torch.isfinite(p.grad).all() for p in layer.parameters()) and torch.isfinite(xin.grad).all()

@@ -457,7 +457,7 @@ def test_abi_argument_errors_of_the_round3_entry_points():
     z = (pp,) * 5
     assert L.ign_attn_fwd_h3(*z, 1, 8, 8, 1, 128, 128, 128, 128, 128, 128, 128, 1.0, None, pp, pp, pp) == UNSUP
     assert L.ign_attn_fwd_h3(*z, 1, 8, 8, 1, 64, 64, 64, 64, 64, 64, 64, 1.0, None, pp, None, pp) == ARG
-    assert L.ign_attn_bwd_h3(*((pp,) * 10), 1, 8, 8, 1, 64, 64, 64, 64, 64, 64, 64, 1.0, None, 0, 0, pp, pp, pp, None) == ARG
+    assert L.ign_attn_bwd_h3(*((pp,) * 10), 1, 8, 8, 1, 64, 64, 64, 64, 64, 64, 64, 1.0, None, 0, 0, pp, pp, pp, None, None) == ARG
     # fused regulariser, bank backward, head backward with an addend
     assert L.ign_sbm_reg_fwd_bwd(pp, pp, 16, 0.1, 9, v1(x.data_ptr()), v1(x.data_ptr()), i1(2), i1(3), 2, 0.1, 1e-6, pp, pp, None) == ARG
     assert L.ign_sbm_reg_fwd_bwd(pp, pp, 16, 0.1, 1, v1(x.data_ptr()), v1(x.data_ptr()), i1(17), i1(3), 2, 0.1, 1e-6, pp, pp, None) == UNSUP
