@@ -495,7 +495,11 @@ _SLOT_POOL = {}
 
 
 def _new_slot(device):
-    """One zero-initialised float on `device`, cut from a pooled zero buffer (one fill launch per 256 slots)."""
+    """One zero-initialised float on `device`, cut from a pooled zero buffer (one fill launch per 256 slots).  While a hipGraph is
+    being captured the slot gets its own fill INSIDE the graph: the kernels max into it atomically, so a slot zeroed once at
+    allocation would carry the maximum over all earlier replays into every later one."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(1, device=device, dtype=torch.float32)
     pool = _SLOT_POOL.get(device)
     if pool is None or pool[1] >= pool[0].numel():
         pool = _SLOT_POOL[device] = [torch.zeros(256, device=device, dtype=torch.float32), 0]

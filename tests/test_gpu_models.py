@@ -473,7 +473,39 @@ def test_ign_step_launch_count():
     assert per_step <= 40, f"{per_step} launches per step: " + ", ".join(f"{k[:40]} x{v / n:g}" for k, v in names.items())
 
 
-@pytest.mark.parametrize("scales", [(1.0, 1.0, 1.0, 1.0), (1.0, 40.0, 3e3, 2e5)], ids=["same magnitude", "growing magnitude"])
+def test_bounds_measured_inside_a_hipgraph_are_per_replay():
+    """A magnitude bound taken by a captured kernel (atomic maximum into a slot) must be the CURRENT batch's at every replay: the
+    slot is zero-filled inside the graph, and a bound cached from the warm-up is not trusted while capturing."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    x = torch.randn(4, 64, 6, device=dev)
+    out_b, out_t = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+
+    def fn():
+        ops.instance_norm(x, input_bound=True)
+        out_b.copy_(ops.cached_bound(x))
+        out_t.copy_(ops.tensor_bound(x[:, :32].contiguous()))       # a tensor without a producer: the ign_absmax route
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()                                                        # warm-up: attaches a bound measured OUTSIDE the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fn()
+    for sc in (1.0, 300.0, 5.0, 0.01):                              # up, down, far down
+        x.copy_(torch.randn(4, 64, 6, device=dev) * sc)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert float(out_b) == float(x.abs().max()), sc
+        assert float(out_t) == float(x[:, :32].abs().max()), sc
+
+
+@pytest.mark.parametrize("scales", [(1.0, 1.0, 1.0, 1.0), (1.0, 40.0, 3e3, 2e5), (2e5, 3e3, 40.0, 1.0)],
+                         ids=["same magnitude", "growing magnitude", "shrinking magnitude"])
 def test_graphed_train_step_equals_eager(scales):
     """One IGN step (fused loss tail, backward, capturable flat Adam) captured as a hipGraph and replayed must walk the same
     parameter trajectory as the eager step.  'growing magnitude': the replayed batches are up to 2e5 times larger than the
