@@ -278,6 +278,11 @@ int ign_conv1_sumsq_bwd(const float* x, const float* w1, const float* mu, float*
 long long ign_layernorm_parts(long long R, int D);
 int ign_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long long R, int D,
                       float eps, void* stream);
+/* y = LayerNorm(x + res) in one pass: the residual connection of a post-norm encoder layer (IGN/layers/Transformer_EncDec.py:
+ * 36-37,48; nn.TransformerEncoderLayer of IGN/model/eegcnn.py:219-228) in front of its LayerNorm.  `sum` (R, D) receives x + res,
+ * the tensor ign_layernorm_bwd takes as `x`; its gx is the gradient of both addends.                                          */
+int ign_layernorm_res_fwd(const float* x, const float* res, float* sum, const float* gamma, const float* beta, float* y,
+                          float* mean, float* rstd, long long R, int D, float eps, void* stream);
 int ign_layernorm_bwd(const float* x, const float* gy, const float* gamma, const float* mean, const float* rstd, float* gx,
                       float* dgamma, float* dbeta, float* part, long long R, int D, void* stream);
 /* ign_layernorm_bwd that also takes max |gx| as an atomic maximum into *amax_slot (caller zeroes): the magnitude bound of dL/dx

@@ -14,6 +14,8 @@ constexpr int LN_ITERS_MAX = 32;              // row groups per wave (fewer when
 
 struct LnArgs {
     const float *x, *gy, *gamma, *beta, *mean_in, *rstd_in;
+    const float* res;                         // forward, nullable: the row normalised is x + res (residual connection) ...
+    float* sum;                               // ... and x + res is written here (the backward's `x`)
     float *y, *gx, *mean, *rstd, *part;       // part: (nblocks, 2, D)
     float* amax;                              // backward, nullable: max |gx| as an atomic maximum (fp16 GEMM operand bound)
     long long R;
@@ -45,13 +47,20 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const LnArgs a) {
         const long long r = row0 + (long long)it * rpw + sub;
         if (row0 + (long long)it * rpw >= a.R) break;               // wave-uniform
         const bool ok = r < a.R;
-        const float4* xr = reinterpret_cast<const float4*>(a.x + (ok ? r : a.R - 1) * a.D);
+        const long long rr = ok ? r : a.R - 1;
+        const float4* xr = reinterpret_cast<const float4*>(a.x + rr * a.D);
+        const float4* er = a.res ? reinterpret_cast<const float4*>(a.res + rr * a.D) : nullptr;
         float4 xv[NV];
         float s = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int c = li + v * G;
             xv[v] = c < D4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (er && c < D4) {
+                const float4 e = er[c];
+                xv[v] = make_float4(xv[v].x + e.x, xv[v].y + e.y, xv[v].z + e.z, xv[v].w + e.w);
+                if (ok) reinterpret_cast<float4*>(a.sum + r * a.D)[c] = xv[v];
+            }
             s += (xv[v].x + xv[v].y) + (xv[v].z + xv[v].w);
         }
         const float mean = group_sum(s, G) * invD;
@@ -227,11 +236,11 @@ extern "C" long long ign_layernorm_parts(long long R, int D) {
         default: hipLaunchKernelGGL((KERNEL<16>), grid, dim3(256), lds, s, args); break;                                  \
     }
 
-extern "C" int ign_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                                 long long R, int D, float eps, void* stream) {
-    static const char* who = "ign_layernorm_fwd";
+static int layernorm_fwd_impl(const char* who, const float* x, const float* res, float* sum, const float* gamma, const float* beta,
+                              float* y, float* mean, float* rstd, long long R, int D, float eps, void* stream) {
     if (!x || !gamma || !y || !mean || !rstd) { ign_set_error("%s: null pointer", who); return IGN_E_ARG; }
     LnArgs a = {};
+    a.res = res; a.sum = sum;
     long long nblk;
     int rc;
     if ((rc = ln_geometry(who, R, D, &a.G, &a.nv, &nblk, &a.iters))) return rc;
@@ -239,6 +248,20 @@ extern "C" int ign_layernorm_fwd(const float* x, const float* gamma, const float
     IgnScopedTimer tm("layernorm_fwd", (hipStream_t)stream);
     IGN_LN_DISPATCH(layernorm_fwd_kernel, a.nv, dim3((unsigned)nblk), 0, (hipStream_t)stream, a);
     return ign_check_launch("layernorm_fwd_kernel");
+}
+
+extern "C" int ign_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                 long long R, int D, float eps, void* stream) {
+    return layernorm_fwd_impl("ign_layernorm_fwd", x, nullptr, nullptr, gamma, beta, y, mean, rstd, R, D, eps, stream);
+}
+
+// y = LayerNorm(x + res): the residual connection in front of a post-norm encoder's LayerNorm inside the same pass (4 memory
+// passes instead of the 5 of an add kernel + ign_layernorm_fwd); `sum` (R, D) receives x + res, which is the `x` the backward
+// (ign_layernorm_bwd on `sum`) needs -- its gx is the gradient of BOTH addends.
+extern "C" int ign_layernorm_res_fwd(const float* x, const float* res, float* sum, const float* gamma, const float* beta, float* y,
+                                     float* mean, float* rstd, long long R, int D, float eps, void* stream) {
+    if (!res || !sum) { ign_set_error("ign_layernorm_res_fwd: null res / sum"); return IGN_E_ARG; }
+    return layernorm_fwd_impl("ign_layernorm_res_fwd", x, res, sum, gamma, beta, y, mean, rstd, R, D, eps, stream);
 }
 
 // part: ign_layernorm_parts(R, D) * 2 * D floats of workspace; dgamma / dbeta may be NULL

@@ -27,6 +27,7 @@ SIGNATURES = {
     "ign_shapelet_bwd_workspace_bytes": (sz, [ci, ci, ci, ci, ci, ci, ci]),
     "ign_layernorm_parts": (ll, [ll, ci]),
     "ign_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ll, ci, cf, vp]),
+    "ign_layernorm_res_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, cf, vp]),
     "ign_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp]),
     "ign_layernorm_bwd_amax": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp]),
     "ign_autocorr_parts": (ll, [ci]),

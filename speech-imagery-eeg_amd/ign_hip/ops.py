@@ -727,8 +727,10 @@ class LayerNormFn(torch.autograd.Function):
     -- PatchTST's 3.9 M rows of 64 -- run 10x off the memory roofline)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
-        _need_gpu("layer_norm", x, weight, bias)
+    def forward(ctx, x, res, weight, bias, eps):
+        """`res` (same shape as x, or None): the row normalised is x + res -- the residual connection of a post-norm encoder
+        layer -- added inside the same pass (ign_layernorm_res_fwd)."""
+        _need_gpu("layer_norm", x, res, weight, bias)
         L = _lib.lib()
         D = x.shape[-1]
         x2 = x.reshape(-1, D)
@@ -737,10 +739,21 @@ class LayerNormFn(torch.autograd.Function):
         y = torch.empty_like(x2)
         mean = torch.empty(R, device=x.device, dtype=torch.float32)
         rstd = torch.empty(R, device=x.device, dtype=torch.float32)
-        _lib.check(L.ign_layernorm_fwd(_ptr(x2), _ptr(weight), _ptr(bias), _ptr(y), _ptr(mean), _ptr(rstd), R, D, float(eps),
-                                       _stream()), "ign_layernorm_fwd")
+        if res is not None:
+            r2 = res.reshape(-1, D)
+            r2 = r2 if r2.is_contiguous() else r2.contiguous()
+            if r2.shape != x2.shape:
+                raise _lib.IgnError(f"layer_norm: residual {tuple(res.shape)} does not match {tuple(x.shape)}")
+            s2 = torch.empty_like(x2)
+            _lib.check(L.ign_layernorm_res_fwd(_ptr(x2), _ptr(r2), _ptr(s2), _ptr(weight), _ptr(bias), _ptr(y), _ptr(mean), _ptr(rstd),
+                                               R, D, float(eps), _stream()), "ign_layernorm_res_fwd")
+            x2 = s2
+        else:
+            _lib.check(L.ign_layernorm_fwd(_ptr(x2), _ptr(weight), _ptr(bias), _ptr(y), _ptr(mean), _ptr(rstd), R, D, float(eps),
+                                           _stream()), "ign_layernorm_fwd")
         ctx.save_for_backward(x2, weight, mean, rstd)
         ctx.has_bias = bias is not None
+        ctx.has_res = res is not None
         return y.view(x.shape)
 
     @staticmethod
@@ -751,7 +764,7 @@ class LayerNormFn(torch.autograd.Function):
         g2 = gy.reshape(R, D)
         g2 = g2 if g2.is_contiguous() else g2.contiguous()
         gx = torch.empty_like(x2)
-        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        need_w = ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3])
         dgamma = torch.empty(D, device=x2.device, dtype=torch.float32) if need_w else None
         dbeta = torch.empty(D, device=x2.device, dtype=torch.float32) if need_w and ctx.has_bias else None
         part = torch.empty(int(L.ign_layernorm_parts(R, D)) * 2 * D, device=x2.device, dtype=torch.float32)
@@ -765,20 +778,21 @@ class LayerNormFn(torch.autograd.Function):
         else:
             _lib.check(L.ign_layernorm_bwd(_ptr(x2), _ptr(g2), _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(dgamma), _ptr(dbeta),
                                            _ptr(part), R, D, _stream()), "ign_layernorm_bwd")
-        return gxv, dgamma, dbeta, None
+        return gxv, (gxv if ctx.has_res else None), dgamma, dbeta, None          # d(x + res): the same gradient for both addends
 
 
-def layer_norm(x, norm):
+def layer_norm(x, norm, residual=None):
     """Apply an nn.LayerNorm module (normalised over the last dimension, affine) on the hand-written kernels; shapes they do not
-    cover go through the module itself (torch on the GPU)."""
+    cover go through the module itself (torch on the GPU).  `residual`: normalise x + residual (the add rides on the same pass)."""
     D = x.shape[-1]
     # torch's kernels fall off the memory roofline for many narrow rows (Transformer: 256 000 rows of 512, 96.9 -> 94.9 ms/step;
     # PatchTST: 3.9 M rows of 64, 123.9 -> 79.4 ms/step); for few rows (EEG-CNN: 25 600 rows of 512) the grid is sized by the row
     # count and the d(gamma) partials are reduced in parallel: 22 / 37 us per call against torch's 34 / 97 (7.52 -> 7.36 ms/step)
     if (not x.is_cuda or x.dtype != torch.float32 or norm.weight is None or len(norm.normalized_shape) != 1 or D % 4 or D > 2048
-            or x.numel() == 0 or x.numel() < LAYERNORM_MIN_ROWS * D):
-        return norm(x)
-    out = LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
+            or x.numel() == 0 or x.numel() < LAYERNORM_MIN_ROWS * D
+            or (residual is not None and (residual.shape != x.shape or residual.dtype != x.dtype or not residual.is_cuda))):
+        return norm(x if residual is None else x + residual)
+    out = LayerNormFn.apply(x, residual, norm.weight, norm.bias, norm.eps)
     if GEMM_MATH == "f16x3" and norm.bias is not None and not torch.is_autocast_enabled():
         # a row standardised with its own mean and (biased) variance over D elements cannot exceed sqrt(D - 1): the output is
         # bounded by max_d(|gamma_d| sqrt(D - 1) + |beta_d|) -- from the parameters alone, one tiny launch instead of a pass over

@@ -22,14 +22,14 @@ class EncoderLayer(nn.Module):
 
     def forward(self, x, attn_mask=None, tau=None, delta=None):
         new_x, attn = self.attention(x, x, x, attn_mask=attn_mask, tau=tau, delta=delta)
-        x = ops.layer_norm(x + self.dropout(new_x), self.norm1)
+        x = ops.layer_norm(x, self.norm1, residual=self.dropout(new_x))       # LayerNorm(x + attention(x)): the add rides on the pass
         # the k=1 convolutions are plain GEMMs over (B*T, d): apply them without the two transposes
         u = ops.linear(x, self.conv1.weight.squeeze(-1), self.conv1.bias)
         y = self.activation(u)
         if self.training and self.dropout.p > 0:
             y = self.dropout(y)
         y = self.dropout(ops.linear(y, self.conv2.weight.squeeze(-1), self.conv2.bias))
-        return ops.layer_norm(x + y, self.norm2), attn
+        return ops.layer_norm(x, self.norm2, residual=y), attn
 
 
 class Encoder(nn.Module):

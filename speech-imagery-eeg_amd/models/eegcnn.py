@@ -185,13 +185,13 @@ def _encoder_layer_forward(layer, x, n_heads):
     qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias).view(B, S, 3, n_heads, d // n_heads)
     o = ops.attention_packed(qkv, 1.0 / math.sqrt(d // n_heads))      # gradients land in one packed buffer
     a = ops.linear(o.reshape(B, S, d), sa.out_proj.weight, sa.out_proj.bias)
-    x = ops.layer_norm(x + layer.dropout1(a), layer.norm1)
+    x = ops.layer_norm(x, layer.norm1, residual=layer.dropout1(a))
     u = ops.linear(x, layer.linear1.weight, layer.linear1.bias)
     hdn = ops.relu(u)                                               # (magnitude bound handed on in both directions)
     if layer.training and layer.dropout.p > 0:
         hdn = layer.dropout(hdn)
     ff = ops.linear(hdn, layer.linear2.weight, layer.linear2.bias)
-    return ops.layer_norm(x + layer.dropout2(ff), layer.norm2)
+    return ops.layer_norm(x, layer.norm2, residual=layer.dropout2(ff))
 
 
 class EEGCNNTransformer(nn.Module):

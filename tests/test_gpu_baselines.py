@@ -647,6 +647,42 @@ def test_layer_norm_against_float64(shape, bias, monkeypatch):
     assert torch.equal(g1[0], xg.grad) and torch.equal(g1[1], lg.weight.grad)
 
 
+@pytest.mark.parametrize("shape", [(1000, 64), (3, 100, 512), (2, 5, 2048), (130, 12), (1, 1, 128)])
+def test_layer_norm_with_the_residual_add_in_the_same_pass(shape, monkeypatch):
+    """ops.layer_norm(x, norm, residual=r) (ign_layernorm_res_fwd) == LayerNorm(x + r): output and all four gradients against
+    float64 torch, and bitwise against the two-launch route on the same kernels (torch add, then ign_layernorm_fwd)."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    monkeypatch.setattr(ops, "LAYERNORM_MIN_ROWS", 0)
+    D = shape[-1]
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x, r, gy = (torch.randn(*shape, generator=g) * 2 + 0.5, torch.randn(*shape, generator=g), torch.randn(*shape, generator=g))
+    ln = torch.nn.LayerNorm(D)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_(0, 0.3)
+    ref = torch.nn.LayerNorm(D).double()
+    ref.load_state_dict({k: v.double() for k, v in ln.state_dict().items()})
+    xd, rd = x.double().requires_grad_(True), r.double().requires_grad_(True)
+    yd = ref(xd + rd)
+    (yd * gy.double()).sum().backward()
+    lg = ln.to(dev)
+    res = {}
+    for fused in (True, False):
+        lg.zero_grad(set_to_none=True)
+        xg, rg = x.to(dev).requires_grad_(True), r.to(dev).requires_grad_(True)
+        y = ops.layer_norm(xg, lg, residual=rg) if fused else ops.layer_norm(xg + rg, lg)
+        (y * gy.to(dev)).sum().backward()
+        res[fused] = (y.detach(), xg.grad, rg.grad, lg.weight.grad.clone(), lg.bias.grad.clone())
+    y, gx, gr, gw, gb = res[True]
+    assert _rel(y, yd) < 2e-6 and _rel(gx, xd.grad) < 5e-6 and _rel(gr, rd.grad) < 5e-6
+    assert _rel(gw, ref.weight.grad) < 1e-5 and _rel(gb, ref.bias.grad) < 1e-5
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    assert gx.data_ptr() != gr.data_ptr() or not (xg.is_leaf and rg.is_leaf)      # two leaves never share one gradient buffer
+
+
 # ------------------------------------------------------------------ size-independent properties at the benchmark shape (B=256, L=1000)
 def test_attention_x6_full_size_batch_independence_and_linearity():
     """B=256, H=8, L=S=1000, E=64 (the Transformer baseline's attention): every sample's output / gradients equal those of a
