@@ -297,9 +297,31 @@ long long ign_autocorr_parts(int rows);
 int ign_autocorr_fwd(const float* x_rows, float* part, int rows, int T, int K, void* stream);
 /* The edge terms of that Gram matrix: per row only the first / last k-1 samples of the zero-padded row xp (left pad pad_left)
  * enter.  part: (ign_edge_lagprod_parts(rows), 2, 124, 128) floats, [b][0][s][d] = sum over the block's rows of xp[s] xp[s+d]
- * (head, s + d < k-1), [b][1][s][d] = the same at xp[T+s] (tail); summed over b by the caller in double.  k <= 125.          */
+ * (head, s + d < k-1), [b][1][s][d] = the same at xp[T+s] (tail); summed over b by the caller in double.  k <= 125.  Column
+ * d = 127 (never a lag) carries the plain column sums of the same samples: [b][0][s][127] = sum xp[s], [b][1][s][127] = sum
+ * xp[T+s] -- what the zero padding removes from the per-tap sums behind BatchNorm-1's batch MEAN (ign_bn1_gram).                */
 long long ign_edge_lagprod_parts(int rows);
 int ign_edge_lagprod_fwd(const float* x_rows, float* part, int rows, int T, int k, int pad_left, void* stream);
+/* BatchNorm-1 of the EEG-CNN block (IGN/model/eegcnn.py:90-91: batch statistics of the (B, F1, C, T) temporal convolution that is
+ * never formed) from data statistics, in three small launches instead of ~45 float64 library kernels (cumsum / flip / cat /
+ * gather / einsum and their autograd):
+ *   ign_bn1_gram      C (k), D = sum of the ign_edge_lagprod_fwd partials (2, 124, 128), total = sum of all samples (device scalar)
+ *                     -> the window Gram matrix G (k, k) and the per-tap sums S (k), float64:
+ *                        G[j][j+d] = C[d] - sum_{s<j} D[0][s][d] - sum_{s>=j} D[1][s][d],  S[j] = total - (samples tap j never sees)
+ *   ign_bn1_fold_fwd  per filter f: mu = w_f . S / n, var = w_f^T G w_f / n - mu^2, a = gamma_f / sqrt(var + eps), b = beta_f - a mu;
+ *                     outputs alpha[f D + i] = a, cshift[f D + i] = b * rs[f D + i] (rs = row sums of the depthwise weights: the
+ *                     affine map of BatchNorm-1 as it enters the fused BatchNorm-2 op), updates the running statistics
+ *                     (nullable) with `momentum`, saves G w_f, mu, var, 1/sqrt for the backward
+ *   ign_bn1_fold_bwd  gradients of w1 (F1, k), gamma, beta and rs from those of alpha / cshift (closed form: d mu = S / n,
+ *                     d var = 2 G w / n - 2 mu S / n).
+ * k <= 125, F1 * D <= 4096.                                                                                                    */
+int ign_bn1_gram(const double* C, const double* D, const float* total, double* G, double* S, int k, int pad_left, void* stream);
+int ign_bn1_fold_fwd(const float* w1, const float* gamma, const float* beta, const float* rs, const double* G, const double* S,
+                     double n, float eps, float momentum, float* running_mean, float* running_var, float* alpha, float* cshift,
+                     double* saved /* (F1, k + 4) */, int F1, int k, int Dm, void* stream);
+int ign_bn1_fold_bwd(const float* g_alpha, const float* g_cshift, const float* w1, const float* gamma, const float* rs,
+                     const double* S, const double* saved, double n, float* g_w1, float* g_gamma, float* g_beta, float* g_rs,
+                     int F1, int k, int Dm, void* stream);
 /* Depthwise (per-channel) 1-D convolution over time, zero 'same' padding: y[b,c,t] = sum_j w[c,j] xpad[b,c,t+j].
  * Replaces the temporal convolutions of IGN/model/eegcnn.py:67 (after the channel contraction) and :78 (block2_conv1).
  * flip=1 correlates with the reversed filter (gradient w.r.t. x: call with dy and pad_left = k-1-pad_left).

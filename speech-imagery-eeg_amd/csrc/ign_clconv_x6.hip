@@ -136,9 +136,6 @@ __device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const
 #endif
 constexpr int X6T_SPAN = TM + 15;                  // k <= 16
 constexpr int X6T_APLANE = X6T_SPAN * X6_PITCH;
-constexpr int X6T_ABUF = 3 * X6T_APLANE;
-constexpr int X6T_BBUF = 3 * X6_PLANE;
-constexpr size_t X6T_LDS_BYTES = (size_t)2 * (X6T_ABUF + X6T_BBUF) * sizeof(unsigned short);
 
 // LDS of one workgroup: two stages of NPL operand planes each (NPL = 2 for the fp16 arithmetic: 52 KB, three workgroups per CU
 // -- the register budget below is set to match; 3 otherwise: 78 KB, two workgroups per CU)
@@ -736,8 +733,6 @@ __global__ void __launch_bounds__(256, ((NP == 2 && KT <= 5) ? IGN_H3_WAVES : 2)
 // barrier.  Same staging (row-major, one split per element), same transposing reads, same fixed-order reduction of the splits.
 constexpr int W1_PITCH = 128 + 32;            // bf16 per staged row: 320 B; rows 0..3 of a block start 16 banks apart
 constexpr int W1_PLANE = 16 * W1_PITCH;
-constexpr int W1_STAGE = 6 * W1_PLANE;        // three dy planes + three x planes
-constexpr size_t W1_LDS_BYTES = (size_t)2 * W1_STAGE * sizeof(unsigned short);
 
 struct Wgrad1Args {
     const float* dy; const float* x; float* part;      // dy (M, Co), x (M, Ci), part (nsplit, Co, Ci)

@@ -471,6 +471,7 @@ __global__ void __launch_bounds__(256) edge_lagprod_kernel(const float* __restri
     float ah[EG_HALF], at[EG_HALF];
 #pragma unroll
     for (int i = 0; i < EG_HALF; ++i) { ah[i] = 0.f; at[i] = 0.f; }
+    float csh = 0.f, cst = 0.f;            // thread i < m: column sums of xp[i] and xp[T + i] over the block's rows (column 127)
     for (int r = r0; r < r1; ++r) {
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * EG_MAXM + 8; i += 256) {
@@ -486,6 +487,12 @@ __global__ void __launch_bounds__(256) edge_lagprod_kernel(const float* __restri
             ah[i] = fmaf(hs[s], hs[s + d], ah[i]);
             at[i] = fmaf(ts[s], ts[s + d], at[i]);
         }
+        if (threadIdx.x < EG_MAXM) { csh += hs[threadIdx.x]; cst += ts[threadIdx.x]; }
+    }
+    if (threadIdx.x < EG_MAXM) {
+        float* pb = part + (size_t)blockIdx.x * 2 * EG_MAXM * 128;
+        pb[(size_t)threadIdx.x * 128 + 127] = csh;
+        pb[(size_t)(EG_MAXM + threadIdx.x) * 128 + 127] = cst;
     }
     if (d < k) {
         float* pb = part + (size_t)blockIdx.x * 2 * EG_MAXM * 128;
@@ -753,7 +760,8 @@ extern "C" int ign_autocorr_fwd(const float* x, float* part, int rows, int T, in
     return ign_check_launch("autocorr_kernel");
 }
 
-// part: (ign_edge_lagprod_parts(rows), 2, 124, 128) floats; [.,0,s,d] head products, [.,1,s,d] tail products (s >= k-1 rows and
+// part: (ign_edge_lagprod_parts(rows), 2, 124, 128) floats; [.,0,s,d] head products, [.,1,s,d] tail products; column 127 (never a
+// lag: k <= 125) carries the column sums [.,0,s,127] = sum_rows xp[s], [.,1,s,127] = sum_rows xp[T+s] (s >= k-1 rows and
 // d >= k columns are zero / unwritten garbage-free: the kernel writes every (s < 124, d < k) slot).  k <= 125.
 extern "C" long long ign_edge_lagprod_parts(int rows) { return rows > 0 ? std::min(256, rows) : 0; }
 

@@ -1,0 +1,153 @@
+// BatchNorm-1 of the EEG-CNN block from data statistics (IGN/model/eegcnn.py:90-91; models/eegcnn.py::_forward_hip).
+// The batch mean and variance of y[f] = w1[f] (*) x over (batch, electrode, time) are a linear and a quadratic form in the filter:
+//     mean_f = w_f . S / n,      E[y_f^2] = w_f^T G w_f / n,
+// S[j] = sum of the samples tap j sees, G[j][j'] = sum_{rows,t} xp[t+j] xp[t+j'] (xp = the zero-padded row) -- both from one pass
+// over the data (ign_autocorr_fwd, ign_edge_lagprod_fwd).  Rounds 1-3 assembled G and the forms with float64 torch ops (cumsum,
+// flip, cat, gather, einsum + autograd: ~45 launches of a few microseconds each per step); these three kernels do the same
+// arithmetic in float64 in three launches.  Tiny problems (k <= 125 taps, F1 = 8 filters): latency, not throughput.
+#include "ign_common.h"
+
+constexpr int B1_MAXM = 124, B1_LD = 128;           // layout of the summed edge partials: (2, 124, 128), column 127 = column sums
+
+// One block, thread d < k walks the d-th diagonal of G with running prefix / suffix sums of the edge terms.
+__global__ void __launch_bounds__(128) bn1_gram_kernel(const double* __restrict__ C, const double* __restrict__ D,
+                                                       const float* __restrict__ total, double* __restrict__ G,
+                                                       double* __restrict__ S, int k, int pl) {
+    const int d = threadIdx.x, m = k - 1;
+    const double* Dh = D;
+    const double* Dt = D + (size_t)B1_MAXM * B1_LD;
+    if (d < k) {
+        // G[j][j+d] = C[d] - sum_{s<j} Dh[s][d] - sum_{s>=j} Dt[s][d],  j = 0 .. k-1-d   (entries with s + d >= m are zero by construction)
+        double pt = 0.0;
+        for (int s = 0; s < m; ++s) pt += Dt[(size_t)s * B1_LD + d];
+        double ph = 0.0;
+        const double c = C[d];
+        for (int j = 0; j + d < k; ++j) {
+            const double g = c - ph - pt;
+            G[(size_t)j * k + j + d] = g;
+            G[(size_t)(j + d) * k + j] = g;
+            if (j < m) { ph += Dh[(size_t)j * B1_LD + d]; pt -= Dt[(size_t)j * B1_LD + d]; }
+        }
+        // S[j]: all samples minus those tap j never sees.  Column 127 holds ch[i] = sum_rows xp[i] and ct[i] = sum_rows xp[T+i];
+        // x[t] = xp[pl + t].  Tap j < pl misses the LAST pl - j samples, tap j > pl the FIRST j - pl.
+        const int j = d;
+        double miss = 0.0;
+        if (j < pl)      for (int i = j; i < pl; ++i) miss += Dt[(size_t)i * B1_LD + 127];
+        else if (j > pl) for (int t = 0; t < j - pl; ++t) miss += Dh[(size_t)(pl + t) * B1_LD + 127];
+        S[j] = (double)total[0] - miss;
+    }
+}
+
+__device__ __forceinline__ double block_sum_128(double v, double* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double t = sh[0] + sh[1];
+    __syncthreads();
+    return t;
+}
+
+// saved[f][0..k) = u = G w_f;  saved[f][k..k+4) = mu, var, r = 1/sqrt(var + eps) (as the float the forward used), b1
+__global__ void __launch_bounds__(128) bn1_fold_fwd_kernel(const float* __restrict__ w1, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ rs,
+                                                           const double* __restrict__ G, const double* __restrict__ S, double n,
+                                                           float eps, float momentum, float* __restrict__ run_mean,
+                                                           float* __restrict__ run_var, float* __restrict__ alpha,
+                                                           float* __restrict__ cshift, double* __restrict__ saved, int k, int Dm) {
+    __shared__ double sh[2];
+    __shared__ float wf[128];
+    const int f = blockIdx.x, j = threadIdx.x;
+    wf[j] = j < k ? w1[(size_t)f * k + j] : 0.f;
+    __syncthreads();
+    double u = 0.0;
+    if (j < k)
+        for (int jp = 0; jp < k; ++jp) u = fma(G[(size_t)jp * k + j], (double)wf[jp], u);      // G symmetric: column j, coalesced
+    const double q = block_sum_128(j < k ? (double)wf[j] * u : 0.0, sh);
+    const double ms = block_sum_128(j < k ? (double)wf[j] * S[j] : 0.0, sh);
+    const float mu1 = (float)(ms / n);                                 // the float the rest of the network sees
+    const float var1 = (float)(q / n - (double)mu1 * (double)mu1);
+    const float r = 1.f / sqrtf(var1 + eps);
+    const float a1 = gamma[f] * r;
+    const float b1 = beta[f] - a1 * mu1;
+    double* sv = saved + (size_t)f * (k + 4);
+    if (j < k) sv[j] = u;
+    if (j == 0) {
+        sv[k] = (double)mu1; sv[k + 1] = (double)var1; sv[k + 2] = (double)r; sv[k + 3] = (double)b1;
+        if (run_mean) {
+            run_mean[f] = (1.f - momentum) * run_mean[f] + momentum * mu1;
+            run_var[f] = (1.f - momentum) * run_var[f] + momentum * (float)((double)var1 * (n / (n - 1.0)));
+        }
+    }
+    for (int i = j; i < Dm; i += 128) {
+        alpha[(size_t)f * Dm + i] = a1;
+        cshift[(size_t)f * Dm + i] = b1 * rs[(size_t)f * Dm + i];
+    }
+}
+
+__global__ void __launch_bounds__(128) bn1_fold_bwd_kernel(const float* __restrict__ g_alpha, const float* __restrict__ g_cshift,
+                                                           const float* __restrict__ gamma, const float* __restrict__ rs,
+                                                           const double* __restrict__ S, const double* __restrict__ saved,
+                                                           double n, float* __restrict__ g_w1, float* __restrict__ g_gamma,
+                                                           float* __restrict__ g_beta, float* __restrict__ g_rs, int k, int Dm) {
+    __shared__ double sh[2];
+    const int f = blockIdx.x, j = threadIdx.x;
+    const double* sv = saved + (size_t)f * (k + 4);
+    const double mu = sv[k], r = sv[k + 2], b1 = sv[k + 3];
+    double ga = 0.0, gb = 0.0;
+    for (int i = j; i < Dm; i += 128) {
+        const double gc = (double)g_cshift[(size_t)f * Dm + i];
+        ga += (double)g_alpha[(size_t)f * Dm + i];
+        gb += gc * (double)rs[(size_t)f * Dm + i];
+        g_rs[(size_t)f * Dm + i] = (float)(gc * b1);
+    }
+    ga = block_sum_128(ga, sh);
+    gb = block_sum_128(gb, sh);
+    // a = gamma r, b = beta - a mu, r = (var + eps)^(-1/2)
+    const double gam = (double)gamma[f];
+    const double g_a = ga - gb * mu;                   // dL/da including the path through b
+    const double g_mu = -gb * gam * r;
+    const double g_var = g_a * gam * (-0.5 * r * r * r);
+    if (j == 0) { g_gamma[f] = (float)(g_a * r); g_beta[f] = (float)gb; }
+    if (j < k) {
+        const double Sj = S[j];
+        g_w1[(size_t)f * k + j] = (float)(g_mu * Sj / n + g_var * (2.0 * sv[j] / n - 2.0 * mu * Sj / n));
+    }
+}
+
+extern "C" int ign_bn1_gram(const double* C, const double* D, const float* total, double* G, double* S, int k, int pad_left,
+                            void* stream) {
+    if (!C || !D || !total || !G || !S || k < 2 || k - 1 > B1_MAXM || pad_left < 0 || pad_left >= k) {
+        ign_set_error("ign_bn1_gram: null pointer or k=%d outside 2..%d or pad_left=%d", k, B1_MAXM + 1, pad_left);
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(bn1_gram_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, C, D, total, G, S, k, pad_left);
+    return ign_check_launch("bn1_gram_kernel");
+}
+
+extern "C" int ign_bn1_fold_fwd(const float* w1, const float* gamma, const float* beta, const float* rs, const double* G,
+                                const double* S, double n, float eps, float momentum, float* running_mean, float* running_var,
+                                float* alpha, float* cshift, double* saved, int F1, int k, int Dm, void* stream) {
+    if (!w1 || !gamma || !beta || !rs || !G || !S || !alpha || !cshift || !saved || F1 <= 0 || k < 2 || k > 128 || Dm <= 0
+        || (long long)F1 * Dm > 4096 || n <= 1.0 || (running_mean != nullptr) != (running_var != nullptr)) {
+        ign_set_error("ign_bn1_fold_fwd: null pointer or bad shape (F1=%d k=%d D=%d n=%g)", F1, k, Dm, n);
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(bn1_fold_fwd_kernel, dim3(F1), dim3(128), 0, (hipStream_t)stream, w1, gamma, beta, rs, G, S, n, eps, momentum,
+                       running_mean, running_var, alpha, cshift, saved, k, Dm);
+    return ign_check_launch("bn1_fold_fwd_kernel");
+}
+
+extern "C" int ign_bn1_fold_bwd(const float* g_alpha, const float* g_cshift, const float* w1, const float* gamma, const float* rs,
+                                const double* S, const double* saved, double n, float* g_w1, float* g_gamma, float* g_beta,
+                                float* g_rs, int F1, int k, int Dm, void* stream) {
+    (void)w1;
+    if (!g_alpha || !g_cshift || !gamma || !rs || !S || !saved || !g_w1 || !g_gamma || !g_beta || !g_rs || F1 <= 0 || k < 2 || k > 128
+        || Dm <= 0 || (long long)F1 * Dm > 4096 || n <= 1.0) {
+        ign_set_error("ign_bn1_fold_bwd: null pointer or bad shape (F1=%d k=%d D=%d n=%g)", F1, k, Dm, n);
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(bn1_fold_bwd_kernel, dim3(F1), dim3(128), 0, (hipStream_t)stream, g_alpha, g_cshift, gamma, rs, S, saved, n, g_w1,
+                       g_gamma, g_beta, g_rs, k, Dm);
+    return ign_check_launch("bn1_fold_bwd_kernel");
+}

@@ -13,7 +13,7 @@ _LIB = None
 
 c_f = ctypes.POINTER(ctypes.c_float)
 c_i32 = ctypes.POINTER(ctypes.c_int32)
-vp, ci, cf, sz, ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_longlong
+vp, ci, cf, sz, ll, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_longlong, ctypes.c_double
 
 # name -> (restype, argtypes); must list every symbol include/ign_abi.h declares (tests/test_abi_symbols.py)
 SIGNATURES = {
@@ -27,6 +27,9 @@ SIGNATURES = {
     "ign_shapelet_bwd_workspace_bytes": (sz, [ci, ci, ci, ci, ci, ci, ci]),
     "ign_layernorm_parts": (ll, [ll, ci]),
     "ign_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ll, ci, cf, vp]),
+    "ign_bn1_gram": (ci, [vp, vp, vp, vp, vp, ci, ci, vp]),
+    "ign_bn1_fold_fwd": (ci, [vp, vp, vp, vp, vp, vp, cd, cf, cf, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
+    "ign_bn1_fold_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, cd, vp, vp, vp, vp, ci, ci, ci, vp]),
     "ign_layernorm_res_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, cf, vp]),
     "ign_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp]),
     "ign_layernorm_bwd_amax": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp]),

@@ -1067,6 +1067,69 @@ def conv1_sumsq(x_rows, w1, mu, pad_left):
     return Conv1SumSqFn.apply(x_rows, w1, mu, pad_left)
 
 
+def bn1_data_stats(x_rows, k, pad_left):
+    """(G, S), float64: the window Gram matrix (k, k) and the per-tap sums (k) of the zero-padded rows of `x_rows` (R, T) -- the
+    data side of BatchNorm-1's batch statistics (models/eegcnn.py).  Two passes over the data (ign_autocorr_fwd: lag sums;
+    ign_edge_lagprod_fwd: edge terms and column sums of the first / last k-1 samples), one over it for the total, three partial
+    sums in float64, one assembly launch (ign_bn1_gram).  No gradient: the operand is input data.  k <= 125, T >= k."""
+    _need_gpu("bn1_data_stats", x_rows)
+    L = _lib.lib()
+    x_rows = x_rows.contiguous()
+    R, T = x_rows.shape
+    dev = x_rows.device
+    C = autocorr(x_rows, k)
+    part = torch.empty(int(L.ign_edge_lagprod_parts(R)), 2, 124, 128, device=dev, dtype=torch.float32)
+    _lib.check(L.ign_edge_lagprod_fwd(_ptr(x_rows), _ptr(part), R, T, int(k), int(pad_left), _stream()), "ign_edge_lagprod_fwd")
+    D = part.sum(dim=0, dtype=torch.float64)             # (2, 124, 128); columns k..126 are never written nor read
+    total = x_rows.sum().reshape(1)
+    G = torch.empty(k, k, device=dev, dtype=torch.float64)
+    S = torch.empty(k, device=dev, dtype=torch.float64)
+    _lib.check(L.ign_bn1_gram(_ptr(C), _ptr(D), _ptr(total), _ptr(G), _ptr(S), int(k), int(pad_left), _stream()), "ign_bn1_gram")
+    return G, S
+
+
+class Bn1FoldFn(torch.autograd.Function):
+    """(w1 (F1,k), gamma, beta (F1), rs (F1*D)) -> (alpha, cshift) (F1*D each): BatchNorm-1 with batch statistics folded into the
+    per-channel affine map the fused BatchNorm-2 op absorbs -- mean and variance are the linear / quadratic form of the filter
+    over the data statistics (S, G), so forward and backward are closed-form in the parameters (ign_bn1_fold_fwd / _bwd).
+    Running statistics (nullable) are updated by the forward launch."""
+
+    @staticmethod
+    def forward(ctx, w1, gamma, beta, rs, G, S, n, eps, momentum, run_mean, run_var, Dm):
+        _need_gpu("bn1_fold", w1, gamma, beta, rs)
+        L = _lib.lib()
+        w1, gamma, beta, rs = w1.contiguous(), gamma.contiguous(), beta.contiguous(), rs.contiguous()
+        F1, k = w1.shape
+        alpha = torch.empty(F1 * Dm, device=w1.device, dtype=torch.float32)
+        cshift = torch.empty_like(alpha)
+        saved = torch.empty(F1, k + 4, device=w1.device, dtype=torch.float64)
+        _lib.check(L.ign_bn1_fold_fwd(_ptr(w1), _ptr(gamma), _ptr(beta), _ptr(rs), _ptr(G), _ptr(S), float(n), float(eps),
+                                      float(momentum), _ptr(run_mean), _ptr(run_var), _ptr(alpha), _ptr(cshift), _ptr(saved), F1, k,
+                                      int(Dm), _stream()), "ign_bn1_fold_fwd")
+        ctx.save_for_backward(w1, gamma, rs, S, saved)
+        ctx.meta = (float(n), int(Dm))
+        return alpha, cshift
+
+    @staticmethod
+    def backward(ctx, g_alpha, g_cshift):
+        w1, gamma, rs, S, saved = ctx.saved_tensors
+        n, Dm = ctx.meta
+        F1, k = w1.shape
+        g_alpha, g_cshift = g_alpha.contiguous(), g_cshift.contiguous()
+        g_w1 = torch.empty_like(w1)
+        g_gamma = torch.empty_like(gamma)
+        g_beta = torch.empty_like(gamma)
+        g_rs = torch.empty_like(rs)
+        _lib.check(_lib.lib().ign_bn1_fold_bwd(_ptr(g_alpha), _ptr(g_cshift), _ptr(w1), _ptr(gamma), _ptr(rs), _ptr(S), _ptr(saved), n,
+                                               _ptr(g_w1), _ptr(g_gamma), _ptr(g_beta), _ptr(g_rs), F1, k, Dm, _stream()),
+                   "ign_bn1_fold_bwd")
+        return g_w1, g_gamma, g_beta, g_rs, None, None, None, None, None, None, None, None
+
+
+def bn1_fold(w1, gamma, beta, rs, G, S, n, eps, momentum, running_mean, running_var, Dm):
+    return Bn1FoldFn.apply(w1, gamma, beta, rs, G, S, n, eps, momentum, running_mean, running_var, Dm)
+
+
 class DwConv1dFn(torch.autograd.Function):
     """Depthwise 'same' 1-D convolution y[b,c,t] = sum_j w[c,j] xpad[b,c,t+j]  (ign_dwconv1d_*)."""
 

@@ -134,7 +134,25 @@ class EEGcnn(nn.Module):
         D = w2.shape[0] // F1
         pl1 = (k1 - 1) // 2
         x = x.contiguous()
-        if bn1.training or not bn1.track_running_stats:
+        batch_stats = bn1.training or not bn1.track_running_stats
+        if batch_stats and _BN1_VARIANCE == "gram" and 2 <= k1 <= 125 and T >= k1 and bn1.weight is not None \
+                and (bn1.momentum is not None or not bn1.track_running_stats):
+            # BatchNorm-1's batch statistics are a linear / quadratic form of the filter over statistics of the INPUT (per-tap sums
+            # S, window Gram matrix G: two passes over x for all filters, no pass over the (B,F1,C,T) convolution): data statistics,
+            # then mean / variance / affine fold and their gradients in closed form (ops.bn1_fold), running statistics included
+            with torch.no_grad():
+                G, S = ops.bn1_data_stats(x.view(B * C, T), k1, pl1)
+                track = bn1.track_running_stats and bn1.training
+                if track:
+                    bn1.num_batches_tracked.add_(1)
+            alpha, cshift = ops.bn1_fold(w1, bn1.weight, bn1.bias, w2.sum(dim=1), G, S, B * C * T, bn1.eps,
+                                         bn1.momentum if track else 0.0, bn1.running_mean if track else None,
+                                         bn1.running_var if track else None, D)
+            u = ops.chan_contract(x, w2)
+            v = ops.dwconv1d(u, w1.repeat_interleave(D, dim=0), pl1)
+            h = ops.bn_elu_pool(v, self.block1_bn2, self.block1_pool.kernel_size[1], alpha=alpha, cshift=cshift)
+            return self._block2(self.block1_drop(h))
+        if batch_stats:
             n = B * C * T
             mu1 = (w1 @ self._shifted_sums(x, k1, pl1)) / n
             if _BN1_VARIANCE == "gram" and k1 <= 128 and T >= k1:
@@ -163,7 +181,9 @@ class EEGcnn(nn.Module):
         v = ops.dwconv1d(u, w1.repeat_interleave(D, dim=0), pl1)
         h = ops.bn_elu_pool(v, self.block1_bn2, self.block1_pool.kernel_size[1], alpha=a1.repeat_interleave(D),
                             cshift=b1.repeat_interleave(D) * w2.sum(dim=1))
-        h = self.block1_drop(h)
+        return self._block2(self.block1_drop(h))
+
+    def _block2(self, h):
         # Block 2: depthwise temporal conv -> pointwise 64 -> 64 (the same contraction kernel) -> [BN3, ELU, AvgPool]
         w3 = self.block2_conv1.weight.reshape(self.block2_conv1.weight.shape[0], -1)           # (F1*D, k2)
         q = ops.dwconv1d(h, w3, (w3.shape[1] - 1) // 2)

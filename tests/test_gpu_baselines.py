@@ -610,6 +610,64 @@ def test_window_gram_matrix_equals_brute_force(R, T, k, pl):
     assert _rel(torch.einsum('fj,jk,fk->f', w, G, w), y.square().sum(dim=(0, 2))) < 2e-6
 
 
+@pytest.mark.parametrize("R,T,k,pl", [(7, 200, 125, 62), (33, 1000, 125, 62), (5, 64, 25, 12), (3, 130, 8, 0), (300, 129, 124, 123),
+                                      (2, 40, 2, 1), (700, 125, 125, 0)])
+def test_bn1_data_statistics_equal_brute_force(R, T, k, pl):
+    """ops.bn1_data_stats (lag sums, edge terms and column sums from two kernels, assembled by ign_bn1_gram) against the
+    brute-force Gram matrix and per-tap sums of all zero-padded windows in float64."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    g = torch.Generator().manual_seed(R + T + k)
+    x = torch.randn(R, T, generator=g) + 0.3
+    G, S = ops.bn1_data_stats(x.to(dev), k, pl)
+    xp = F.pad(x.double(), (pl, k - 1 - pl))
+    W = xp.unfold(1, k, 1)[:, :T]
+    Gref = torch.einsum('rtj,rtk->jk', W, W)
+    Sref = W.sum(dim=(0, 1))
+    assert float((G.cpu() - Gref).abs().max() / Gref.abs().max()) < 2e-6
+    assert float((S.cpu() - Sref).abs().max() / Sref.abs().max()) < 2e-6
+    assert torch.equal(G, G.t())
+
+
+@pytest.mark.parametrize("F1,k,D,track", [(8, 125, 8, True), (3, 25, 2, False), (16, 7, 16, True)])
+def test_bn1_fold_against_the_float64_composition(F1, k, D, track):
+    """ops.bn1_fold (ign_bn1_fold_fwd / _bwd): BatchNorm-1 with batch statistics as a closed form in the filter -- outputs, the four
+    parameter gradients and the running-statistics update against the same algebra written with float64 torch ops and autograd."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    g = torch.Generator().manual_seed(F1 * k + D)
+    R, T, pl = 40, 300, (k - 1) // 2
+    x = torch.randn(R, T, generator=g) * 2 + 0.7
+    G, S = ops.bn1_data_stats(x.to(dev), k, pl)
+    n, eps, mom = float(R * T), 1e-5, 0.1
+    w1 = (torch.randn(F1, k, generator=g) / k ** 0.5)
+    gamma, beta = torch.rand(F1, generator=g) + 0.5, torch.randn(F1, generator=g) * 0.2
+    rs = torch.randn(F1 * D, generator=g)
+    ga, gc = torch.randn(F1 * D, generator=g), torch.randn(F1 * D, generator=g)
+    # reference algebra, float64
+    p = [t.double().to(dev).requires_grad_(True) for t in (w1, gamma, beta, rs)]
+    mu = p[0] @ S / n
+    var = torch.einsum('fj,jk,fk->f', p[0], G, p[0]) / n - mu.square()
+    a = p[1] * torch.rsqrt(var + eps)
+    b = p[2] - a * mu
+    alpha_r, cshift_r = a.repeat_interleave(D), b.repeat_interleave(D) * p[3]
+    (alpha_r * ga.double().to(dev) + cshift_r * gc.double().to(dev)).sum().backward()
+    q = [t.to(dev).requires_grad_(True) for t in (w1, gamma, beta, rs)]
+    rm, rv = torch.full((F1,), 0.25, device=dev), torch.full((F1,), 1.5, device=dev)
+    alpha, cshift = ops.bn1_fold(*q, G, S, n, eps, mom if track else 0.0, rm if track else None, rv if track else None, D)
+    (alpha * ga.to(dev) + cshift * gc.to(dev)).sum().backward()
+    assert _rel(alpha, alpha_r) < 2e-6 and _rel(cshift, cshift_r) < 2e-6
+    for name, u, v in zip(("w1", "gamma", "beta", "rs"), q, p):
+        assert _rel(u.grad, v.grad) < 1e-5, name
+    if track:
+        assert _rel(rm, 0.9 * 0.25 + 0.1 * mu.detach()) < 2e-6
+        assert _rel(rv, 0.9 * 1.5 + 0.1 * var.detach() * (n / (n - 1))) < 2e-6
+    else:
+        assert float(rm[0]) == 0.25 and float(rv[0]) == 1.5
+
+
 @pytest.mark.parametrize("shape", [(1000, 64), (7, 33, 16), (3, 100, 512), (2, 5, 2048), (130, 12), (4, 9, 200), (1, 1, 128)])
 @pytest.mark.parametrize("bias", [True, False])
 def test_layer_norm_against_float64(shape, bias, monkeypatch):
