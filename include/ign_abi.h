@@ -305,9 +305,11 @@ int ign_edge_lagprod_fwd(const float* x_rows, float* part, int rows, int T, int 
 /* BatchNorm-1 of the EEG-CNN block (IGN/model/eegcnn.py:90-91: batch statistics of the (B, F1, C, T) temporal convolution that is
  * never formed) from data statistics, in three small launches instead of ~45 float64 library kernels (cumsum / flip / cat /
  * gather / einsum and their autograd):
- *   ign_bn1_gram      C (k), D = sum of the ign_edge_lagprod_fwd partials (2, 124, 128), total = sum of all samples (device scalar)
- *                     -> the window Gram matrix G (k, k) and the per-tap sums S (k), float64:
- *                        G[j][j+d] = C[d] - sum_{s<j} D[0][s][d] - sum_{s>=j} D[1][s][d],  S[j] = total - (samples tap j never sees)
+ *   ign_bn1_data_stats  x (rows, T) -> the window Gram matrix G (k, k) and the per-tap sums S (k), float64, in four launches and no
+ *                     library call: lag sums + row sums (ign_autocorr_sum_fwd), edge terms + column sums of the first / last k-1
+ *                     samples (ign_edge_lagprod_fwd), their per-block partials summed in float64, and the assembly
+ *                        G[j][j+d] = C[d] - sum_{s<j} Dh[s][d] - sum_{s>=j} Dt[s][d],  S[j] = total - (samples tap j never sees).
+ *                     workspace: ign_bn1_data_stats_workspace_bytes.  IGN_E_UNSUP for rows longer than 1024 samples.
  *   ign_bn1_fold_fwd  per filter f: mu = w_f . S / n, var = w_f^T G w_f / n - mu^2, a = gamma_f / sqrt(var + eps), b = beta_f - a mu;
  *                     outputs alpha[f D + i] = a, cshift[f D + i] = b * rs[f D + i] (rs = row sums of the depthwise weights: the
  *                     affine map of BatchNorm-1 as it enters the fused BatchNorm-2 op), updates the running statistics
@@ -315,7 +317,11 @@ int ign_edge_lagprod_fwd(const float* x_rows, float* part, int rows, int T, int 
  *   ign_bn1_fold_bwd  gradients of w1 (F1, k), gamma, beta and rs from those of alpha / cshift (closed form: d mu = S / n,
  *                     d var = 2 G w / n - 2 mu S / n).
  * k <= 125, F1 * D <= 4096.                                                                                                    */
-int ign_bn1_gram(const double* C, const double* D, const float* total, double* G, double* S, int k, int pad_left, void* stream);
+size_t ign_bn1_data_stats_workspace_bytes(int rows, int T, int k);
+int ign_bn1_data_stats(const float* x_rows, int rows, int T, int k, int pad_left, void* workspace, double* G, double* S, void* stream);
+/* ign_autocorr_fwd restricted to its register-tiled kernel (T <= 1024), which then also returns the plain sum of each block's rows:
+ * rowsum_part[p], p < *used_parts = partial rows actually written (later rows of `part` are not touched).                         */
+int ign_autocorr_sum_fwd(const float* x_rows, float* part, float* rowsum_part, int rows, int T, int K, int* used_parts, void* stream);
 int ign_bn1_fold_fwd(const float* w1, const float* gamma, const float* beta, const float* rs, const double* G, const double* S,
                      double n, float eps, float momentum, float* running_mean, float* running_var, float* alpha, float* cshift,
                      double* saved /* (F1, k + 4) */, int F1, int k, int Dm, void* stream);

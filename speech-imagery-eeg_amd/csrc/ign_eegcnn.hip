@@ -375,7 +375,7 @@ constexpr int XC_NA = 4, XC_NB = 6;                // register prefetch of one p
 template <int NT>
 __global__ void __launch_bounds__(256) xcorr_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part,
                                                     int nrows_g /* rows per group */, int Cc, int T, int K, int pl, int lpr, int T4,
-                                                    int BL) {
+                                                    int BL, float* __restrict__ asum_part /* nullable: per-block sum of the a rows */) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int rpp = 256 / lpr;                      // rows per pass
     float* as_ = sm;                                // [rpp][T4]
@@ -409,10 +409,11 @@ __global__ void __launch_bounds__(256) xcorr_kernel(const float* __restrict__ a,
         }
     };
     if (r0 < r1) gload(r0);
+    float asum = 0.f;                               // every a element of the block passes through pa exactly once (0 where masked)
     for (int rb = r0; rb < r1; rb += rpp) {
         __syncthreads();                            // the previous pass has consumed the LDS rows
 #pragma unroll
-        for (int q = 0; q < NA; ++q) { const int i = tid + 256 * q; if (i < rpp * T4) as_[i] = pa[q]; }
+        for (int q = 0; q < NA; ++q) { const int i = tid + 256 * q; if (i < rpp * T4) as_[i] = pa[q]; asum += pa[q]; }
 #pragma unroll
         for (int q = 0; q < NB; ++q) { const int i = tid + 256 * q; if (i < rpp * BL) bs_[i] = pb[q]; }
         __syncthreads();
@@ -452,6 +453,14 @@ __global__ void __launch_bounds__(256) xcorr_kernel(const float* __restrict__ a,
     __syncthreads();
     if (tid < NT * 32 && tid < K)
         part[((size_t)bsl * Cc + ch) * K + tid] = ((red[tid] + red[NT * 32 + tid]) + red[2 * NT * 32 + tid]) + red[3 * NT * 32 + tid];
+    if (asum_part) {                                // block-uniform
+        __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) asum += __shfl_xor(asum, o, 64);
+        if (lane == 0) red[wave] = asum;
+        __syncthreads();
+        if (tid == 0) asum_part[(size_t)bsl * Cc + ch] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
 }
 
 // Edge terms of the window Gram matrix (models/eegcnn.py::_window_gram): per row only the first / last k-1 samples of the
@@ -663,9 +672,9 @@ extern "C" int ign_dwconv1d_bwd_weight(const float* x, const float* dy, float* d
             {
                 IgnScopedTimer tm("dwconv1d_bwd_w", s);
                 if (NT == 1) hipLaunchKernelGGL(xcorr_kernel<1>, dim3(Cc, nsl), dim3(256), l2, s, dy, x, (float*)workspace, B, Cc, T, k,
-                                                pad_left, lpr, T4, BL);
+                                                pad_left, lpr, T4, BL, (float*)nullptr);
                 else         hipLaunchKernelGGL(xcorr_kernel<4>, dim3(Cc, nsl), dim3(256), l2, s, dy, x, (float*)workspace, B, Cc, T, k,
-                                                pad_left, lpr, T4, BL);
+                                                pad_left, lpr, T4, BL, (float*)nullptr);
             }
             if ((rc = ign_check_launch("xcorr_kernel"))) return rc;
             ign_launch_reduce_parts((const float*)workspace, dw, nsl, (size_t)Cc * k, s);
@@ -746,8 +755,8 @@ extern "C" int ign_autocorr_fwd(const float* x, float* part, int rows, int T, in
             hipStream_t s = (hipStream_t)stream;
             if (nparts > nsl) (void)hipMemsetAsync(part + (size_t)nsl * K, 0, (size_t)(nparts - nsl) * K * sizeof(float), s);
             IgnScopedTimer tm("autocorr", s);
-            if (NT == 1) hipLaunchKernelGGL(xcorr_kernel<1>, dim3(1, nsl), dim3(256), l2, s, x, x, part, rows, 1, T, K, 0, lpr, T4, BL);
-            else         hipLaunchKernelGGL(xcorr_kernel<4>, dim3(1, nsl), dim3(256), l2, s, x, x, part, rows, 1, T, K, 0, lpr, T4, BL);
+            if (NT == 1) hipLaunchKernelGGL(xcorr_kernel<1>, dim3(1, nsl), dim3(256), l2, s, x, x, part, rows, 1, T, K, 0, lpr, T4, BL, (float*)nullptr);
+            else         hipLaunchKernelGGL(xcorr_kernel<4>, dim3(1, nsl), dim3(256), l2, s, x, x, part, rows, 1, T, K, 0, lpr, T4, BL, (float*)nullptr);
             return ign_check_launch("xcorr_kernel");
         }
     }
@@ -758,6 +767,29 @@ extern "C" int ign_autocorr_fwd(const float* x, float* part, int rows, int T, in
     IgnScopedTimer tm("autocorr", (hipStream_t)stream);
     hipLaunchKernelGGL(autocorr_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, x, part, rows, T, K, xs_len);
     return ign_check_launch("autocorr_kernel");
+}
+
+// ign_autocorr_fwd on the register-tiled kernel only (rows of <= 1024 samples), which then also returns the plain sum of its rows per
+// block: rowsum_part[p], p < *used_parts = the partial rows actually written (part rows beyond are NOT touched).
+extern "C" int ign_autocorr_sum_fwd(const float* x, float* part, float* rowsum_part, int rows, int T, int K, int* used_parts,
+                                    void* stream) {
+    static const char* who = "ign_autocorr_sum_fwd";
+    if (!x || !part || !rowsum_part || !used_parts || rows <= 0 || T <= 0 || K <= 0) {
+        ign_set_error("%s: bad argument (rows=%d T=%d K=%d)", who, rows, T, K);
+        return IGN_E_ARG;
+    }
+    int lpr, T4, BL, NT; size_t l2;
+    if (K > AC_LAGS || !xcorr_geometry(T, K, &lpr, &T4, &BL, &NT, &l2)) {
+        ign_set_error("%s: T=%d K=%d outside the register-tiled kernel (T <= 1024, K <= 128)", who, T, K);
+        return IGN_E_UNSUP;
+    }
+    const int nsl = (rows + XC_ROWS - 1) / XC_ROWS;
+    hipStream_t s = (hipStream_t)stream;
+    IgnScopedTimer tm("autocorr", s);
+    if (NT == 1) hipLaunchKernelGGL(xcorr_kernel<1>, dim3(1, nsl), dim3(256), l2, s, x, x, part, rows, 1, T, K, 0, lpr, T4, BL, rowsum_part);
+    else         hipLaunchKernelGGL(xcorr_kernel<4>, dim3(1, nsl), dim3(256), l2, s, x, x, part, rows, 1, T, K, 0, lpr, T4, BL, rowsum_part);
+    *used_parts = nsl;
+    return ign_check_launch("xcorr_kernel");
 }
 
 // part: (ign_edge_lagprod_parts(rows), 2, 124, 128) floats; [.,0,s,d] head products, [.,1,s,d] tail products; column 127 (never a

@@ -9,19 +9,59 @@
 
 constexpr int B1_MAXM = 124, B1_LD = 128;           // layout of the summed edge partials: (2, 124, 128), column 127 = column sums
 
+// Float64 sums of the fp32 per-block partials of the two data passes, one launch:
+//   blocks [0, nbD):        D[col] = sum_b pe[b][col], col < 2*124*128 (thread <-> column: coalesced; 8 loads in flight)
+//   blocks [nbD, nbD+nsC):  slice s of the autocorrelation partials: Cs[s][d] = sum over its rows of pc[.][d], ts[s] = sum of prs[.]
+// (the slices are added by bn1_gram_kernel in ascending order: fixed order, reproducible).
+constexpr int B1_CSLICE = 64;                       // autocorrelation partial rows per slice
+__global__ void __launch_bounds__(256) bn1_partial_sums_kernel(const float* __restrict__ pe, int npe, const float* __restrict__ pc,
+                                                               const float* __restrict__ prs, int npc, int k, int nbD,
+                                                               double* __restrict__ D, double* __restrict__ Cs,
+                                                               double* __restrict__ ts) {
+    constexpr int NCOL = 2 * B1_MAXM * B1_LD;
+    if ((int)blockIdx.x < nbD) {
+        const int col = blockIdx.x * 256 + threadIdx.x;
+        if (col >= NCOL) return;
+        double s = 0.0;
+        int b = 0;
+        for (; b + 8 <= npe; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pe[(size_t)(b + u) * NCOL + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; b < npe; ++b) s += (double)pe[(size_t)b * NCOL + col];
+        D[col] = s;
+        return;
+    }
+    const int sl = blockIdx.x - nbD, d = threadIdx.x;
+    const int r0 = sl * B1_CSLICE, r1 = min(npc, r0 + B1_CSLICE);
+    if (d < k) {
+        double s = 0.0;
+        for (int r = r0; r < r1; ++r) s += (double)pc[(size_t)r * k + d];
+        Cs[(size_t)sl * B1_LD + d] = s;
+    } else if (d == 128) {
+        double s = 0.0;
+        for (int r = r0; r < r1; ++r) s += (double)prs[r];
+        ts[sl] = s;
+    }
+}
+
 // One block, thread d < k walks the d-th diagonal of G with running prefix / suffix sums of the edge terms.
-__global__ void __launch_bounds__(128) bn1_gram_kernel(const double* __restrict__ C, const double* __restrict__ D,
-                                                       const float* __restrict__ total, double* __restrict__ G,
+__global__ void __launch_bounds__(128) bn1_gram_kernel(const double* __restrict__ Cs, const double* __restrict__ ts, int nsC,
+                                                       const double* __restrict__ D, double* __restrict__ G,
                                                        double* __restrict__ S, int k, int pl) {
     const int d = threadIdx.x, m = k - 1;
     const double* Dh = D;
     const double* Dt = D + (size_t)B1_MAXM * B1_LD;
     if (d < k) {
+        double c = 0.0, total = 0.0;
+        for (int sl = 0; sl < nsC; ++sl) { c += Cs[(size_t)sl * B1_LD + d]; total += ts[sl]; }
         // G[j][j+d] = C[d] - sum_{s<j} Dh[s][d] - sum_{s>=j} Dt[s][d],  j = 0 .. k-1-d   (entries with s + d >= m are zero by construction)
         double pt = 0.0;
         for (int s = 0; s < m; ++s) pt += Dt[(size_t)s * B1_LD + d];
         double ph = 0.0;
-        const double c = C[d];
         for (int j = 0; j + d < k; ++j) {
             const double g = c - ph - pt;
             G[(size_t)j * k + j + d] = g;
@@ -34,7 +74,7 @@ __global__ void __launch_bounds__(128) bn1_gram_kernel(const double* __restrict_
         double miss = 0.0;
         if (j < pl)      for (int i = j; i < pl; ++i) miss += Dt[(size_t)i * B1_LD + 127];
         else if (j > pl) for (int t = 0; t < j - pl; ++t) miss += Dh[(size_t)(pl + t) * B1_LD + 127];
-        S[j] = (double)total[0] - miss;
+        S[j] = total - miss;
     }
 }
 
@@ -115,13 +155,51 @@ __global__ void __launch_bounds__(128) bn1_fold_bwd_kernel(const float* __restri
     }
 }
 
-extern "C" int ign_bn1_gram(const double* C, const double* D, const float* total, double* G, double* S, int k, int pad_left,
-                            void* stream) {
-    if (!C || !D || !total || !G || !S || k < 2 || k - 1 > B1_MAXM || pad_left < 0 || pad_left >= k) {
-        ign_set_error("ign_bn1_gram: null pointer or k=%d outside 2..%d or pad_left=%d", k, B1_MAXM + 1, pad_left);
+// workspace: autocorrelation partials + row sums, edge partials (fp32), then the float64 sums
+struct Bn1Ws { size_t pc, prs, pe, D, Cs, ts, total; int npc_max, npe, nsC_max; };
+static Bn1Ws bn1_ws_layout(int rows, int k) {
+    Bn1Ws w;
+    w.npc_max = (int)ign_autocorr_parts(rows);
+    w.npe = (int)ign_edge_lagprod_parts(rows);
+    w.nsC_max = (w.npc_max + B1_CSLICE - 1) / B1_CSLICE;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    w.pc = take((size_t)w.npc_max * k * sizeof(float));
+    w.prs = take((size_t)w.npc_max * sizeof(float));
+    w.pe = take((size_t)w.npe * 2 * B1_MAXM * B1_LD * sizeof(float));
+    w.D = take((size_t)2 * B1_MAXM * B1_LD * sizeof(double));
+    w.Cs = take((size_t)w.nsC_max * B1_LD * sizeof(double));
+    w.ts = take((size_t)w.nsC_max * sizeof(double));
+    w.total = o;
+    return w;
+}
+
+extern "C" size_t ign_bn1_data_stats_workspace_bytes(int rows, int T, int k) {
+    if (rows <= 0 || T <= 0 || k < 2 || k - 1 > B1_MAXM) return 0;
+    return bn1_ws_layout(rows, k).total;
+}
+
+extern "C" int ign_bn1_data_stats(const float* x_rows, int rows, int T, int k, int pad_left, void* workspace, double* G, double* S,
+                                  void* stream) {
+    if (!x_rows || !workspace || !G || !S || rows <= 0 || T < k || k < 2 || k - 1 > B1_MAXM || pad_left < 0 || pad_left >= k
+        || ((uintptr_t)workspace & 15)) {
+        ign_set_error("ign_bn1_data_stats: null / unaligned pointer or bad shape (rows=%d T=%d k=%d pad_left=%d; needs 2 <= k <= %d, T >= k)",
+                      rows, T, k, pad_left, B1_MAXM + 1);
         return IGN_E_ARG;
     }
-    hipLaunchKernelGGL(bn1_gram_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, C, D, total, G, S, k, pad_left);
+    const Bn1Ws w = bn1_ws_layout(rows, k);
+    char* base = (char*)workspace;
+    float *pc = (float*)(base + w.pc), *prs = (float*)(base + w.prs), *pe = (float*)(base + w.pe);
+    double *D = (double*)(base + w.D), *Cs = (double*)(base + w.Cs), *ts = (double*)(base + w.ts);
+    int rc, npc = 0;
+    if ((rc = ign_autocorr_sum_fwd(x_rows, pc, prs, rows, T, k, &npc, stream))) return rc;        // IGN_E_UNSUP beyond T = 1024
+    if ((rc = ign_edge_lagprod_fwd(x_rows, pe, rows, T, k, pad_left, stream))) return rc;
+    const int nsC = (npc + B1_CSLICE - 1) / B1_CSLICE;
+    const int nbD = (2 * B1_MAXM * B1_LD + 255) / 256;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn1_partial_sums_kernel, dim3(nbD + nsC), dim3(256), 0, s, pe, w.npe, pc, prs, npc, k, nbD, D, Cs, ts);
+    if ((rc = ign_check_launch("bn1_partial_sums_kernel"))) return rc;
+    hipLaunchKernelGGL(bn1_gram_kernel, dim3(1), dim3(128), 0, s, Cs, ts, nsC, D, G, S, k, pad_left);
     return ign_check_launch("bn1_gram_kernel");
 }
 

@@ -27,7 +27,9 @@ SIGNATURES = {
     "ign_shapelet_bwd_workspace_bytes": (sz, [ci, ci, ci, ci, ci, ci, ci]),
     "ign_layernorm_parts": (ll, [ll, ci]),
     "ign_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ll, ci, cf, vp]),
-    "ign_bn1_gram": (ci, [vp, vp, vp, vp, vp, ci, ci, vp]),
+    "ign_bn1_data_stats_workspace_bytes": (sz, [ci, ci, ci]),
+    "ign_bn1_data_stats": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp]),
+    "ign_autocorr_sum_fwd": (ci, [vp, vp, vp, ci, ci, ci, ctypes.POINTER(ctypes.c_int), vp]),
     "ign_bn1_fold_fwd": (ci, [vp, vp, vp, vp, vp, vp, cd, cf, cf, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     "ign_bn1_fold_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, cd, vp, vp, vp, vp, ci, ci, ci, vp]),
     "ign_layernorm_res_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, cf, vp]),

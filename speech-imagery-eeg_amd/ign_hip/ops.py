@@ -1069,22 +1069,19 @@ def conv1_sumsq(x_rows, w1, mu, pad_left):
 
 def bn1_data_stats(x_rows, k, pad_left):
     """(G, S), float64: the window Gram matrix (k, k) and the per-tap sums (k) of the zero-padded rows of `x_rows` (R, T) -- the
-    data side of BatchNorm-1's batch statistics (models/eegcnn.py).  Two passes over the data (ign_autocorr_fwd: lag sums;
-    ign_edge_lagprod_fwd: edge terms and column sums of the first / last k-1 samples), one over it for the total, three partial
-    sums in float64, one assembly launch (ign_bn1_gram).  No gradient: the operand is input data.  k <= 125, T >= k."""
+    data side of BatchNorm-1's batch statistics (models/eegcnn.py), one C call = four launches (ign_bn1_data_stats: lag sums and
+    row sums, edge terms and column sums, float64 sums of the per-block partials, assembly).  No gradient: the operand is input
+    data.  2 <= k <= 125, k <= T <= 1024."""
     _need_gpu("bn1_data_stats", x_rows)
     L = _lib.lib()
     x_rows = x_rows.contiguous()
     R, T = x_rows.shape
     dev = x_rows.device
-    C = autocorr(x_rows, k)
-    part = torch.empty(int(L.ign_edge_lagprod_parts(R)), 2, 124, 128, device=dev, dtype=torch.float32)
-    _lib.check(L.ign_edge_lagprod_fwd(_ptr(x_rows), _ptr(part), R, T, int(k), int(pad_left), _stream()), "ign_edge_lagprod_fwd")
-    D = part.sum(dim=0, dtype=torch.float64)             # (2, 124, 128); columns k..126 are never written nor read
-    total = x_rows.sum().reshape(1)
+    ws = torch.empty(int(L.ign_bn1_data_stats_workspace_bytes(R, T, int(k))), device=dev, dtype=torch.uint8)
     G = torch.empty(k, k, device=dev, dtype=torch.float64)
     S = torch.empty(k, device=dev, dtype=torch.float64)
-    _lib.check(L.ign_bn1_gram(_ptr(C), _ptr(D), _ptr(total), _ptr(G), _ptr(S), int(k), int(pad_left), _stream()), "ign_bn1_gram")
+    _lib.check(L.ign_bn1_data_stats(_ptr(x_rows), R, T, int(k), int(pad_left), _ptr(ws), _ptr(G), _ptr(S), _stream()),
+               "ign_bn1_data_stats")
     return G, S
 
 

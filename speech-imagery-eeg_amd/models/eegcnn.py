@@ -135,7 +135,7 @@ class EEGcnn(nn.Module):
         pl1 = (k1 - 1) // 2
         x = x.contiguous()
         batch_stats = bn1.training or not bn1.track_running_stats
-        if batch_stats and _BN1_VARIANCE == "gram" and 2 <= k1 <= 125 and T >= k1 and bn1.weight is not None \
+        if batch_stats and _BN1_VARIANCE == "gram" and 2 <= k1 <= 125 and k1 <= T <= 1024 and bn1.weight is not None \
                 and (bn1.momentum is not None or not bn1.track_running_stats):
             # BatchNorm-1's batch statistics are a linear / quadratic form of the filter over statistics of the INPUT (per-tap sums
             # S, window Gram matrix G: two passes over x for all filters, no pass over the (B,F1,C,T) convolution): data statistics,
