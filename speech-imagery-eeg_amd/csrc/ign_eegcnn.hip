@@ -469,11 +469,14 @@ __global__ void __launch_bounds__(256) xcorr_kernel(const float* __restrict__ a,
 //     out[1][s][d] = sum_rows xp[T+s] xp[T+s+d]      (the tail),
 // which round 1 took from two batched GEMMs over zero-padded copies.  Thread <-> (lag d, half of the s range): 2 x 62
 // accumulators, the two segments of a row in LDS; partials per block, the caller adds them in double.  4.8e8 FMA at the benchmark
-// shape: launch-bound.
+// shape; eight rows are staged per barrier pair.
 constexpr int EG_MAXM = 124, EG_HALF = 62;
+constexpr int EG_RB = 8;                            // rows staged per barrier pair: 16 independent loads per thread in flight (one row per
+                                                    // pair made the kernel a chain of ~120 exposed memory round trips: 0.18 ms)
 __global__ void __launch_bounds__(256) edge_lagprod_kernel(const float* __restrict__ x, float* __restrict__ part, int rows, int T, int k,
                                                            int pl, int rows_per_block) {
-    __shared__ float hs[2 * EG_MAXM + 8], ts[2 * EG_MAXM + 8];
+    constexpr int W = 2 * EG_MAXM + 8;              // = 256 staged samples per row and end: one per thread
+    __shared__ float hs[EG_RB][W], ts[EG_RB][W];
     const int m = k - 1;
     const int d = threadIdx.x & 127, half = threadIdx.x >> 7;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
@@ -481,22 +484,32 @@ __global__ void __launch_bounds__(256) edge_lagprod_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < EG_HALF; ++i) { ah[i] = 0.f; at[i] = 0.f; }
     float csh = 0.f, cst = 0.f;            // thread i < m: column sums of xp[i] and xp[T + i] over the block's rows (column 127)
-    for (int r = r0; r < r1; ++r) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < 2 * EG_MAXM + 8; i += 256) {
-            // head: xp[i] = x[i - pl], i < m;   tail: xp[T + i] = x[T + i - pl], i < pl   (zero elsewhere, and beyond m)
-            const int sh = i - pl, st = T + i - pl;
-            hs[i] = (i < m && sh >= 0 && sh < T) ? x[(size_t)r * T + sh] : 0.f;
-            ts[i] = (i < m && st >= 0 && st < T) ? x[(size_t)r * T + st] : 0.f;
-        }
-        __syncthreads();
+    const int i = threadIdx.x;
+    // head: xp[i] = x[i - pl], i < m;   tail: xp[T + i] = x[T + i - pl], i < pl   (zero elsewhere, and beyond m)
+    const int sh = i - pl, st = T + i - pl;
+    const bool hok = i < m && sh >= 0 && sh < T, tok = i < m && st >= 0 && st < T;
+    for (int rb = r0; rb < r1; rb += EG_RB) {
+        float vh[EG_RB], vt[EG_RB];
 #pragma unroll
-        for (int i = 0; i < EG_HALF; ++i) {
-            const int s = half * EG_HALF + i;
-            ah[i] = fmaf(hs[s], hs[s + d], ah[i]);
-            at[i] = fmaf(ts[s], ts[s + d], at[i]);
+        for (int q = 0; q < EG_RB; ++q) {
+            const int r = rb + q;
+            vh[q] = (hok && r < r1) ? x[(size_t)r * T + sh] : 0.f;
+            vt[q] = (tok && r < r1) ? x[(size_t)r * T + st] : 0.f;
         }
-        if (threadIdx.x < EG_MAXM) { csh += hs[threadIdx.x]; cst += ts[threadIdx.x]; }
+        __syncthreads();                            // the previous batch of rows has been consumed
+#pragma unroll
+        for (int q = 0; q < EG_RB; ++q) { hs[q][i] = vh[q]; ts[q][i] = vt[q]; }
+        __syncthreads();
+        const int nq = min(EG_RB, r1 - rb);
+        for (int q = 0; q < nq; ++q) {              // rows in ascending order: the sums are those of the one-row-per-pass kernel, bit for bit
+#pragma unroll
+            for (int e = 0; e < EG_HALF; ++e) {
+                const int s = half * EG_HALF + e;
+                ah[e] = fmaf(hs[q][s], hs[q][s + d], ah[e]);
+                at[e] = fmaf(ts[q][s], ts[q][s + d], at[e]);
+            }
+            if (threadIdx.x < EG_MAXM) { csh += hs[q][threadIdx.x]; cst += ts[q][threadIdx.x]; }
+        }
     }
     if (threadIdx.x < EG_MAXM) {
         float* pb = part + (size_t)blockIdx.x * 2 * EG_MAXM * 128;
@@ -506,10 +519,10 @@ __global__ void __launch_bounds__(256) edge_lagprod_kernel(const float* __restri
     if (d < k) {
         float* pb = part + (size_t)blockIdx.x * 2 * EG_MAXM * 128;
 #pragma unroll
-        for (int i = 0; i < EG_HALF; ++i) {
-            const int s = half * EG_HALF + i;
-            pb[(size_t)s * 128 + d] = ah[i];
-            pb[(size_t)(EG_MAXM + s) * 128 + d] = at[i];
+        for (int e = 0; e < EG_HALF; ++e) {
+            const int s = half * EG_HALF + e;
+            pb[(size_t)s * 128 + d] = ah[e];
+            pb[(size_t)(EG_MAXM + s) * 128 + d] = at[e];
         }
     }
 }
