@@ -456,6 +456,8 @@ int ign_clconv_pack_weights_x3_multi(int n, const float* const* w_oik, void* con
  * this headroom where dL/du of a GELU inherits the bound of dL/dy), an element beyond 4 times the bound overflows to infinity.
  * Replaces the same reference lines as ign_clconv_fwd / _dgrad / _wgrad (IGN/model/FullyConvNet.py:31-59 and its autograd).   */
 int ign_absmax(const float* x, long long n, float* slot /* max'ed into, caller zeroes */, void* stream);
+/* ... of up to 16 tensors in one launch (a model's dense-layer weights once per step): slots[i] = max |x[i][0..count[i])|.     */
+int ign_absmax_multi(int n, const float* const* x, const long long* count, float* const* slots, void* stream);
 /* ign_fcn_scan also clears `zero[0..nzero)` (nullable / 0): the identically-zero gradients of the convolution biases in front of
  * a batch-statistics BatchNorm are views of that buffer, so the backward needs no fill launch.                               */
 int ign_fcn_scan(int nl, const float* const* w, const long long* nw, const float* const* gamma_prev, const float* const* beta_prev,

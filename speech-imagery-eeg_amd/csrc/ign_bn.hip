@@ -263,6 +263,31 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
     if (threadIdx.x == 0) atomic_absmax(slot, m);
 }
 
+// max |x| of up to 16 tensors in one launch (the weights of a model's dense layers: one launch per step instead of one per layer);
+// grid.y = tensor, grid.x = chunks of it, atomic maximum into the tensor's own slot (caller zeroes the slots).
+constexpr int AMM_MAX = 16;
+struct AbsmaxMultiTable { const float* x[AMM_MAX]; long long n[AMM_MAX]; float* slot[AMM_MAX]; };
+__global__ void __launch_bounds__(256) absmax_multi_kernel(const AbsmaxMultiTable t) {
+    __shared__ float sh[16];
+    const int g = blockIdx.y;
+    const float* __restrict__ x = t.x[g];
+    const long long n = t.n[g];
+    float m = 0.f;
+    if (((uintptr_t)x & 15) == 0) {
+        const long long n4 = n >> 2;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        if (blockIdx.x == 0)
+            for (long long i = (n4 << 2) + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    }
+    m = block_max_1024(m, sh);
+    if (threadIdx.x == 0) atomic_absmax(t.slot[g], m);
+}
+
 constexpr int SCAN_LMAX = 8;
 struct FcnScanTable {
     const float* w[SCAN_LMAX]; long long nw[SCAN_LMAX];
@@ -292,6 +317,22 @@ extern "C" int ign_absmax(const float* x, long long n, float* slot, void* stream
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0,
                        (hipStream_t)stream, x, n, slot);
     return ign_check_launch("absmax_kernel");
+}
+
+extern "C" int ign_absmax_multi(int n, const float* const* x, const long long* count, float* const* slots, void* stream) {
+    if (n <= 0 || n > AMM_MAX || !x || !count || !slots) { ign_set_error("ign_absmax_multi: n=%d outside 1..%d or null table", n, AMM_MAX); return IGN_E_ARG; }
+    AbsmaxMultiTable t;
+    long long nmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!x[i] || !slots[i] || count[i] <= 0) { ign_set_error("ign_absmax_multi: tensor %d: null pointer or empty", i); return IGN_E_ARG; }
+        t.x[i] = x[i]; t.n[i] = count[i]; t.slot[i] = slots[i];
+        nmax = count[i] > nmax ? count[i] : nmax;
+    }
+    long long blocks = (nmax / 4 + 256 * 8 - 1) / (256 * 8);
+    blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+    IgnScopedTimer tm("absmax", (hipStream_t)stream);
+    hipLaunchKernelGGL(absmax_multi_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
+    return ign_check_launch("absmax_multi_kernel");
 }
 
 extern "C" int ign_fcn_scan(int nl, const float* const* w, const long long* nw, const float* const* gamma_prev,

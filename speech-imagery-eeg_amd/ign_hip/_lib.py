@@ -108,6 +108,7 @@ SIGNATURES = {
     "ign_clconv_wgrad_reduce_multi": (ci, [ci, vp, vp, vp, vp, vp, vp, vp]),
     "ign_clconv_pack_weights_x3_multi": (ci, [ci, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ign_absmax": (ci, [vp, ll, vp, vp]),
+    "ign_absmax_multi": (ci, [ci, vp, vp, vp, vp]),
     "ign_fcn_scan": (ci, [ci, vp, vp, vp, vp, vp, vp, vp, vp, ll, vp]),
     "ign_clconv_pack_weights_h2_multi": (ci, [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ign_clconv_fwd_h3": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
@@ -132,6 +133,10 @@ class IgnError(RuntimeError):
 
 
 _RAW_STREAM = None
+
+# Bumped whenever parameters are rewritten behind autograd's back (ign_adam_step writes through raw pointers, which does not move
+# the tensors' version counters): anything derived from parameter VALUES and kept across calls is validated against it.
+PARAM_GENERATION = [0]
 
 
 def stream():

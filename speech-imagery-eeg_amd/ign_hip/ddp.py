@@ -173,6 +173,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_count += 1
         g = self.param_groups[0]
         ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+        self._lib.PARAM_GENERATION[0] += 1           # the kernel rewrites the parameters through raw pointers
         if self.capturable:
             self._lib.check(self._lib.lib().ign_adam_step_dev(
                 ptr(self.flat_param), ptr(self.bucket.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),

@@ -611,6 +611,56 @@ def _gemm(L, bf16):
     return (L.ign_clconv_fwd_bf16, L.ign_clconv_wgrad_bf16) if bf16 else (L.ign_clconv_fwd_x6, L.ign_clconv_wgrad_x6)
 
 
+_PREPARED = {}          # (data_ptr, shape) -> (w, version, generation, bound slot, packed forward planes, packed transposed planes)
+
+
+def prepare_linear_weights(weights, need_dx=True):
+    """Model-level prologue of the fp16-plane dense layers: the magnitude bounds of ALL the given weight matrices in one launch
+    (ign_absmax_multi) and their packed plane forms in one launch per eight (ign_clconv_pack_weights_h2_multi), instead of one
+    scan + one packing launch per layer.  `ops.linear` consumes the entry of its weight (once; an entry is valid only for the
+    parameter values it was made from: tensor version and _lib.PARAM_GENERATION).  No-op outside the f16x3 arithmetic."""
+    _PREPARED.clear()
+    if GEMM_MATH != "f16x3" or torch.is_autocast_enabled():
+        return
+    ws = []
+    for w in weights:
+        if w is None or not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or w.shape[0] % 4 or not w.is_contiguous():
+            continue
+        ws.append(w)
+    if not ws:
+        return
+    L = _lib.lib()
+    dev = ws[0].device
+    slots = [_new_slot(dev) for _ in ws]
+    for c0 in range(0, len(ws), 16):
+        cw, cs = ws[c0:c0 + 16], slots[c0:c0 + 16]
+        n = len(cw)
+        vpa, lla = ctypes.c_void_p * n, ctypes.c_longlong * n
+        _lib.check(L.ign_absmax_multi(n, vpa(*[w.data_ptr() for w in cw]), lla(*[w.numel() for w in cw]),
+                                      vpa(*[t.data_ptr() for t in cs]), _stream()), "ign_absmax_multi")
+    gen = _lib.PARAM_GENERATION[0]
+    for c0 in range(0, len(ws), 8):
+        cw, cs = ws[c0:c0 + 8], slots[c0:c0 + 8]
+        n = len(cw)
+        vpa, ia = ctypes.c_void_p * n, ctypes.c_int * n
+        wt = [torch.empty(int(L.ign_clconv_x3_elems(w.shape[0], w.shape[1], 1)), device=dev, dtype=torch.bfloat16) for w in cw]
+        wd = [torch.empty(int(L.ign_clconv_x3_elems(w.shape[1], w.shape[0], 1)), device=dev, dtype=torch.bfloat16) if need_dx else None
+              for w in cw]
+        _lib.check(L.ign_clconv_pack_weights_h2_multi(n, vpa(*[w.data_ptr() for w in cw]), vpa(*[t.data_ptr() for t in wt]),
+                                                      vpa(*[(t.data_ptr() if t is not None else None) for t in wd]) if need_dx else None,
+                                                      ia(*[w.shape[0] for w in cw]), ia(*[w.shape[1] for w in cw]), ia(*([1] * n)), None,
+                                                      vpa(*[t.data_ptr() for t in cs]), _stream()), "ign_clconv_pack_weights_h2_multi")
+        for w, sl, a, b in zip(cw, cs, wt, wd):
+            _PREPARED[(w.data_ptr(), tuple(w.shape))] = (w, w._version, gen, sl, a, b)
+
+
+def _take_prepared(w, need_dx):
+    ent = _PREPARED.pop((w.data_ptr(), tuple(w.shape)), None)
+    if ent is None or ent[1] != w._version or ent[2] != _lib.PARAM_GENERATION[0] or (need_dx and ent[5] is None):
+        return None
+    return ent
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b for the dense layers of the two encoder baselines (IGN/layers/SelfAttention_Family.py:195-211,
     IGN/layers/Transformer_EncDec.py:33-48, nn.TransformerEncoderLayer in IGN/model/eegcnn.py:219-228) on the library's own
@@ -629,20 +679,27 @@ class LinearFn(torch.autograd.Function):
         w = w.contiguous()
         dev = x.device
         need_dx = ctx.needs_input_grad[0]
-        wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, 1)), device=dev, dtype=torch.bfloat16)
-        wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, 1)), device=dev, dtype=torch.bfloat16) if need_dx else None
-        y = torch.empty(*x.shape[:-1], Co, device=dev, dtype=torch.float32)    # final shape (not a view: its reshaped views find its bound)
         ctx.bf16 = torch.is_autocast_enabled()          # autocast region: operands rounded to bf16, one product (see _gemm)
         ctx.h3 = (not ctx.bf16) and GEMM_MATH == "f16x3"
+        prepared = _take_prepared(w, need_dx) if ctx.h3 else None       # bound + packed planes from the model's prologue launch
+        if prepared is not None:
+            wt3, wd3 = prepared[4], (prepared[5] if need_dx else None)
+        else:
+            wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, 1)), device=dev, dtype=torch.bfloat16)
+            wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, 1)), device=dev, dtype=torch.bfloat16) if need_dx else None
+        y = torch.empty(*x.shape[:-1], Co, device=dev, dtype=torch.float32)    # final shape (not a view: its reshaped views find its bound)
         ctx.bx = ctx.bw = None
         if ctx.h3:
             # two fp16 planes, three products: operand bounds on the device (the input's is inherited from x when x2 is a view)
-            ctx.bw = tensor_bound(w)
             ctx.bx = tensor_bound(x) if x2.data_ptr() == x.data_ptr() and x.is_contiguous() else tensor_bound(x2)
-            v1, i1 = _tables(1)
-            _lib.check(L.ign_clconv_pack_weights_h2_multi(1, v1(w.data_ptr()), v1(wt3.data_ptr()), v1(wd3.data_ptr()) if need_dx else None,
-                                                          i1(Co), i1(Ci), i1(1), None, v1(ctx.bw.data_ptr()), _stream()),
-                       "ign_clconv_pack_weights_h2_multi")
+            if prepared is not None:
+                ctx.bw = prepared[3]
+            else:
+                ctx.bw = tensor_bound(w)
+                v1, i1 = _tables(1)
+                _lib.check(L.ign_clconv_pack_weights_h2_multi(1, v1(w.data_ptr()), v1(wt3.data_ptr()),
+                                                              v1(wd3.data_ptr()) if need_dx else None, i1(Co), i1(Ci), i1(1), None,
+                                                              v1(ctx.bw.data_ptr()), _stream()), "ign_clconv_pack_weights_h2_multi")
             # the epilogue also takes max |y|: the operand bound of whatever dense layer / attention core consumes y
             yb = _new_slot(dev)
             _lib.check(L.ign_clconv_fwd_h3_amax(_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, _ptr(ctx.bx), _ptr(ctx.bw),

@@ -1,6 +1,7 @@
 """Encoder stack of the Transformer baseline (IGN/layers/Transformer_EncDec.py:27-80): post-norm layers with a
 1x1-Conv1d feed-forward, and a final LayerNorm.  Decoder / ConvLayer of the reference file are unused by the
 classification path and not rebuilt."""
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -41,7 +42,21 @@ class Encoder(nn.Module):
         self.conv_layers = None
         self.norm = norm_layer
 
+    def dense_weights(self):
+        """The weight matrices of every dense layer of the stack, as `ops.linear` will see them (k = 1 convolutions squeezed)."""
+        ws = []
+        for layer in self.attn_layers:
+            a = layer.attention
+            for name in ("query_projection", "key_projection", "value_projection", "out_projection"):
+                m = getattr(a, name, None)
+                if isinstance(m, nn.Linear):
+                    ws.append(m.weight)
+            ws += [layer.conv1.weight.squeeze(-1), layer.conv2.weight.squeeze(-1)]
+        return ws
+
     def forward(self, x, attn_mask=None, tau=None, delta=None):
+        # bounds and packed planes of all dense-layer weights in one scan + a few packing launches (ops.prepare_linear_weights)
+        ops.prepare_linear_weights(self.dense_weights(), need_dx=torch.is_grad_enabled())
         attns = []
         for layer in self.attn_layers:
             x, attn = layer(x, attn_mask=attn_mask, tau=tau, delta=delta)

@@ -261,6 +261,11 @@ class EEGCNNTransformer(nn.Module):
         h = self.eegcnn(x).permute(0, 2, 1)
         if self.num_layers > 0:
             proj = self.cnn_projection
+            # bounds and packed planes of all dense-layer weights of the encoder in one scan + two packing launches
+            ops.prepare_linear_weights(([proj.weight] if isinstance(proj, nn.Linear) else []) +
+                                       [w for l in self.transformer_encoder.layers
+                                        for w in (l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.linear1.weight,
+                                                  l.linear2.weight)], need_dx=torch.is_grad_enabled())
             h = ops.linear(h, proj.weight, proj.bias) if isinstance(proj, nn.Linear) else proj(h)
             h = self.pos_encoder(h)
             for layer in self.transformer_encoder.layers:

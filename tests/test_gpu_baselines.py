@@ -893,3 +893,53 @@ def test_backward_operand_bounds_come_from_the_producers():
     # dense outputs, their four input gradients, the two LayerNorm input gradients, the packed attention gradient
     assert exact >= 11, (exact, len(seen))
     assert all(torch.isfinite(p.grad).all() for p in layer.parameters()) and torch.isfinite(xin.grad).all()
+
+
+def test_dense_layer_prologue_matches_the_per_layer_route_and_goes_stale_safely():
+    """ops.prepare_linear_weights: bounds + packed planes of several weights in one scan and one packing launch.  (1) ops.linear on a
+    prepared weight is bitwise the per-layer route; (2) an entry is consumed once; (3) an entry made before the parameters changed
+    -- in place (version counter) or through the flat Adam kernel (raw pointers: _lib.PARAM_GENERATION) -- is NOT used."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops, _lib
+    from ign_hip.ddp import FlatAdam, FlatParamBucket
+    if ops.GEMM_MATH != "f16x3":
+        pytest.skip("needs the f16x3 arithmetic")
+    torch.manual_seed(0)
+    lins = [torch.nn.Linear(64, 128).to(dev), torch.nn.Linear(128, 64).to(dev), torch.nn.Linear(64, 512, bias=False).to(dev)]
+    xs = [torch.randn(50, 64, device=dev), torch.randn(50, 128, device=dev), torch.randn(7, 9, 64, device=dev)]
+
+    def run(prep):
+        outs = []
+        if prep:
+            ops.prepare_linear_weights([l.weight for l in lins])
+            assert len(ops._PREPARED) == 3
+        for l, x in zip(lins, xs):
+            xr = x.clone().requires_grad_(True)
+            y = ops.linear(xr, l.weight, l.bias)
+            y.square().sum().backward()
+            outs += [y.detach(), xr.grad, l.weight.grad.clone()]
+            l.zero_grad(set_to_none=True)
+        return outs
+
+    a, b = run(False), run(True)
+    assert not ops._PREPARED                                            # consumed
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    # stale by an in-place update
+    ops.prepare_linear_weights([l.weight for l in lins])
+    with torch.no_grad():
+        lins[0].weight.mul_(300.0)
+    y = ops.linear(xs[0], lins[0].weight, lins[0].bias)
+    ref = torch.nn.functional.linear(xs[0].double(), lins[0].weight.detach().double(), lins[0].bias.detach().double())
+    assert torch.isfinite(y).all() and _rel(y, ref) < 3e-6
+    # stale by the flat Adam kernel (no version bump)
+    bucket = FlatParamBucket(lins[1], 1)
+    opt = FlatAdam(bucket, lr=30.0)
+    ops.linear(xs[1], lins[1].weight, lins[1].bias).square().mean().backward()
+    ops.prepare_linear_weights([l.weight for l in lins])
+    opt.step()
+    bucket.zero_grad()
+    y = ops.linear(xs[1], lins[1].weight, lins[1].bias)
+    ref = torch.nn.functional.linear(xs[1].double(), lins[1].weight.detach().double(), lins[1].bias.detach().double())
+    assert float(lins[1].weight.detach().abs().max()) > 20.0 and torch.isfinite(y).all() and _rel(y, ref) < 3e-6
