@@ -296,7 +296,7 @@ class Bench:
                     out, info = model(x, mask, None, None)
                     return F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y)
                 if cfgname == "eegcnn":
-                    out, info = model(x.permute(0, 2, 1).contiguous())
+                    out, info = model(x.permute(0, 2, 1))
                     return F.cross_entropy(out, y) + info.loss.mean()
                 return F.cross_entropy(model(x, mask, None, None), y)
         if cfgname == "ign":
@@ -304,7 +304,7 @@ class Bench:
             # = F.cross_entropy(out, y) + info.loss.mean() + 1.0 * F.cross_entropy(info.shapelet_preds, y), one launch
             return self.ops.ign_loss(info.shapelet_preds, info.dnn_preds, y, 1.0, reg=info.loss)[0]
         if cfgname == "eegcnn":
-            out, info = model(x.permute(0, 2, 1).contiguous())        # (B,C,T), no mask
+            out, info = model(x.permute(0, 2, 1))                     # (B,C,T) view of the time-first batch, no mask
             return F.cross_entropy(out, y) + info.loss.mean()
         return F.cross_entropy(model(x, mask, None, None), y)
 

@@ -52,6 +52,10 @@ int ign_instnorm_fwd(const float* x_btc, float* xn_bct, float* xt_bct, int B, in
 int ign_instnorm_fwd_amax(const float* x_btc, float* xn_bct, float* xt_bct, int B, int T, int C, float eps, float* amax_slot,
                           void* stream);
 
+/* Plain (B,T,C) -> (B,C,T) transpose of a batch: what `x.permute(0, 2, 1)` means for a consumer that needs electrodes-first rows
+ * (the EEG-CNN baseline, IGN/model/eegcnn.py:134, fed from the time-first item contract of IGN/data_factory/uea.py).           */
+int ign_transpose_btc_to_bct(const float* x_btc, float* out_bct, int B, int T, int C, void* stream);
+
 /* On-GPU input pipeline of the CHISCO loader: raw (B,C,T) recordings -> standardised (B,T,C) batches.
  * Replaces, per batch, Normalizer('per_sample_std') of IGN/data_factory/eeg.py:332-367 (per sample and channel over time:
  * (x - mean) / (std(ddof=1) + eps)) and the (C,T) -> (T,C) item transpose that IGN/data_factory/uea.py:7-42 batches.

@@ -178,3 +178,35 @@ extern "C" int ign_standardise_nct_to_btc(const float* x_nct, float* out_btc, fl
                        C, T);
     return ign_check_launch("std_apply_transpose_kernel");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Plain (B, T, C) -> (B, C, T) transpose of a batch: the EEG-CNN baseline takes electrodes-first input (IGN/model/eegcnn.py:134)
+// while the loader's item contract is time-first, so the reference's harness hands it `x.permute(0, 2, 1)`.  64 (t) x 32 (c) tiles
+// through LDS: 128-byte reads along c, 256-byte writes along t (torch's strided copy of the 125 MB batch took 0.16 ms per step).
+__global__ void __launch_bounds__(256) transpose_btc_bct_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int C) {
+    __shared__ float tile[64][33];
+    const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 64;
+    const int cc = threadIdx.x & 31, tr = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int tl = tr * 8 + i, t = t0 + tl, c = c0 + cc;
+        tile[tl][cc] = (t < T && c < C) ? x[((size_t)b * T + t) * C + c] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int cl = w * 8 + i, c = c0 + cl, t = t0 + lane;
+        if (c < C && t < T) out[((size_t)b * C + c) * T + t] = tile[lane][cl];
+    }
+}
+
+extern "C" int ign_transpose_btc_to_bct(const float* x_btc, float* out_bct, int B, int T, int C, void* stream) {
+    if (!x_btc || !out_bct || B <= 0 || T <= 0 || C <= 0 || B > 65535) {
+        ign_set_error("ign_transpose_btc_to_bct: null pointer or bad dimension (B=%d T=%d C=%d)", B, T, C);
+        return IGN_E_ARG;
+    }
+    hipLaunchKernelGGL(transpose_btc_bct_kernel, dim3((T + 63) / 64, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, x_btc, out_bct,
+                       T, C);
+    return ign_check_launch("transpose_btc_bct_kernel");
+}

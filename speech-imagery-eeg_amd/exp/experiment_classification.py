@@ -178,7 +178,7 @@ class Experiment(object):
         if a.model == 'DNN':
             return self.model(batch_x, padding_mask, None, None), None
         if a.model == 'EEGCNN':
-            return self.model(batch_x.permute(0, 2, 1).contiguous())      # (B,C,T), no mask (D9)
+            return self.model(batch_x.permute(0, 2, 1))                   # (B,C,T) view, no mask (D9); the model transposes in HIP
         if test:
             return self.model(batch_x, padding_mask, None, None, gating_value=gating_value)
         return self.model(batch_x, padding_mask, None, None)

@@ -20,6 +20,7 @@ SIGNATURES = {
     "ign_abi_version": (ci, []),
     "ign_last_error": (ctypes.c_char_p, []),
     "ign_instnorm_fwd": (ci, [vp, vp, vp, ci, ci, ci, cf, vp]),
+    "ign_transpose_btc_to_bct": (ci, [vp, vp, ci, ci, ci, vp]),
     "ign_instnorm_fwd_amax": (ci, [vp, vp, vp, ci, ci, ci, cf, vp, vp]),
     "ign_standardise_nct_to_btc": (ci, [vp, vp, vp, ci, ci, ci, cf, vp]),
     "ign_shapelet_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]),

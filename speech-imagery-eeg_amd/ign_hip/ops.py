@@ -53,6 +53,21 @@ def instance_norm(x_btc, want_raw=False, eps=1e-8, input_bound=False):
     return xn, xt
 
 
+def contiguous_bct(x):
+    """A contiguous (B, C, T) tensor with the contents of `x` (B, C, T).  If `x` is the `permute(0, 2, 1)` view of a contiguous
+    time-first (B, T, C) batch -- what the harness hands the EEG-CNN baseline -- the transpose runs on ign_transpose_btc_to_bct
+    (no gradient: input data); anything else takes torch's `.contiguous()`."""
+    if x.is_contiguous():
+        return x
+    B, C, T = x.shape
+    if (x.is_cuda and x.dtype == torch.float32 and not x.requires_grad and x.stride() == (T * C, 1, C) and B <= 65535
+            and x.data_ptr() % 16 == 0):
+        out = torch.empty(B, C, T, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().ign_transpose_btc_to_bct(_ptr(x), _ptr(out), B, T, C, _stream()), "ign_transpose_btc_to_bct")
+        return out
+    return x.contiguous()
+
+
 def standardise_nct_to_btc(x_nct, eps=1e-8):
     """Raw (B,C,T) recordings -> per-sample / per-channel standardised (B,T,C) batch on the GPU (the CHISCO loader's
     Normalizer('per_sample_std') + item transpose, IGN/data_factory/eeg.py:332-367, for the whole batch at once)."""

@@ -133,7 +133,7 @@ class EEGcnn(nn.Module):
         F1, k1 = w1.shape
         D = w2.shape[0] // F1
         pl1 = (k1 - 1) // 2
-        x = x.contiguous()
+        x = ops.contiguous_bct(x)                   # (a permuted view of the loader's time-first batch: HIP transpose)
         batch_stats = bn1.training or not bn1.track_running_stats
         if batch_stats and _BN1_VARIANCE == "gram" and 2 <= k1 <= 125 and k1 <= T <= 1024 and bn1.weight is not None \
                 and (bn1.momentum is not None or not bn1.track_running_stats):

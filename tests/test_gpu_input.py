@@ -94,3 +94,20 @@ def test_harness_runs_on_the_device_pipeline(tmp_path, monkeypatch):
         losses[flag] = exp.validation()
     # the two input paths agree to ~1e-5 per element; six Adam steps at lr 5e-3 amplify that to the 1e-3 level in the loss
     assert abs(losses[True][0] - losses[False][0]) < 2e-2 and abs(losses[True][1] - losses[False][1]) <= 0.15
+
+
+@pytest.mark.parametrize("B,T,C", [(3, 100, 6), (2, 1000, 122), (5, 65, 33), (1, 1, 1)])
+def test_contiguous_bct_transposes_the_time_first_batch(B, T, C):
+    """ops.contiguous_bct (ign_transpose_btc_to_bct): the permuted view of a time-first batch becomes a contiguous (B, C, T)
+    tensor, bit for bit; other layouts take torch's route."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    x = torch.randn(B, T, C, device="cuda")
+    out = ops.contiguous_bct(x.permute(0, 2, 1))
+    assert out.is_contiguous() and torch.equal(out, x.permute(0, 2, 1).contiguous())
+    y = torch.randn(B, C, T, device="cuda")
+    assert ops.contiguous_bct(y) is y
+    z = torch.randn(B, C, 2 * T, device="cuda")[:, :, ::2]
+    assert torch.equal(ops.contiguous_bct(z), z.contiguous())
