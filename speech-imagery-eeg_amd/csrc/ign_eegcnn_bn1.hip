@@ -59,14 +59,34 @@ __global__ void __launch_bounds__(128) bn1_gram_kernel(const double* __restrict_
         double c = 0.0, total = 0.0;
         for (int sl = 0; sl < nsC; ++sl) { c += Cs[(size_t)sl * B1_LD + d]; total += ts[sl]; }
         // G[j][j+d] = C[d] - sum_{s<j} Dh[s][d] - sum_{s>=j} Dt[s][d],  j = 0 .. k-1-d   (entries with s + d >= m are zero by construction)
+        // (loads in batches of 8 before they are used: a single block walking 125 dependent steps is pure latency otherwise)
         double pt = 0.0;
-        for (int s = 0; s < m; ++s) pt += Dt[(size_t)s * B1_LD + d];
+        for (int s0 = 0; s0 < m; s0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (s0 + u < m) ? Dt[(size_t)(s0 + u) * B1_LD + d] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pt += v[u];
+        }
         double ph = 0.0;
-        for (int j = 0; j + d < k; ++j) {
-            const double g = c - ph - pt;
-            G[(size_t)j * k + j + d] = g;
-            G[(size_t)(j + d) * k + j] = g;
-            if (j < m) { ph += Dh[(size_t)j * B1_LD + d]; pt -= Dt[(size_t)j * B1_LD + d]; }
+        for (int j0 = 0; j0 + d < k; j0 += 8) {
+            double vh[8], vt[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                vh[u] = (j < m) ? Dh[(size_t)j * B1_LD + d] : 0.0;
+                vt[u] = (j < m) ? Dt[(size_t)j * B1_LD + d] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                if (j + d < k) {
+                    const double g = c - ph - pt;
+                    G[(size_t)j * k + j + d] = g;
+                    G[(size_t)(j + d) * k + j] = g;
+                    ph += vh[u]; pt -= vt[u];
+                }
+            }
         }
         // S[j]: all samples minus those tap j never sees.  Column 127 holds ch[i] = sum_rows xp[i] and ct[i] = sum_rows xp[T+i];
         // x[t] = xp[pl + t].  Tap j < pl misses the LAST pl - j samples, tap j > pl the FIRST j - pl.
