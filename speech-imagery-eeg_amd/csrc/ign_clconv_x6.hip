@@ -325,14 +325,24 @@ __global__ void __launch_bounds__(256, (X6tWaves<NP, EPI>::N)) clconv_x6t_kernel
 // to them.  Sharing the activation tile between twice as many waves halves that cost per MFMA: per wave and step one float4 to
 // load / split / store instead of two, the weight side unchanged.  Same packed weights (two consecutive 128-row n-tiles), same
 // arithmetic and summation order per output, same epilogue code.
-constexpr int X6W_ABUF = 3 * TM * X6_PITCH;                       // one 128-row activation tile, three planes
-constexpr int X6W_BBUF = 2 * 3 * X6_PLANE;                        // two 128-row weight blocks, three planes each
-constexpr size_t X6W_LDS_BYTES = (size_t)2 * (X6W_ABUF + X6W_BBUF) * sizeof(unsigned short);
+// LDS sized by the planes actually staged (NP = 2: two fp16 planes = 74 KB, so two workgroups fit a CU's 160 KB; three bf16 planes
+// = 111 KB, one workgroup); IGN_H3W_WAVES = waves per SIMD the register budget of the two-plane variant is pinned to.
+#ifndef IGN_H3W_WAVES
+#define IGN_H3W_WAVES 2
+#endif
+template <int NP> struct X6wLds {
+    static constexpr int NPL = NP == 3 ? 3 : (NP == 2 ? 2 : 1);
+    static constexpr int ABUF = NPL * TM * X6_PITCH;             // one 128-row activation tile
+    static constexpr int BBUF = 2 * NPL * X6_PLANE;              // two 128-row weight blocks
+    static constexpr size_t BYTES = (size_t)2 * (ABUF + BBUF) * sizeof(unsigned short);
+    static constexpr int WAVES = NP == 2 ? IGN_H3W_WAVES : 2;
+};
 
 template <int NP>
-__global__ void __launch_bounds__(512, 2) clconv_x6w_kernel(const ConvX6Args ca) {
+__global__ void __launch_bounds__(512, X6wLds<NP>::WAVES) clconv_x6w_kernel(const ConvX6Args ca) {
     const GemmNTArgs& a = ca.g;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    constexpr int X6W_ABUF = X6wLds<NP>::ABUF, X6W_BBUF = X6wLds<NP>::BBUF, NPL = X6wLds<NP>::NPL;
     __bf16* Abuf = reinterpret_cast<__bf16*>(smem16);
     __bf16* Bbuf = Abuf + 2 * X6W_ABUF;
     constexpr int APLANE = TM * X6_PITCH;
@@ -387,7 +397,7 @@ __global__ void __launch_bounds__(512, 2) clconv_x6w_kernel(const ConvX6Args ca)
         }
     };
     auto bstore = [&](int buf, const uint4& r0, const uint4& r1, const uint4& r2) {
-        __bf16* st = Bbuf + buf * X6W_BBUF + bt * 3 * X6_PLANE + brw * X6_PITCH + 8 * bh;
+        __bf16* st = Bbuf + buf * X6W_BBUF + bt * NPL * X6_PLANE + brw * X6_PITCH + 8 * bh;
         *reinterpret_cast<uint4*>(st) = r0;
         if constexpr (NP >= 2) *reinterpret_cast<uint4*>(st + X6_PLANE) = r1;
         if constexpr (NP == 3) *reinterpret_cast<uint4*>(st + 2 * X6_PLANE) = r2;
@@ -415,7 +425,7 @@ __global__ void __launch_bounds__(512, 2) clconv_x6w_kernel(const ConvX6Args ca)
     const bool late = wave >= 4;
     auto mm = [&](int step) {
         const __bf16* As = Abuf + (step & 1) * X6W_ABUF + (wm * 64 + l31) * X6_PITCH + 8 * h;
-        const __bf16* Bs = Bbuf + (step & 1) * X6W_BBUF + (wn >> 1) * 3 * X6_PLANE + ((wn & 1) * 64 + l31) * X6_PITCH + 8 * h;
+        const __bf16* Bs = Bbuf + (step & 1) * X6W_BBUF + (wn >> 1) * NPL * X6_PLANE + ((wn & 1) * 64 + l31) * X6_PITCH + 8 * h;
         bf16x8 af[2][NP], bf[2][NP];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -903,11 +913,11 @@ static int launch_x6w(const ConvX6Args& a, hipStream_t s) {
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_x6w_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)X6W_LDS_BYTES);
+                                  (int)X6wLds<NP>::BYTES);
         once = true;
     }
     const unsigned nwg = (unsigned)(a.g.mtiles * (a.g.N / 256));
-    hipLaunchKernelGGL((clconv_x6w_kernel<NP>), dim3(nwg), dim3(512), X6W_LDS_BYTES, s, a);
+    hipLaunchKernelGGL((clconv_x6w_kernel<NP>), dim3(nwg), dim3(512), X6wLds<NP>::BYTES, s, a);
     return ign_check_launch("clconv_x6w_kernel");
 }
 
