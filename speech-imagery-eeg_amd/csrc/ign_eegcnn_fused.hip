@@ -105,6 +105,87 @@ __global__ void __launch_bounds__(256) chan_contract_bwd_w_kernel(const float* _
         }
 }
 
+// The same weight gradient on the matrix cores (rows of a multiple of four samples): dW = sum over slices of du_slice x_slice^T is a
+// 64 x 128 x (B T) GEMM whose two operands are both contiguous along the reduction axis t -- fp32 MFMA (v_mfma_f32_32x32x2_f32:
+// exact fp32 products, an fmaf chain per output, no operand splitting and no magnitude bounds).  Wave w owns the 32 input channels
+// 32 w .. 32 w + 31 and both 32-row halves of the outputs (2 accumulators); lane (l31, h) reads four consecutive t of its du / x
+// row per ds_read_b128 (h selects t .. t+3 or t+4 .. t+7: the MFMA pairs k = t+e of the h = 0 lanes with k = t+4+e of the h = 1
+// lanes -- any pairing is a valid reduction order as long as both operands use the same one), i.e. 8 MFMAs per 3 LDS reads.  Row
+// pitch 68 floats: the 32 rows of a b128 read spread over all banks.  Same slices, same partials, same fixed-order reduction as
+// the VALU kernel above (which at 2.7 FMAs per ds_read_b32 ran at 27 TFLOP/s: 150 us per call; this one ~45).
+typedef float cw_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int CWM_PITCH = 68;
+__global__ void __launch_bounds__(256) chan_contract_bwd_w_mfma_kernel(const float* __restrict__ du, const float* __restrict__ x,
+                                                                       float* __restrict__ part, int B, int Ci, int Co, int T) {
+    __shared__ __attribute__((aligned(16))) float dus[64 * CWM_PITCH];
+    __shared__ __attribute__((aligned(16))) float xs[128 * CWM_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nchunk = (T + CW_TC - 1) / CW_TC;
+    const int nslice = B * nchunk;
+    cw_f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const bool wave_on = wave * 32 < Ci;                             // block-uniform per wave: its 32 input channels exist
+    for (int sl = blockIdx.x; sl < nslice; sl += gridDim.x) {
+        const int b = sl / nchunk, t0 = (sl - b * nchunk) * CW_TC;
+        // stage: 16 float4 per row, 64 + 128 rows (T % 4 == 0: a float4 is inside the row or past its end)
+        float4 v[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int i = tid + 256 * q;                             // 0 .. 3071
+            const int r = i >> 4, t4 = (i & 15) * 4;
+            const bool isx = r >= 64;
+            const int rr = isx ? r - 64 : r;
+            const bool ok = (t0 + t4 < T) && (isx ? rr < Ci : rr < Co);
+            const float* src = isx ? x + ((size_t)b * Ci + rr) * T : du + ((size_t)b * Co + rr) * T;
+            v[q] = ok ? *reinterpret_cast<const float4*>(src + t0 + t4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();                                             // the previous slice has been consumed
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int i = tid + 256 * q;
+            const int r = i >> 4, t4 = (i & 15) * 4;
+            float* dst = (r >= 64) ? xs + (r - 64) * CWM_PITCH + t4 : dus + r * CWM_PITCH + t4;
+            *reinterpret_cast<float4*>(dst) = v[q];
+        }
+        __syncthreads();
+        if (wave_on) {
+            const float* a0p = dus + l31 * CWM_PITCH + 4 * h;
+            const float* a1p = dus + (32 + l31) * CWM_PITCH + 4 * h;
+            const float* bp = xs + (wave * 32 + l31) * CWM_PITCH + 4 * h;
+#pragma unroll
+            for (int kk = 0; kk < CW_TC; kk += 8) {
+                const float4 a0 = *reinterpret_cast<const float4*>(a0p + kk);
+                const float4 a1 = *reinterpret_cast<const float4*>(a1p + kk);
+                const float4 bq = *reinterpret_cast<const float4*>(bp + kk);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bq.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bq.x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bq.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bq.y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bq.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bq.z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bq.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bq.w, acc[1], 0, 0, 0);
+            }
+        }
+    }
+    // accumulator (i, r) of lane (l31, h): output row o = 32 i + 8 (r / 4) + 4 h + r % 4, input channel c = 32 wave + l31
+    float* pb = part + (size_t)blockIdx.x * Co * Ci;
+    const int c = wave * 32 + l31;
+    if (c < Ci) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (o < Co) pb[(size_t)o * Ci + c] = acc[i][r];
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ BatchNorm + ELU + AvgPool
 // block reduction of two doubles (fixed order: lanes by shuffle tree, then waves ascending)
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* sm) {
@@ -290,7 +371,10 @@ extern "C" int ign_chan_contract_bwd_weight(const float* du_bot, const float* x_
     const int nb = cw_blocks(B, T);
     {
         IgnScopedTimer tm("chan_contract_bwd_w", s);
-        hipLaunchKernelGGL(chan_contract_bwd_w_kernel, dim3(nb), dim3(256), 0, s, du_bot, x_bct, (float*)workspace, B, Ci, Co, T);
+        if (T % 4 == 0 && !((uintptr_t)du_bot & 15) && !((uintptr_t)x_bct & 15))
+            hipLaunchKernelGGL(chan_contract_bwd_w_mfma_kernel, dim3(nb), dim3(256), 0, s, du_bot, x_bct, (float*)workspace, B, Ci, Co, T);
+        else
+            hipLaunchKernelGGL(chan_contract_bwd_w_kernel, dim3(nb), dim3(256), 0, s, du_bot, x_bct, (float*)workspace, B, Ci, Co, T);
     }
     if ((rc = ign_check_launch("chan_contract_bwd_w_kernel"))) return rc;
     ign_launch_reduce_parts((const float*)workspace, dw_oc, nb, (size_t)Co * Ci, s);
