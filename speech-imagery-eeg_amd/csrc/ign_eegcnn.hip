@@ -324,26 +324,31 @@ __global__ void __launch_bounds__(64) dwconv1d_wave_kernel(const float* __restri
                                                            float* __restrict__ y, int Cc, int T, int k, int pl, int xs_len) {
     extern __shared__ __attribute__((aligned(16))) float xs[];
     typedef const __attribute__((address_space(4))) float* cfp;
+    // Lane l reads sample TT l + c of the padded row for the same c in every lane: stored plainly, the lanes of a half-wave would
+    // hit 32 / TT banks (TT = 16: two banks, a 16-way conflict per ds_read_b32 -- the LDS reads then cost as much as the FMAs).
+    // Sample e lives at e + e / TT instead: the lane pitch becomes TT + 1, odd, one bank per lane.
+    constexpr int SH = TT == 16 ? 4 : TT == 8 ? 3 : 2;
+#define IGN_SK(e) ((e) + ((e) >> SH))
     const int r = blockIdx.x, lane = threadIdx.x;
     const int ch = r % Cc;
     const float* row = x + (size_t)r * T;
     for (int i = lane; i < xs_len; i += 64) {
         const int s = i - pl;
-        xs[i] = (s >= 0 && s < T) ? row[s] : 0.f;
+        xs[IGN_SK(i)] = (s >= 0 && s < T) ? row[s] : 0.f;
     }
     __syncthreads();
     const cfp wk = (cfp)(uintptr_t)(w + (size_t)ch * k);
-    const float* xl = xs + lane * TT;
+    const float* xl = xs + lane * (TT + 1);         // = IGN_SK(TT lane + c) - (c + c / TT)
     constexpr int J = 8;                            // taps per unrolled group: one s_load_dwordx8 of taps, TT-1 register moves
     float acc[TT], xw[TT + J - 1];
 #pragma unroll
     for (int t = 0; t < TT; ++t) acc[t] = 0.f;
 #pragma unroll
-    for (int i = 0; i < TT - 1; ++i) xw[i] = xl[i];
+    for (int i = 0; i < TT - 1; ++i) xw[i] = xl[IGN_SK(i)];
     int j0 = 0;
     for (; j0 + J <= k; j0 += J) {
 #pragma unroll
-        for (int jj = 0; jj < J; ++jj) xw[TT - 1 + jj] = xl[j0 + TT - 1 + jj];
+        for (int jj = 0; jj < J; ++jj) xw[TT - 1 + jj] = xl[IGN_SK(j0 + TT - 1 + jj)];
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) {
             const float wv = FLIP ? wk[k - 1 - (j0 + jj)] : wk[j0 + jj];             // wave-uniform: s_load, SGPR operand
@@ -354,7 +359,7 @@ __global__ void __launch_bounds__(64) dwconv1d_wave_kernel(const float* __restri
         for (int i = 0; i < TT - 1; ++i) xw[i] = xw[i + J];
     }
     for (; j0 < k; ++j0) {
-        xw[TT - 1] = xl[j0 + TT - 1];
+        xw[TT - 1] = xl[IGN_SK(j0 + TT - 1)];
         const float wv = FLIP ? wk[k - 1 - j0] : wk[j0];
 #pragma unroll
         for (int t = 0; t < TT; ++t) acc[t] = fmaf(wv, xw[t], acc[t]);
@@ -364,10 +369,11 @@ __global__ void __launch_bounds__(64) dwconv1d_wave_kernel(const float* __restri
     // lane-major registers -> time-major LDS -> coalesced stores (the row is no longer needed)
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < TT; ++t) xs[lane * TT + t] = acc[t];
+    for (int t = 0; t < TT; ++t) xs[lane * (TT + 1) + t] = acc[t];
     __syncthreads();
     float* yo = y + (size_t)r * T;
-    for (int i = lane; i < T; i += 64) yo[i] = xs[i];
+    for (int i = lane; i < T; i += 64) yo[i] = xs[IGN_SK(i)];
+#undef IGN_SK
 }
 
 constexpr int XC_ROWS = 32;                        // rows per block and group
@@ -646,7 +652,8 @@ extern "C" int ign_dwconv1d_fwd(const float* x, const float* w, float* y, int B,
         // one wave per row, TT = 4 / 8 / 16 outputs per lane (the smallest that covers T)
         const int TT = T <= 256 ? 4 : T <= 512 ? 8 : 16;
         const int xl = (64 * TT + k + 3) & ~3;
-        const size_t l2 = (size_t)xl * 4;
+        const size_t l2 = (size_t)(xl + xl / TT + 4) * 4;             // skewed layout: sample e at e + e / TT
+
         const dim3 grid((unsigned)B * Cc), block(64);
 #define IGN_DW(TTV)                                                                                                                 \
         do {                                                                                                                        \
