@@ -595,3 +595,35 @@ def test_ign_in_autocast_mode_tracks_the_oracle_in_autocast_mode():
             continue
         ref = go[n].grad.float()
         assert float((p.grad.float().cpu() - ref).norm()) < 0.1 * float(ref.norm()) + 1e-4, n
+
+
+def test_one_stream_and_two_stream_expert_dispatch_give_the_same_step():
+    """InterpGN runs its two experts on one stream below 2^21 input elements (the instance-norm pass then also takes the raw batch's
+    magnitude bound for the FCN expert) and on two streams above: same logits, same loss, same gradients, bit for bit -- the bound
+    is the exact maximum either way and nothing else differs but the queue the kernels are issued to."""
+    dev = _dev()
+    import copy
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops
+    from models.InterpGN import InterpGN
+    cfg = make_cfg()
+    torch.manual_seed(0)
+    base = InterpGN(cfg).to(dev).train()
+    x = torch.randn(16, 100, 6, device=dev) * 3.0
+    y = (torch.arange(16) % 4).to(dev)
+    mask = torch.ones(16, 100, device=dev)
+    res = {}
+    for mode, thresh in (("one", 1 << 40), ("two", 0)):
+        m = copy.deepcopy(base)
+        m.two_stream_min_elems = thresh
+        xin = x.clone()
+        out, info = m(xin, mask, None, None)
+        loss = ops.ign_loss(info.shapelet_preds, info.dnn_preds, y, 1.0, reg=info.loss)[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        assert (ops.cached_bound(xin) is not None) == (mode == "one")          # attached by the instance-norm pass on the shared stream
+        res[mode] = (out.detach(), loss.detach(), [p.grad.clone() for p in m.parameters() if p.grad is not None])
+    assert torch.equal(res["one"][0], res["two"][0]) and torch.equal(res["one"][1], res["two"][1])
+    assert len(res["one"][2]) == len(res["two"][2])
+    for a, b in zip(res["one"][2], res["two"][2]):
+        assert torch.equal(a, b)
