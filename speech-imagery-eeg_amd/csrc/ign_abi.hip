@@ -218,8 +218,22 @@ extern "C" int ign_shapelet_fwd_bank(const float* xn_bct, int G, const float* co
         if ((rc = plan_fwd(who, xn_bct, w_kcl[g], thr_kc ? thr_kc[g] : nullptr, p_out, dmin_out, ld, col0[g], tstar[g], zmu[g],
                            d_save ? d_save[g] : nullptr, xstat_save ? xstat_save[g] : nullptr, B, C, T, K[g], L[g], stride[g], eps,
                            mode, &pl[g]))) return rc;
-    for (int g = 0; g < G; ++g)
-        if ((rc = launch_fwd_group(who, pl[g], stream))) return rc;
+    // Launch order: longest shapelets first.  The groups are independent (results do not depend on the order), but the tail of a
+    // group's grid -- its last, partly filled round of blocks -- is covered by the start of the next group's grid, so only the LAST
+    // group's tail is exposed, and the group with the shortest blocks has the shortest one (same box, four orders x 60 runs:
+    // 3.85-3.86 ms ending on L = 100 or 300 against 3.91 ms ending on L = 500).
+    int order[SHP_MAX_GROUPS];
+    for (int g = 0; g < G; ++g) order[g] = g;
+#ifndef IGN_FWD_GROUP_ORDER_AS_GIVEN
+    for (int i = 1; i < G; ++i) {                 // insertion sort, descending L, stable
+        const int v = order[i];
+        int j = i - 1;
+        while (j >= 0 && L[order[j]] < L[v]) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = v;
+    }
+#endif
+    for (int i = 0; i < G; ++i)
+        if ((rc = launch_fwd_group(who, pl[order[i]], stream))) return rc;
     return 0;
 }
 
@@ -430,6 +444,7 @@ extern "C" int ign_shapelet_bwd_bank(const float* xn_bct, int G, const float* co
     ReduceBankTable t;
     char* ws[SHP_MAX_GROUPS];
     int rc;
+    // (launch order as given: longest-first, which helps the forward bank, measured neutral-to-worse here)
     for (int pass = 0; pass < 2; ++pass) {            // pass 0 validates every group, pass 1 launches
         char* cur = (char*)workspace;
         for (int g = 0; g < G; ++g) {
