@@ -478,6 +478,13 @@ int ign_clconv_fwd_h3(const float* x, const void* wt_h2, const float* bias, cons
 int ign_clconv_fwd_h3_amax(const float* x, const void* wt_h2, const float* bias, const float* pro_a, const float* pro_b, float* y,
                            float* stat_part, const float* bound_in, const float* bound_w, float* amax_out, int B, int Tin, int Ci,
                            int Co, int k, void* stream);
+/* du = (g W) * gelu'(u) in ONE GEMM: the input gradient of the feed-forward's second dense layer z = gelu(u) W^T + b
+ * (IGN/layers/Transformer_EncDec.py:46-47) THROUGH the activation -- the exact-GELU derivative Phi(u) + u phi(u) is applied in the
+ * epilogue, so dL/dy is never written and aten::gelu_backward's three passes over the (rows, d_ff) tensors disappear.  g (M, Co),
+ * wd_h2 = the packed TRANSPOSED weight (as for the input gradient via ign_clconv_fwd_h3), u / du (M, Ci); Ci % 256 == 0,
+ * Co % 4 == 0; amax_out nullable (max |du|).  f16x3 arithmetic only (IGN_E_UNSUP otherwise: callers keep the two-kernel route).  */
+int ign_linear_dgrad_gelu_h3(const float* g, const void* wd_h2, const float* u, float* du, const float* bound_g, const float* bound_w,
+                             float* amax_out, long long M, int Co, int Ci, void* stream);
 int ign_clconv_dgrad_h3(const float* dyp, const void* wt_h2_dgrad, const float* y_in, const float* a_in, const float* b_in,
                         const float* mean_in, const float* invstd_in, float* g_in, float* stat_part, const float* bound_dy,
                         const float* bound_w, int B, int Tin, int Ci, int Co, int k, void* stream);

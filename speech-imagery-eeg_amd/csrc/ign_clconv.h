@@ -44,7 +44,14 @@ __device__ __forceinline__ void vstore(float* p, const float (&d)[V]) {
     else *p = d[0];
 }
 
-enum { EPI_BIAS_STATS = 0, EPI_MASK_STATS = 1 };
+enum { EPI_BIAS_STATS = 0, EPI_MASK_STATS = 1, EPI_GELU_BWD = 2 };
+
+// d gelu(u) / du of the exact (erf) GELU, as aten::gelu_backward evaluates it: Phi(u) + u phi(u)
+__device__ __forceinline__ float ign_gelu_grad(float u) {
+    const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * expf(-0.5f * u * u);
+    return fmaf(u, pdf, cdf);
+}
 
 struct GemmNTArgs {
     const float* A; RowMap am; int K;          // A[m][kk] = A[row_off(m) + kk]
@@ -53,7 +60,8 @@ struct GemmNTArgs {
     const float* bias;                         // [N] or null
     const float* pro_a; const float* pro_b; int pro_c;    // prologue: A <- relu(pro_a[c]*A + pro_b[c]), c = kk % pro_c
     float* part;                               // (mtiles, 2, N) partial sums, or null
-    // EPI_MASK_STATS: g = acc * [ea*y + eb > 0]; partials of g and g*(y - mean)*invstd
+    // EPI_MASK_STATS: g = acc * [ea*y + eb > 0]; partials of g and g*(y - mean)*invstd.   EPI_GELU_BWD: C = acc * gelu'(ey) (ey = the
+    // pre-activation u, same (M, N) layout as C): the backward of y = gelu(u) in the epilogue of the GEMM that produces dL/dy
     const float* ey; const float* ea; const float* eb; const float* emean; const float* einv;
     int mtiles, ntiles;
     const unsigned short* B3; int Kp;          // split-bf16 kernels: Bt as 3 bf16 planes (3, N, Kp), Kp = K rounded up to 8
@@ -85,7 +93,7 @@ __device__ __forceinline__ void nt_epilogue_body(const GemmNTArgs& a, const f32x
         for (int i = 0; i < 2; ++i) {
             const int mb = m0 + wm * 64 + i * 32;
             float yv[16];
-            if (EPI == EPI_MASK_STATS) {
+            if (EPI == EPI_MASK_STATS || EPI == EPI_GELU_BWD) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mb + acc_row16(r, h);
@@ -101,6 +109,8 @@ __device__ __forceinline__ void nt_epilogue_body(const GemmNTArgs& a, const f32x
                 if (EPI == EPI_BIAS_STATS) {
                     v += bv;
                     if (ok) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+                } else if (EPI == EPI_GELU_BWD) {
+                    v *= ign_gelu_grad(yv[r]);
                 } else {
                     v = (fmaf(ea, yv[r], eb) > 0.f) ? v : 0.f;
                     if (ok) { s1[j] += v; s2[j] = fmaf(v, (yv[r] - em) * ei, s2[j]); }

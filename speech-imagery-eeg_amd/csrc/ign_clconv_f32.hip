@@ -381,7 +381,8 @@ extern "C" int ign_clconv_pack_weights(const float* w_oik, float* wt_fwd, float*
 // x6: 0 = fp32 MFMA, 6 = split bf16 (six products), 1 = operands rounded to bf16 (one product)
 static int clconv_fwd_impl(const char* who, int x6, const float* x, const void* wt, const float* bias, const float* pro_a,
                            const float* pro_b, float* y, float* stat_part, int B, int Tin, int Ci, int Co, int k, void* stream,
-                           const float* bound_a = nullptr, const float* bound_w = nullptr, float* amax_out = nullptr) {
+                           const float* bound_a = nullptr, const float* bound_w = nullptr, float* amax_out = nullptr,
+                           int epi = EPI_BIAS_STATS, const float* ey = nullptr) {
     const int Tout = Tin - k + 1;
     if (!x || !wt || !y || B <= 0 || Ci <= 0 || Co <= 0 || k <= 0 || Tout <= 0 || ((pro_a == nullptr) != (pro_b == nullptr))) {
         ign_set_error("%s: bad argument (B=%d Tin=%d Ci=%d Co=%d k=%d)", who, B, Tin, Ci, Co, k);
@@ -393,7 +394,7 @@ static int clconv_fwd_impl(const char* who, int x6, const float* x, const void* 
     a.A = x; a.am = RowMap{Tout, 0, Ci, (long long)Tin * Ci}; a.K = k * Ci;
     a.Bt = x6 ? nullptr : (const float*)wt; a.ldb = k * Ci; a.C = y; a.M = (int)M; a.N = Co; a.bias = bias;
     a.B3 = x6 ? (const unsigned short*)wt : nullptr; a.Kp = 0;
-    a.pro_a = pro_a; a.pro_b = pro_b; a.pro_c = Ci; a.part = stat_part; a.amax_out = amax_out;
+    a.pro_a = pro_a; a.pro_b = pro_b; a.pro_c = Ci; a.part = stat_part; a.amax_out = amax_out; a.ey = ey;
     a.mtiles = (int)((M + TM - 1) / TM); a.ntiles = (Co + TN - 1) / TN;
     IgnScopedTimer tm("clconv_fwd", (hipStream_t)stream);
     if (x6) {
@@ -403,8 +404,9 @@ static int clconv_fwd_impl(const char* who, int x6, const float* x, const void* 
         c.cin = Ci; c.cp = (Ci + 15) / 16 * 16; c.k = k; c.g.Kp = k * c.cp;
         c.sample_pitch = (long long)Tin * Ci; c.rows_in = Tin; c.trows = Tout; c.tps = (Tout + TM - 1) / TM;
         c.g.mtiles = B * c.tps; c.nprod = x6; c.bound_a = bound_a; c.bound_b = bound_w;
-        return ign_clconv_launch_x6t(c, EPI_BIAS_STATS, ign_vec_width(Ci), pro_a != nullptr, (hipStream_t)stream);
+        return ign_clconv_launch_x6t(c, epi, ign_vec_width(Ci), pro_a != nullptr, (hipStream_t)stream);
     }
+    if (epi != EPI_BIAS_STATS) { ign_set_error("%s: epilogue %d needs the split kernels", who, epi); return IGN_E_UNSUP; }
     return launch_nt<EPI_BIAS_STATS>(a, ign_vec_width(Ci), pro_a != nullptr, (hipStream_t)stream);
 }
 
@@ -435,6 +437,19 @@ extern "C" int ign_clconv_fwd_h3_amax(const float* x, const void* wt_h2, const f
     if (!bound_in || !bound_w) { ign_set_error("ign_clconv_fwd_h3: null operand bound"); return IGN_E_ARG; }
     return clconv_fwd_impl("ign_clconv_fwd_h3", 3, x, wt_h2, bias, pro_a, pro_b, y, stat_part, B, Tin, Ci, Co, k, stream, bound_in,
                            bound_w, amax_out);
+}
+
+// du = (g W) * gelu'(u): the input gradient of a dense layer z = gelu(u) W^T + b, through the activation, in one GEMM
+// (g (M, Co), wd_h2 = the transposed packed weight as for ign_clconv_fwd_h3's input gradient, u / du (M, Ci), Ci % 256 == 0).
+extern "C" int ign_linear_dgrad_gelu_h3(const float* g, const void* wd_h2, const float* u, float* du, const float* bound_g,
+                                        const float* bound_w, float* amax_out, long long M, int Co, int Ci, void* stream) {
+    if (!bound_g || !bound_w || !u) { ign_set_error("ign_linear_dgrad_gelu_h3: null bound / pre-activation"); return IGN_E_ARG; }
+    if (M <= 0 || M > 0x3fffffffLL || Ci % 256 || Co % 4) {
+        ign_set_error("ign_linear_dgrad_gelu_h3: needs 0 < M < 2^30, Ci %% 256 == 0, Co %% 4 == 0 (M=%lld Co=%d Ci=%d)", M, Co, Ci);
+        return IGN_E_UNSUP;
+    }
+    return clconv_fwd_impl("ign_linear_dgrad_gelu_h3", 3, g, wd_h2, nullptr, nullptr, nullptr, du, nullptr, 1, (int)M, Co, Ci, 1, stream,
+                           bound_g, bound_w, amax_out, EPI_GELU_BWD, u);
 }
 
 static int clconv_dgrad_impl(const char* who, int x6, const float* dyp, const void* wt_dgrad, const float* y_in, const float* a_in,

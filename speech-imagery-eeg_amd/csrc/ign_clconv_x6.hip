@@ -338,7 +338,7 @@ template <int NP> struct X6wLds {
     static constexpr int WAVES = NP == 2 ? IGN_H3W_WAVES : 2;
 };
 
-template <int NP>
+template <int NP, int EPI = EPI_BIAS_STATS>
 __global__ void __launch_bounds__(512, X6wLds<NP>::WAVES) clconv_x6w_kernel(const ConvX6Args ca) {
     const GemmNTArgs& a = ca.g;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
@@ -468,8 +468,8 @@ __global__ void __launch_bounds__(512, X6wLds<NP>::WAVES) clconv_x6w_kernel(cons
     // epilogue: bias + store (nt_epilogue_body derives wm / wn from the thread index: wn 0..3 covers the 256 columns)
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
     const int m_lim = a.M;
-    if (m0 + TM <= m_lim) nt_epilogue_body<EPI_BIAS_STATS, true, NP == 2>(a, acc, s1, s2, m0, n0, m_lim, osc);
-    else nt_epilogue_body<EPI_BIAS_STATS, false, NP == 2>(a, acc, s1, s2, m0, n0, m_lim, osc);
+    if (m0 + TM <= m_lim) nt_epilogue_body<EPI, true, NP == 2>(a, acc, s1, s2, m0, n0, m_lim, osc);
+    else nt_epilogue_body<EPI, false, NP == 2>(a, acc, s1, s2, m0, n0, m_lim, osc);
 }
 
 // Step-block-major planes for the kernel above: block (n-tile, chunk cc, tap j) = [plane][row 0..127][16 channels of chunk cc]
@@ -908,20 +908,29 @@ static int launch_x6t(const ConvX6Args& a, int V, bool pro, hipStream_t s) {
     return ign_check_launch("clconv_x6t_kernel");
 }
 
-template <int NP>
+template <int NP, int EPI = EPI_BIAS_STATS>
 static int launch_x6w(const ConvX6Args& a, hipStream_t s) {
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_x6w_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clconv_x6w_kernel<NP, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)X6wLds<NP>::BYTES);
         once = true;
     }
     const unsigned nwg = (unsigned)(a.g.mtiles * (a.g.N / 256));
-    hipLaunchKernelGGL((clconv_x6w_kernel<NP>), dim3(nwg), dim3(512), X6wLds<NP>::BYTES, s, a);
+    hipLaunchKernelGGL((clconv_x6w_kernel<NP, EPI>), dim3(nwg), dim3(512), X6wLds<NP>::BYTES, s, a);
     return ign_check_launch("clconv_x6w_kernel");
 }
 
 int ign_clconv_launch_x6t(const ConvX6Args& a, int epi, int V, bool pro, hipStream_t s) {
+    if (epi == EPI_GELU_BWD) {
+        // dense layer's input gradient with the GELU derivative in the epilogue: the wide-tile kernel on fp16 planes only
+        if (!(a.k == 1 && a.g.N % 256 == 0 && V == 4 && !pro && !a.g.part && a.tps * 1 == a.g.mtiles && a.trows == a.g.M && a.nprod == 3
+              && a.g.ey)) {
+            ign_set_error("ign_clconv_launch_x6t: the GELU-gradient epilogue needs k = 1, N %% 256 == 0, C %% 4 == 0, the f16x3 arithmetic");
+            return IGN_E_UNSUP;
+        }
+        return launch_x6w<2, EPI_GELU_BWD>(a, s);
+    }
     // Linear layers with wide outputs: the 128 x 256 tile kernel (see clconv_x6w_kernel)
     if (a.k == 1 && a.g.N % 256 == 0 && V == 4 && !pro && epi == EPI_BIAS_STATS && !a.g.part &&
         a.tps * 1 == a.g.mtiles && a.trows == a.g.M)

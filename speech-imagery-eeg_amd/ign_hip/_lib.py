@@ -114,6 +114,7 @@ SIGNATURES = {
     "ign_clconv_pack_weights_h2_multi": (ci, [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ign_clconv_fwd_h3": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ign_clconv_fwd_h3_amax": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "ign_linear_dgrad_gelu_h3": (ci, [vp, vp, vp, vp, vp, vp, vp, ll, ci, ci, vp]),
     "ign_clconv_dgrad_h3": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ign_clconv_wgrad_h3": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "ign_linear_wgrad_h3": (ci, [vp, vp, vp, vp, vp, vp, vp, ll, ci, ci, vp]),

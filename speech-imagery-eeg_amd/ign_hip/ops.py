@@ -676,6 +676,111 @@ def _take_prepared(w, need_dx):
     return ent
 
 
+def _linear_forward(ctx, x, w, bias, extra=()):
+    """LinearFn.forward; `extra`: tensors saved behind x2 (GeluLinearFn: the pre-activation)."""
+    L = _lib.lib()
+    Co, Ci = w.shape
+    x2 = x.reshape(-1, Ci)
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    M = x2.shape[0]
+    w = w.contiguous()
+    dev = x.device
+    need_dx = ctx.needs_input_grad[0]
+    ctx.bf16 = torch.is_autocast_enabled()          # autocast region: operands rounded to bf16, one product (see _gemm)
+    ctx.h3 = (not ctx.bf16) and GEMM_MATH == "f16x3"
+    prepared = _take_prepared(w, need_dx) if ctx.h3 else None       # bound + packed planes from the model's prologue launch
+    if prepared is not None:
+        wt3, wd3 = prepared[4], (prepared[5] if need_dx else None)
+    else:
+        wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, 1)), device=dev, dtype=torch.bfloat16)
+        wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, 1)), device=dev, dtype=torch.bfloat16) if need_dx else None
+    y = torch.empty(*x.shape[:-1], Co, device=dev, dtype=torch.float32)    # final shape (not a view: its reshaped views find its bound)
+    ctx.bx = ctx.bw = None
+    if ctx.h3:
+        # two fp16 planes, three products: operand bounds on the device (the input's is inherited from x when x2 is a view)
+        ctx.bx = tensor_bound(x) if x2.data_ptr() == x.data_ptr() and x.is_contiguous() else tensor_bound(x2)
+        if prepared is not None:
+            ctx.bw = prepared[3]
+        else:
+            ctx.bw = tensor_bound(w)
+            v1, i1 = _tables(1)
+            _lib.check(L.ign_clconv_pack_weights_h2_multi(1, v1(w.data_ptr()), v1(wt3.data_ptr()),
+                                                          v1(wd3.data_ptr()) if need_dx else None, i1(Co), i1(Ci), i1(1), None,
+                                                          v1(ctx.bw.data_ptr()), _stream()), "ign_clconv_pack_weights_h2_multi")
+        # the epilogue also takes max |y|: the operand bound of whatever dense layer / attention core consumes y
+        yb = _new_slot(dev)
+        _lib.check(L.ign_clconv_fwd_h3_amax(_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, _ptr(ctx.bx), _ptr(ctx.bw),
+                                            _ptr(yb), 1, M, Ci, Co, 1, _stream()), "ign_clconv_fwd_h3")
+    else:
+        yb = None
+        _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt3), _ptr(wd3), Co, Ci, 1, _stream()), "ign_clconv_pack_weights_x3")
+        _lib.check(_gemm(L, ctx.bf16)[0](_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, 1, M, Ci, Co, 1, _stream()),
+                   "ign_clconv_fwd_x6")
+    ctx.save_for_backward(x2, *extra)
+    ctx.wd3, ctx.dims, ctx.has_bias, ctx.xshape = wd3, (M, Ci, Co), bias is not None, x.shape
+    ctx.mark_non_differentiable(*([yb] if yb is not None else []))
+    ctx.set_materialize_grads(False)              # no zero-filled "gradient" of the bound output per backward call
+    return y, yb
+
+
+def _linear_backward(ctx, gy, gelu=False):
+    """LinearFn.backward.  `gelu`: the layer's input was gelu(u), u saved behind x2 -- the returned input gradient is dL/du, the
+    activation's derivative applied in the epilogue of the input-gradient GEMM (ign_linear_dgrad_gelu_h3) where the shape allows."""
+    if gy is None:
+        return None, None, None
+    L = _lib.lib()
+    x2 = ctx.saved_tensors[0]
+    u2 = ctx.saved_tensors[1].reshape(x2.shape) if gelu else None
+    M, Ci, Co = ctx.dims
+    g2 = gy.reshape(M, Co)
+    g2 = g2 if g2.is_contiguous() else g2.contiguous()
+    dx = dw = db = None
+    bg = tensor_bound(g2) if ctx.h3 else None
+    if ctx.needs_input_grad[0]:
+        dx = torch.empty(M, Ci, device=g2.device, dtype=torch.float32)
+        dxb = None
+        fused = gelu and ctx.h3 and Ci % 256 == 0 and Co % 4 == 0 and u2.is_contiguous()
+        if fused:
+            dxb = _new_slot(g2.device)           # dL/du = (g W) * gelu'(u) in one GEMM; its epilogue also takes max |dL/du|
+            _lib.check(L.ign_linear_dgrad_gelu_h3(_ptr(g2), _ptr(ctx.wd3), _ptr(u2), _ptr(dx), _ptr(bg), _ptr(ctx.bw), _ptr(dxb), M, Co, Ci,
+                                                  _stream()), "ign_linear_dgrad_gelu_h3")
+        elif ctx.h3:
+            dxb = _new_slot(g2.device)           # the epilogue takes max |dx|: the next backward GEMM's operand bound
+            _lib.check(L.ign_clconv_fwd_h3_amax(_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, _ptr(bg), _ptr(ctx.bw),
+                                                _ptr(dxb), 1, M, Co, Ci, 1, _stream()), "ign_clconv_fwd_h3_amax(dx)")
+        else:
+            _lib.check(_gemm(L, ctx.bf16)[0](_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, 1, M, Co, Ci, 1, _stream()),
+                       "ign_clconv_fwd_x6(dx)")
+        if gelu and not fused:                   # shapes / arithmetics outside the fused kernel: torch's element-wise backward
+            dx = torch.ops.aten.gelu_backward(dx, u2)     # (|gelu'| <= 1.13: dxb stays a usable bound, see keep_bound)
+        dx = dx.view(ctx.xshape)
+        if dxb is not None:
+            set_bound(dx, dxb)
+    want_db = ctx.has_bias and ctx.needs_input_grad[2]
+    if ctx.needs_input_grad[1]:
+        dw = torch.empty(Co, Ci, device=g2.device, dtype=torch.float32)
+        if Ci % 4 == 0 and LINEAR_WGRAD == "bf16x6":
+            # weight and bias gradient in one pass over dy (the bias gradient rides on the tiles that stage dy anyway)
+            ws = torch.empty(int(L.ign_clconv_wgrad_x6_workspace_bytes(1, M, Ci, Co, 1)) // 4, device=g2.device,
+                             dtype=torch.float32)
+            if want_db:
+                db = torch.empty(Co, device=g2.device, dtype=torch.float32)
+            if ctx.h3:
+                _lib.check(L.ign_linear_wgrad_h3(_ptr(g2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(ws), _ptr(bg), _ptr(ctx.bx), M, Ci, Co,
+                                                 _stream()), "ign_linear_wgrad_h3")
+            else:
+                fn = L.ign_linear_wgrad_bf16 if ctx.bf16 else L.ign_linear_wgrad_x6
+                _lib.check(fn(_ptr(g2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(ws), M, Ci, Co, _stream()), "ign_linear_wgrad_x6")
+        else:
+            ws = torch.empty(int(L.ign_clconv_wgrad_workspace_bytes(1, M, Ci, Co, 1)) // 4, device=g2.device,
+                             dtype=torch.float32)
+            _lib.check(L.ign_clconv_wgrad(_ptr(g2), 0, _ptr(x2), None, None, _ptr(dw), _ptr(ws), 1, M, Ci, Co, 1, _stream()),
+                       "ign_clconv_wgrad")
+    if want_db and db is None:
+        db = g2.sum(dim=0)
+    return dx, dw, db
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b for the dense layers of the two encoder baselines (IGN/layers/SelfAttention_Family.py:195-211,
     IGN/layers/Transformer_EncDec.py:33-48, nn.TransformerEncoderLayer in IGN/model/eegcnn.py:219-228) on the library's own
@@ -686,97 +791,27 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias):
-        L = _lib.lib()
-        Co, Ci = w.shape
-        x2 = x.reshape(-1, Ci)
-        x2 = x2 if x2.is_contiguous() else x2.contiguous()
-        M = x2.shape[0]
-        w = w.contiguous()
-        dev = x.device
-        need_dx = ctx.needs_input_grad[0]
-        ctx.bf16 = torch.is_autocast_enabled()          # autocast region: operands rounded to bf16, one product (see _gemm)
-        ctx.h3 = (not ctx.bf16) and GEMM_MATH == "f16x3"
-        prepared = _take_prepared(w, need_dx) if ctx.h3 else None       # bound + packed planes from the model's prologue launch
-        if prepared is not None:
-            wt3, wd3 = prepared[4], (prepared[5] if need_dx else None)
-        else:
-            wt3 = torch.empty(int(L.ign_clconv_x3_elems(Co, Ci, 1)), device=dev, dtype=torch.bfloat16)
-            wd3 = torch.empty(int(L.ign_clconv_x3_elems(Ci, Co, 1)), device=dev, dtype=torch.bfloat16) if need_dx else None
-        y = torch.empty(*x.shape[:-1], Co, device=dev, dtype=torch.float32)    # final shape (not a view: its reshaped views find its bound)
-        ctx.bx = ctx.bw = None
-        if ctx.h3:
-            # two fp16 planes, three products: operand bounds on the device (the input's is inherited from x when x2 is a view)
-            ctx.bx = tensor_bound(x) if x2.data_ptr() == x.data_ptr() and x.is_contiguous() else tensor_bound(x2)
-            if prepared is not None:
-                ctx.bw = prepared[3]
-            else:
-                ctx.bw = tensor_bound(w)
-                v1, i1 = _tables(1)
-                _lib.check(L.ign_clconv_pack_weights_h2_multi(1, v1(w.data_ptr()), v1(wt3.data_ptr()),
-                                                              v1(wd3.data_ptr()) if need_dx else None, i1(Co), i1(Ci), i1(1), None,
-                                                              v1(ctx.bw.data_ptr()), _stream()), "ign_clconv_pack_weights_h2_multi")
-            # the epilogue also takes max |y|: the operand bound of whatever dense layer / attention core consumes y
-            yb = _new_slot(dev)
-            _lib.check(L.ign_clconv_fwd_h3_amax(_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, _ptr(ctx.bx), _ptr(ctx.bw),
-                                                _ptr(yb), 1, M, Ci, Co, 1, _stream()), "ign_clconv_fwd_h3")
-        else:
-            yb = None
-            _lib.check(L.ign_clconv_pack_weights_x3(_ptr(w), _ptr(wt3), _ptr(wd3), Co, Ci, 1, _stream()), "ign_clconv_pack_weights_x3")
-            _lib.check(_gemm(L, ctx.bf16)[0](_ptr(x2), _ptr(wt3), _ptr(bias), None, None, _ptr(y), None, 1, M, Ci, Co, 1, _stream()),
-                       "ign_clconv_fwd_x6")
-        ctx.save_for_backward(x2)
-        ctx.wd3, ctx.dims, ctx.has_bias, ctx.xshape = wd3, (M, Ci, Co), bias is not None, x.shape
-        ctx.mark_non_differentiable(*([yb] if yb is not None else []))
-        ctx.set_materialize_grads(False)              # no zero-filled "gradient" of the bound output per backward call
-        return y, yb
+        return _linear_forward(ctx, x, w, bias)
 
     @staticmethod
     def backward(ctx, gy, _gyb=None):
-        if gy is None:
-            return None, None, None
-        L = _lib.lib()
-        (x2,) = ctx.saved_tensors
-        M, Ci, Co = ctx.dims
-        g2 = gy.reshape(M, Co)
-        g2 = g2 if g2.is_contiguous() else g2.contiguous()
-        dx = dw = db = None
-        bg = tensor_bound(g2) if ctx.h3 else None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, Ci, device=g2.device, dtype=torch.float32)
-            dxb = None
-            if ctx.h3:
-                dxb = _new_slot(g2.device)           # the epilogue takes max |dx|: the next backward GEMM's operand bound
-                _lib.check(L.ign_clconv_fwd_h3_amax(_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, _ptr(bg), _ptr(ctx.bw),
-                                                    _ptr(dxb), 1, M, Co, Ci, 1, _stream()), "ign_clconv_fwd_h3_amax(dx)")
-            else:
-                _lib.check(_gemm(L, ctx.bf16)[0](_ptr(g2), _ptr(ctx.wd3), None, None, None, _ptr(dx), None, 1, M, Co, Ci, 1, _stream()),
-                           "ign_clconv_fwd_x6(dx)")
-            dx = dx.view(ctx.xshape)
-            if dxb is not None:
-                set_bound(dx, dxb)
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty(Co, Ci, device=g2.device, dtype=torch.float32)
-            if Ci % 4 == 0 and LINEAR_WGRAD == "bf16x6":
-                # weight and bias gradient in one pass over dy (the bias gradient rides on the tiles that stage dy anyway)
-                ws = torch.empty(int(L.ign_clconv_wgrad_x6_workspace_bytes(1, M, Ci, Co, 1)) // 4, device=g2.device,
-                                 dtype=torch.float32)
-                if want_db:
-                    db = torch.empty(Co, device=g2.device, dtype=torch.float32)
-                if ctx.h3:
-                    _lib.check(L.ign_linear_wgrad_h3(_ptr(g2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(ws), _ptr(bg), _ptr(ctx.bx), M, Ci, Co,
-                                                     _stream()), "ign_linear_wgrad_h3")
-                else:
-                    fn = L.ign_linear_wgrad_bf16 if ctx.bf16 else L.ign_linear_wgrad_x6
-                    _lib.check(fn(_ptr(g2), _ptr(x2), _ptr(dw), _ptr(db), _ptr(ws), M, Ci, Co, _stream()), "ign_linear_wgrad_x6")
-            else:
-                ws = torch.empty(int(L.ign_clconv_wgrad_workspace_bytes(1, M, Ci, Co, 1)) // 4, device=g2.device,
-                                 dtype=torch.float32)
-                _lib.check(L.ign_clconv_wgrad(_ptr(g2), 0, _ptr(x2), None, None, _ptr(dw), _ptr(ws), 1, M, Ci, Co, 1, _stream()),
-                           "ign_clconv_wgrad")
-        if want_db and db is None:
-            db = g2.sum(dim=0)
-        return dx, dw, db
+        return _linear_backward(ctx, gy)
+
+
+class GeluLinearFn(torch.autograd.Function):
+    """z = gelu(u) W^T + b -- the activation and second dense layer of an encoder's feed-forward block
+    (IGN/layers/Transformer_EncDec.py:46-47) as one node: forward = torch's GELU kernel + the dense layer's GEMM; backward = the
+    weight gradient from the saved gelu(u) and the input gradient THROUGH the activation in one GEMM (ign_linear_dgrad_gelu_h3:
+    dL/dy is never written, aten::gelu_backward's three passes over the (rows, d_ff) tensors disappear)."""
+
+    @staticmethod
+    def forward(ctx, u, w, bias):
+        y = keep_bound(torch.nn.functional.gelu(u), u)
+        return _linear_forward(ctx, y, w, bias, extra=(u,))
+
+    @staticmethod
+    def backward(ctx, gy, _gyb=None):
+        return _linear_backward(ctx, gy, gelu=True)
 
 
 def linear(x, w, bias=None):
@@ -789,6 +824,18 @@ def linear(x, w, bias=None):
             or x.numel() // x.shape[-1] >= (1 << 30)):
         return torch.nn.functional.linear(x, w, bias)
     y, yb = LinearFn.apply(x, w, bias)
+    if yb is not None:
+        set_bound(y, yb)
+    return y
+
+
+def gelu_linear(u, w, bias=None):
+    """linear(gelu(u), w, bias) with the GELU's backward folded into the dense layer's input-gradient GEMM (GeluLinearFn); inputs the
+    hand-written GEMMs do not cover take the two-op route."""
+    if (not u.is_cuda or u.dtype != torch.float32 or w.dtype != torch.float32 or w.shape[0] % 4 or u.numel() == 0
+            or u.shape[-1] != w.shape[1] or u.numel() // u.shape[-1] >= (1 << 30)):
+        return linear(gelu(u), w, bias)
+    y, yb = GeluLinearFn.apply(u, w, bias)
     if yb is not None:
         set_bound(y, yb)
     return y

@@ -26,10 +26,16 @@ class EncoderLayer(nn.Module):
         x = ops.layer_norm(x, self.norm1, residual=self.dropout(new_x))       # LayerNorm(x + attention(x)): the add rides on the pass
         # the k=1 convolutions are plain GEMMs over (B*T, d): apply them without the two transposes
         u = ops.linear(x, self.conv1.weight.squeeze(-1), self.conv1.bias)
-        y = self.activation(u)
-        if self.training and self.dropout.p > 0:
-            y = self.dropout(y)
-        y = self.dropout(ops.linear(y, self.conv2.weight.squeeze(-1), self.conv2.bias))
+        drop = self.training and self.dropout.p > 0
+        if self.activation is ops.gelu and not drop:
+            # gelu + second dense layer as one node: the activation's backward runs in the epilogue of the input-gradient GEMM
+            y = ops.gelu_linear(u, self.conv2.weight.squeeze(-1), self.conv2.bias)
+        else:
+            y = self.activation(u)
+            if drop:
+                y = self.dropout(y)
+            y = ops.linear(y, self.conv2.weight.squeeze(-1), self.conv2.bias)
+        y = self.dropout(y)
         return ops.layer_norm(x, self.norm2, residual=y), attn
 
 

@@ -943,3 +943,41 @@ def test_dense_layer_prologue_matches_the_per_layer_route_and_goes_stale_safely(
     y = ops.linear(xs[1], lins[1].weight, lins[1].bias)
     ref = torch.nn.functional.linear(xs[1].double(), lins[1].weight.detach().double(), lins[1].bias.detach().double())
     assert float(lins[1].weight.detach().abs().max()) > 20.0 and torch.isfinite(y).all() and _rel(y, ref) < 3e-6
+
+
+@pytest.mark.parametrize("shape,Ci,Co,bias", [((4, 300, 512), 512, 128, True), ((3, 77, 256), 256, 64, False), ((130, 64), 64, 12, True),
+                                              ((2, 50, 768), 768, 256, True)])
+@pytest.mark.parametrize("gmath", ["f16x3", "bf16x6"])
+def test_gelu_linear_against_float64(shape, Ci, Co, bias, gmath, monkeypatch):
+    """ops.gelu_linear(u, W, b) = linear(gelu(u)): output, dL/du (the GELU derivative applied in the epilogue of the input-gradient
+    GEMM where d_ff % 256 == 0 on the f16x3 arithmetic, torch's gelu_backward otherwise), dW, db against float64."""
+    dev = _dev()
+    import speech_imagery_eeg_amd  # noqa
+    from ign_hip import ops, _lib
+    monkeypatch.setattr(ops, "GEMM_MATH", gmath)
+    g = torch.Generator().manual_seed(Ci + Co)
+    u = torch.randn(*shape, generator=g) * 1.5
+    w = torch.randn(Co, Ci, generator=g) / Ci ** 0.5
+    b = torch.randn(Co, generator=g) * 0.1 if bias else None
+    gz = torch.randn(*shape[:-1], Co, generator=g)
+    ud, wd = u.double().requires_grad_(True), w.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True) if bias else None
+    zd = F.linear(F.gelu(ud), wd, bd)
+    (zd * gz.double()).sum().backward()
+    ug, wg = u.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    bg = b.to(dev).requires_grad_(True) if bias else None
+    L = _lib.lib()
+    fused_calls = []
+    orig = L.ign_linear_dgrad_gelu_h3
+    L.ign_linear_dgrad_gelu_h3 = lambda *a: (fused_calls.append(1), orig(*a))[1]
+    try:
+        z = ops.gelu_linear(ug, wg, bg)
+        (z * gz.to(dev)).sum().backward()
+    finally:
+        L.ign_linear_dgrad_gelu_h3 = orig
+    assert bool(fused_calls) == (gmath == "f16x3" and Ci % 256 == 0)
+    assert _rel(z, zd) < 3e-6
+    assert _rel(ug.grad, ud.grad) < 5e-6
+    assert _rel(wg.grad, wd.grad) < 5e-6
+    if bias:
+        assert _rel(bg.grad, bd.grad) < 5e-6
